@@ -1,0 +1,82 @@
+// common.h -- shared device/host helpers for libcaspr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/caspr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+void caspr_set_error(const char *fmt, ...);
+
+#define CASPR_REQUIRE(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            caspr_set_error(__VA_ARGS__);   \
+            return CASPR_EINVAL;            \
+        }                                   \
+    } while (0)
+
+#define CASPR_CHECK_LAUNCH(name)                                                        \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) {                                                        \
+            caspr_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return CASPR_ELAUNCH;                                                       \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// MFMA f32 16x16x4 conventions (see DESIGN.md "fragment conventions")
+//
+//   lane l : g = l >> 4 (k sub-index / row quad), j = l & 15 (A row / B,D column)
+//   A operand  : A[i = j][kk = g]      B operand : B[kk = g][col = j]
+//   D[reg r]   : row = 4*g + r, col = j
+//
+// Packed weights ("A-pack"), produced by caspr_pack_weight_f32:
+//   packed[((mt*KC + kc)*64 + l)*4 + q] = W[mt*16 + (l&15)][kc*16 + 4*(l>>4) + q]
+// so one float4 per lane feeds four consecutive MFMA k-steps q = 0..3 of chunk kc, where k-step q
+// contracts k in {kc*16 + 4*kk + q : kk = 0..3}.
+//
+// LDS operand tiles ("B-tile") are stored as [kq = k/4][col][4] with the 16-byte slot XOR-swizzled
+// by kq so that both the 16-B fragment reads (lane (g,j) reads kq = 4*kc+g, col = 16*ct+j) and the
+// 16-B epilogue writes are bank-conflict free:
+//   float offset = (kq*NCOL + (col ^ (kq & 15))) * 4
+// The D fragment of row tile mt is exactly the float4 at kq = 4*mt + g, col = 16*ct + j of the next
+// layer's B-tile, so chained layers never shuffle data between lanes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int btile_off(int kq, int col, int ncol)
+{
+    return (kq * ncol + (col ^ (kq & 15))) << 2;
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// softplus (beta=1, threshold=20) as torch.nn.Softplus: odefunc.py:55 NONLINEARITIES["softplus"]
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Hot-loop variants for the CNF epilogues, built on the 1-ulp hardware v_exp_f32 / v_log_f32 / v_rcp_f32:
+//   softplus(x) = max(x,0) + log1p(u), u = exp(-|x|) in (0,1];  log1p(u) = log(w) * u / (w - 1), w = fl(1+u)
+// (the classic compensated form: a few ulp relative on log1p for every u, ~14 VALU instead of ~60).
+__device__ __forceinline__ float softplus_fast(float x)
+{
+    const float u = __expf(-fabsf(x));
+    const float w = 1.0f + u;
+    const float d = w - 1.0f;
+    const float r = (d == 0.0f) ? u : __logf(w) * __fdividef(u, d);
+    return fmaxf(x, 0.0f) + r;
+}
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

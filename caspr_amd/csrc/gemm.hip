@@ -1,0 +1,348 @@
+// gemm.hip -- pointwise convolution (nn.Conv1d k=1 / nn.Linear) on the f32 MFMA pipe of gfx950,
+// weight packing, and GroupNorm statistics.  Replaces the cuDNN/cuBLAS calls behind
+// models/pointnet.py:37-41, models/pointnet2.py:525,247 and models/tpointnet2.py:99-105.
+//
+// conv1x1: Y[b,p,co] = act(sum_k W[co,k] * in(X[b,p,k]) + bias[co] + bbias[b,co]).
+//   Block tile 128 (co) x 128 (points), K tile 32, 256 threads = 2x2 waves of 64x64 (4x4 MFMA
+//   16x16x4 tiles, 64 accumulator VGPRs).  The point operand is staged through a double-buffered,
+//   XOR-swizzled LDS B-tile (register staging, so the previous layer's GroupNorm+ReLU is applied
+//   on the fly: one pass over the activations instead of three).  Weights are read straight from
+//   the packed A-fragment stream (one coalesced 1-KiB dwordx4 load per wave per 16x16 tile per
+//   16 k), prefetched one chunk ahead: they never touch LDS.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// packing
+// ---------------------------------------------------------------------------------------------
+extern "C" long caspr_packed_size(int Cout, int Cin)
+{
+    const long mt = (Cout + 15) / 16, kc = 2L * ((Cin + 31) / 32);
+    return mt * kc * 256;
+}
+
+__global__ void pack_weight_kernel(const float *__restrict__ w, int ldw, int Cout, int col0, int ncols, int KC,
+                                   float *__restrict__ packed, long total)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int q = (int)(t & 3), l = (int)((t >> 2) & 63);
+    const long tile = t >> 8;
+    const int kc = (int)(tile % KC), mt = (int)(tile / KC);
+    const int row = mt * 16 + (l & 15), k = kc * 16 + 4 * (l >> 4) + q;
+    packed[t] = (row < Cout && k < ncols) ? w[(long)row * ldw + col0 + k] : 0.0f;
+}
+
+extern "C" int caspr_pack_weight_f32(const float *w, int ldw, int Cout, int col0, int ncols, float *packed,
+                                     void *stream)
+{
+    CASPR_REQUIRE(w && packed && Cout > 0 && ncols > 0 && col0 >= 0 && ldw >= col0 + ncols,
+                  "pack_weight: bad arguments");
+    const int KC = 2 * ((ncols + 31) / 32);
+    const long total = caspr_packed_size(Cout, ncols);
+    pack_weight_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        w, ldw, Cout, col0, ncols, KC, packed, total);
+    CASPR_CHECK_LAUNCH("pack_weight");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv1x1
+// ---------------------------------------------------------------------------------------------
+#define GEMM_MT 128
+#define GEMM_NT 128
+#define GEMM_KT 32
+
+__global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
+                                                      const float *__restrict__ bbias, const float *__restrict__ X,
+                                                      int ldx, const float *__restrict__ in_scale,
+                                                      const float *__restrict__ in_shift, int in_relu,
+                                                      int relu_from, float *__restrict__ Y, int ldy, int P, int Cin,
+                                                      int Cout, int act)
+{
+    __shared__ __attribute__((aligned(16))) float sB[2][8 * GEMM_NT * 4];  // 2 x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.y * GEMM_NT;
+    const int co0 = blockIdx.x * GEMM_MT;
+    const int KC = 2 * ((Cin + 31) / 32);
+    const int MT16 = (Cout + 15) / 16;
+    const int ntiles = KC / 2;
+
+    const float *Xb = X + (long)b * P * ldx;
+    const float *sc = in_scale ? in_scale + (long)b * Cin : nullptr;
+    const float *sh = in_scale ? in_shift + (long)b * Cin : nullptr;
+
+    // which 16-row tiles of the packed stream this wave owns (wave-uniform validity)
+    const int mt0 = (co0 >> 4) + wm * 4;
+    const float *wbase[4];
+    bool mvalid[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        mvalid[mi] = (mt0 + mi) < MT16;
+        wbase[mi] = wp + ((long)(mvalid[mi] ? mt0 + mi : 0) * KC) * 256 + lane * 4;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging assignment: float4 f = tid + 256*i  ->  kq = f & 7, col = f >> 3
+    f32x4 stage[4];
+    auto load_stage = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            const int kq = f & 7, col = f >> 3;
+            const int k = kt * GEMM_KT + kq * 4;
+            const int p = p0 + col;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < P && k < Cin) {
+                v = ld4(Xb + (long)p * ldx + k);  // ldx >= roundup4(Cin): the tail quad is readable
+                if (sc) {
+                    const f32x4 s4 = ld4(sc + k), t4 = ld4(sh + k);  // scale/shift rows are padded to 4
+                    v = v * s4 + t4;
+                    if (in_relu && k >= relu_from) {  // relu_from % 4 == 0
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k + q >= Cin) v[q] = 0.f;
+            }
+            stage[i] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            const int kq = f & 7, col = f >> 3;
+            st4(&sB[buf][btile_off(kq, col, GEMM_NT)], stage[i]);
+        }
+    };
+
+    f32x4 a_cur[4], a_nxt[4];
+    auto load_a = [&](f32x4(&a)[4], int kc) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a[mi] = ld4(wbase[mi] + (long)kc * 256);
+    };
+
+    load_stage(0);
+    load_a(a_cur, 0);
+    store_stage(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) load_stage(kt + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int kc = kt * 2 + c;
+            if (kc + 1 < KC) load_a(a_nxt, kc + 1);
+            f32x4 bf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                bf[ni] = ld4(&sB[buf][btile_off(c * 4 + g, wn * 64 + ni * 16 + j, GEMM_NT)]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(a_cur[mi][q], bf[ni][q], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a_cur[mi] = a_nxt[mi];
+        }
+        if (kt + 1 < ntiles) {
+            store_stage(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane holds co = co0 + wm*64 + mi*16 + 4g + r (r = 0..3) for point p0 + wn*64 + ni*16 + j
+    const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        if (!mvalid[mi]) continue;
+        const int co = co0 + wm * 64 + mi * 16 + 4 * g;
+        float add[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+            if (co + r < Cout) {
+                if (bias) v += bias[co + r];
+                if (bb) v += bb[co + r];
+            }
+            add[r] = v;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int p = p0 + wn * 64 + ni * 16 + j;
+            if (p >= P) continue;
+            f32x4 v = acc[mi][ni];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] += add[r];
+                if (act == 1) v[r] = sigmoid_f(v[r]);
+            }
+            float *dst = Y + ((long)b * P + p) * ldy + co;
+            if (co + 3 < Cout) {
+                st4(dst, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < Cout) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float *bbias, const float *X, int ldx,
+                                 const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
+                                 int ldy, int B, int P, int Cin, int Cout, int act, void *stream)
+{
+    CASPR_REQUIRE(wp && X && Y && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1: bad arguments");
+    CASPR_REQUIRE(ldx % 4 == 0 && ldx >= ((Cin + 3) & ~3), "conv1x1: ldx=%d must be a multiple of 4 and >= roundup4(Cin=%d)", ldx, Cin);
+    CASPR_REQUIRE(ldy % 4 == 0 && ldy >= Cout, "conv1x1: ldy=%d must be a multiple of 4 and >= Cout=%d", ldy, Cout);
+    CASPR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1: in_scale/in_shift must be given together");
+    CASPR_REQUIRE(in_scale == nullptr || Cin % 4 == 0, "conv1x1: fused input GroupNorm needs Cin %% 4 == 0 (Cin=%d)", Cin);
+    CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wp % 16) == 0, "conv1x1: pointers must be 16-byte aligned");
+    CASPR_REQUIRE(B <= 65535, "conv1x1: B=%d > 65535", B);
+    CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 4 == 0, "conv1x1: in_relu_from=%d must be a non-negative multiple of 4", in_relu_from);
+    dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, GEMM_NT), B);
+    conv1x1_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
+                                                                in_relu_from, Y, ldy, P, Cin, Cout, act);
+    CASPR_CHECK_LAUNCH("conv1x1");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics (+ optional max over points of the normalised output).
+// Pass 1: grid (G, S, B): one workgroup per (group, point split, batch) accumulates sum / sum of
+// squares in f64 and per-channel max / min.  Pass 2: one thread per (b, c) combines the S partials in
+// a fixed order (deterministic) and emits scale / shift / pmax.
+// ---------------------------------------------------------------------------------------------
+#define GN_SPLIT 1024
+
+extern "C" long caspr_gn_ws_bytes(int B, int P, int C, int G)
+{
+    const long S = (P + GN_SPLIT - 1) / GN_SPLIT;
+    return (long)B * G * S * 16 + (long)B * C * S * 8 + 64;
+}
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict__ Y, int ldy, int P, int C, int G,
+                                                         double *__restrict__ psum, float *__restrict__ pmm)
+{
+    __shared__ double s_sum[256], s_sq[256];
+    __shared__ float s_mx[256 * 4], s_mn[256 * 4];
+    const int g = blockIdx.x, s = blockIdx.y, b = blockIdx.z, S = gridDim.y;
+    const int cpg = C / G, Q4 = cpg >> 2;  // host guarantees cpg % 4 == 0 and Q4 <= 256
+    const int TP = 256 / Q4;
+    const int tq = threadIdx.x % Q4, tp = threadIdx.x / Q4;
+    const int pbeg = s * GN_SPLIT, pend = (pbeg + GN_SPLIT) < P ? (pbeg + GN_SPLIT) : P;
+    double sum = 0.0, sq = 0.0;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    if (tp < TP) {
+        const float *base = Y + (long)b * P * ldy + g * cpg + tq * 4;
+#pragma unroll 4
+        for (int p = pbeg + tp; p < pend; p += TP) {
+            const f32x4 v = ld4(base + (long)p * ldy);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sum += (double)v[q];
+                sq += (double)v[q] * (double)v[q];
+                mx[q] = v[q] > mx[q] ? v[q] : mx[q];
+                mn[q] = v[q] < mn[q] ? v[q] : mn[q];
+            }
+        }
+    }
+    s_sum[threadIdx.x] = sum;
+    s_sq[threadIdx.x] = sq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s_mx[threadIdx.x * 4 + q] = mx[q];
+        s_mn[threadIdx.x * 4 + q] = mn[q];
+    }
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+            s_sq[threadIdx.x] += s_sq[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double *o = psum + (((long)b * G + g) * S + s) * 2;
+        o[0] = s_sum[0];
+        o[1] = s_sq[0];
+    }
+    if (threadIdx.x < cpg) {  // one thread per channel of the group folds the TP row partials
+        const int c = threadIdx.x, q4 = c >> 2, q = c & 3;
+        float m1 = -INFINITY, m0 = INFINITY;
+        for (int r = 0; r < TP; ++r) {
+            const float a = s_mx[(r * Q4 + q4) * 4 + q], bb = s_mn[(r * Q4 + q4) * 4 + q];
+            m1 = a > m1 ? a : m1;
+            m0 = bb < m0 ? bb : m0;
+        }
+        float *o = pmm + (((long)b * C + g * cpg + c) * S + s) * 2;
+        o[0] = m1;
+        o[1] = m0;
+    }
+}
+
+__global__ void gn_finalize_kernel(const double *__restrict__ psum, const float *__restrict__ pmm, int B, int P, int C,
+                                   int G, int S, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float eps, float *__restrict__ scale, float *__restrict__ shift,
+                                   float *__restrict__ pmax)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    const int b = t / C, c = t % C, cpg = C / G, g = c / cpg;
+    double sum = 0.0, sq = 0.0;
+    for (int s = 0; s < S; ++s) {
+        sum += psum[(((long)b * G + g) * S + s) * 2 + 0];
+        sq += psum[(((long)b * G + g) * S + s) * 2 + 1];
+    }
+    const double cnt = (double)P * cpg;
+    const double mean = sum / cnt;
+    double var = sq / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * rstd);
+    const float sf = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+    scale[t] = sc;
+    shift[t] = sf;
+    if (pmax) {
+        float m1 = -INFINITY, m0 = INFINITY;
+        for (int s = 0; s < S; ++s) {
+            const float a = pmm[((long)t * S + s) * 2 + 0], bb = pmm[((long)t * S + s) * 2 + 1];
+            m1 = a > m1 ? a : m1;
+            m0 = bb < m0 ? bb : m0;
+        }
+        pmax[t] = (sc >= 0.f ? m1 : m0) * sc + sf;
+    }
+}
+
+extern "C" int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, int G, const float *gamma,
+                                  const float *beta, float eps, float *scale, float *shift, float *pmax, void *ws,
+                                  long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(Y && gamma && beta && scale && shift && ws && B > 0 && P > 0 && C > 0 && G > 0, "gn_stats: bad arguments");
+    CASPR_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && (C / G) <= 256, "gn_stats: C/G=%d must be a multiple of 4 and <= 256", C / G);
+    CASPR_REQUIRE(ldy % 4 == 0 && ldy >= C && ((uintptr_t)Y % 16) == 0, "gn_stats: ldy=%d must be a multiple of 4 and >= C", ldy);
+    CASPR_REQUIRE(ws_bytes >= caspr_gn_ws_bytes(B, P, C, G), "gn_stats: workspace too small (%ld < %ld)", ws_bytes, caspr_gn_ws_bytes(B, P, C, G));
+    CASPR_REQUIRE(B <= 65535, "gn_stats: B too large");
+    const int S = ceil_div(P, GN_SPLIT);
+    double *psum = (double *)ws;
+    float *pmm = (float *)((char *)ws + (((long)B * G * S * 16 + 63) & ~63L));
+    hipStream_t st = (hipStream_t)stream;
+    gn_partial_kernel<<<dim3(G, S, B), dim3(256), 0, st>>>(Y, ldy, P, C, G, psum, pmm);
+    gn_finalize_kernel<<<dim3(ceil_div(B * C, 256)), dim3(256), 0, st>>>(psum, pmm, B, P, C, G, S, gamma, beta, eps, scale,
+                                                                         shift, pmax);
+    CASPR_CHECK_LAUNCH("gn_stats");
+    return CASPR_OK;
+}

@@ -1,0 +1,431 @@
+// ode.hip -- the "advect" and "sample" stages for gfx950: fixed-step RK4 of the latent dynamics net
+// (models/latent_ode_model.py:45-70,139-147) and of the point CNF's gated ODE function
+// (models/cnf.py:70-128, odefunc.py:98-142, diffeq_layers.py:83-90, normalization.py:59-108).
+//
+// cnf_rk4_kernel: ONE launch integrates the whole flow.  A 512-thread workgroup owns 64 columns of
+// one frame (64 points when sampling; 32 points + their 32 Hutchinson tangents when the divergence
+// is integrated).  The 512 x 64 hidden activation lives in LDS as an XOR-swizzled MFMA B-tile
+// (128 KiB); each of the 8 waves owns 64 hidden units x 64 columns (64 accumulator VGPRs) and
+// streams its slice of the packed 512x512 weights straight from L2 into A fragments (prefetched
+// one 16-k chunk ahead).  ConcatSquash gate/bias, softplus, the 3->512 input layer and the
+// 512->3 output layer (fused into the last hidden layer's epilogue as a register-level partial dot
+// product) never leave the CU.  The divergence uses the forward-mode identity
+// e^T (df/dy)^T e == e^T (df/dy) e: tangents ride along as 32 extra columns of the same GEMMs.
+#include "common.h"
+
+#define CNF_H 512
+#define CNF_NCOL 64
+#define CNF_KC (CNF_H / 16)  // 32 chunks of 16 k
+
+// ---------------------------------------------------------------------------------------------
+// latent ODE
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void latent_rk4_kernel(const float *__restrict__ z0, int ldz,
+                                                         const float *__restrict__ times, int Tu, int D, int H,
+                                                         int steps, const float *__restrict__ w0t,
+                                                         const float *__restrict__ b0, const float *__restrict__ w1t,
+                                                         const float *__restrict__ b1, const float *__restrict__ w2t,
+                                                         const float *__restrict__ b2, const float *__restrict__ w3t,
+                                                         const float *__restrict__ b3, float *__restrict__ out)
+{
+    __shared__ float s_in[64], s_h1[512], s_h2[512], s_part[8][64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int o = tid & 63, part = tid >> 6;
+    float z = 0.f, acc = 0.f, k = 0.f;
+    if (tid < D) {
+        z = z0[(long)b * ldz + tid];
+        out[((long)b * Tu) * D + tid] = z;
+    }
+    auto dyn = [&]() {  // s_in -> k (valid for tid < D); all threads participate
+        __syncthreads();
+        if (tid < H) {
+            float s = 0.f;
+            for (int kk = 0; kk < D; ++kk) s += w0t[kk * H + tid] * s_in[kk];
+            s_h1[tid] = tanhf(s + b0[tid]);
+        }
+        __syncthreads();
+        if (tid < H) {
+            float s = 0.f;
+            for (int kk = 0; kk < H; ++kk) s += w1t[kk * H + tid] * s_h1[kk];
+            s_h2[tid] = tanhf(s + b1[tid]);
+        }
+        __syncthreads();
+        if (tid < H) {
+            float s = 0.f;
+            for (int kk = 0; kk < H; ++kk) s += w2t[kk * H + tid] * s_h2[kk];
+            s_h1[tid] = tanhf(s + b2[tid]);
+        }
+        __syncthreads();
+        {
+            float s = 0.f;
+            if (o < D) {
+                const int chunk = (H + 7) / 8;
+                const int k0 = part * chunk, k1 = (k0 + chunk) < H ? (k0 + chunk) : H;
+                for (int kk = k0; kk < k1; ++kk) s += w3t[kk * D + o] * s_h1[kk];
+            }
+            s_part[part][o] = s;
+        }
+        __syncthreads();
+        if (tid < D) {
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) s += s_part[p][tid];
+            k = s + b3[tid];
+        }
+    };
+    const float t_first = times[0];
+    for (int ti = 1; ti < Tu; ++ti) {
+        const float r0 = times[ti - 1] - t_first, r1 = times[ti] - t_first;  // latent_ode_model.py:58
+        const double h = ((double)r1 - (double)r0) / (double)steps;
+        const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
+        for (int s = 0; s < steps; ++s) {
+            if (tid < D) s_in[tid] = z;
+            dyn();
+            acc = k;
+            __syncthreads();
+            if (tid < D) s_in[tid] = z + h2 * k;
+            dyn();
+            acc = acc + 2.0f * k;
+            __syncthreads();
+            if (tid < D) s_in[tid] = z + h2 * k;
+            dyn();
+            acc = acc + 2.0f * k;
+            __syncthreads();
+            if (tid < D) s_in[tid] = z + hh * k;
+            dyn();
+            acc = acc + k;
+            z = z + h6 * acc;
+            __syncthreads();
+        }
+        if (tid < D) out[((long)b * Tu + ti) * D + tid] = z;
+    }
+}
+
+extern "C" int caspr_latent_rk4_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H,
+                                    int steps, const float *w0t, const float *b0, const float *w1t, const float *b1,
+                                    const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
+                                    void *stream)
+{
+    CASPR_REQUIRE(z0 && times && out && w0t && w1t && w2t && w3t && b0 && b1 && b2 && b3, "latent_rk4: null pointer");
+    CASPR_REQUIRE(B > 0 && Tu > 0 && steps > 0 && D > 0 && D <= 64 && H > 0 && H <= 512 && ldz >= D,
+                  "latent_rk4: unsupported sizes D=%d H=%d (need D<=64, H<=512)", D, H);
+    latent_rk4_kernel<<<dim3(B), dim3(512), 0, (hipStream_t)stream>>>(z0, ldz, times, Tu, D, H, steps, w0t, b0, w1t, b1,
+                                                                      w2t, b2, w3t, b3, out);
+    CASPR_CHECK_LAUNCH("latent_rk4");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// point CNF
+// ---------------------------------------------------------------------------------------------
+struct CnfArgs {
+    const float *y_in, *hyper, *tcol, *w0, *b0, *w1p, *b1, *w2p, *b2, *w3, *b3, *mbn_in, *mbn_out, *e, *logp_in;
+    float *logp_out, *y_out;
+    int ldh, n, steps, reverse;
+    float t_end;
+};
+
+// one hidden layer: acc[mi][ct] = sum_k W[64*wave + 16*mi + row][k] * Hbuf[k][16*ct + col]
+__device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, const float *Hbuf, int wave, int lane,
+                                               f32x4 (&acc)[4][4])
+{
+    const int g = lane >> 4, j = lane & 15;
+    const float *wb = wp + ((long)(wave * 4) * CNF_KC) * 256 + lane * 4;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[mi][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a_cur[4], a_nxt[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a_cur[mi] = ld4(wb + (long)mi * CNF_KC * 256);
+#pragma unroll 1
+    for (int kc = 0; kc < CNF_KC; ++kc) {
+        const int kn = (kc + 1 < CNF_KC) ? kc + 1 : kc;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a_nxt[mi] = ld4(wb + ((long)mi * CNF_KC + kn) * 256);
+        f32x4 bf[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) bf[ct] = ld4(Hbuf + btile_off(kc * 4 + g, ct * 16 + j, CNF_NCOL));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[mi][ct] = mfma16(a_cur[mi][q], bf[ct][q], acc[mi][ct]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a_cur[mi] = a_nxt[mi];
+    }
+}
+
+template <bool WITH_DIV>
+__global__ __launch_bounds__(512) void cnf_rk4_kernel(CnfArgs a)
+{
+    constexpr int PT = WITH_DIV ? 32 : 64;  // points per workgroup (the other 32 columns are tangents)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Hbuf = smem;                           // [128 kq][64 col][4]        128 KiB
+    float *s_gate = Hbuf + (CNF_H / 4) * CNF_NCOL * 4;  // [3][512] sigmoid gate per hidden layer
+    float *s_hb = s_gate + 3 * CNF_H;             // [3][512] layer bias*gate + hyper bias
+    float *s_w3 = s_hb + 3 * CNF_H;               // [3][512] output layer weights
+    float *s_red = s_w3 + 3 * CNF_H;              // [8][3][64] per-wave partial outputs
+    float *s_ys = s_red + 8 * 3 * CNF_NCOL;       // [64][4] stage input (value cols) / e (tangent cols)
+    float *s_out = s_ys + CNF_NCOL * 4;           // [3][64] stage output dy / J e
+    float *s_g3 = s_out + 3 * CNF_NCOL;           // [8]: gate3[3], hb3[3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int bt = blockIdx.y;
+    const int p0 = blockIdx.x * PT;
+    const float *hy = a.hyper + (long)bt * a.ldh;
+    constexpr int GOFF = 0, BOFF = 3 * CNF_H + 3;  // column offsets of the gate / bias blocks
+
+    // ---- per-thread constants: input layer rows 4*kq0 .. +3 (kq0 = tid & 127), column group tid >> 7
+    const int kq0 = tid & 127, cg0 = tid >> 7;
+    float w0r[4][3], b0r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = kq0 * 4 + q;
+        w0r[q][0] = a.w0[co * 3 + 0];
+        w0r[q][1] = a.w0[co * 3 + 1];
+        w0r[q][2] = a.w0[co * 3 + 2];
+        b0r[q] = a.b0[co];
+    }
+    for (int i = tid; i < 3 * CNF_H; i += 512) s_w3[i] = a.w3[i];
+
+    // ---- state: thread (d = tid / 64, col = tid % 64), tid < 192
+    const int sd = tid >> 6, scol = tid & 63;
+    const bool is_state = tid < 192 && scol < PT;
+    const int spt = p0 + scol;
+    const bool pvalid = is_state && spt < a.n;
+    float y = 0.f, kacc = 0.f, ev = 0.f;
+    float lp = 0.f, lacc = 0.f;  // log-density state, owned by tid < PT (sd == 0)
+    if (pvalid) {
+        float v = a.y_in[((long)bt * a.n + spt) * 3 + sd];
+        if (a.mbn_in) {
+            const float w = a.mbn_in[sd], bb = a.mbn_in[3 + sd], mean = a.mbn_in[6 + sd], var = a.mbn_in[9 + sd];
+            if (a.reverse) v = (v - bb) * expf(-w) * expf(0.5f * logf(var + 1e-4f)) + mean;   // normalization.py:92-94
+            else v = (v - mean) * expf(-0.5f * logf(var + 1e-4f)) * expf(w) + bb;             // normalization.py:70-74
+        }
+        y = v;
+        if (WITH_DIV) ev = a.e[((long)bt * a.n + spt) * 3 + sd];
+    }
+    if (WITH_DIV) {
+        if (tid < PT && p0 + tid < a.n) {
+            lp = a.logp_in ? a.logp_in[(long)bt * a.n + p0 + tid] : 0.f;
+            if (a.mbn_in) {
+                float ld = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) ld += -0.5f * logf(a.mbn_in[9 + d] + 1e-4f) + a.mbn_in[d];  // :103-108
+                lp = a.reverse ? lp + ld : lp - ld;
+            }
+        }
+        // tangent seed e sits in the tangent columns of s_ys for the whole solve
+        if (is_state) s_ys[(PT + scol) * 4 + sd] = ev;
+    }
+
+    const double t0 = a.reverse ? (double)a.t_end : 0.0, t1 = a.reverse ? 0.0 : (double)a.t_end;
+    const double h = (t1 - t0) / (double)a.steps;
+    const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
+    float kprev = 0.f;
+
+    for (int step = 0; step < a.steps; ++step) {
+#pragma unroll 1
+        for (int stage = 0; stage < 4; ++stage) {
+            const double tc = (stage == 0) ? 0.0 : (stage == 3 ? 1.0 : 0.5);
+            const float t = (float)(t0 + (double)step * h + tc * h);
+            const float aw = (stage == 0) ? 0.f : (stage == 3 ? hh : h2);
+            // ---- stage input + gates
+            if (is_state) s_ys[scol * 4 + sd] = (stage == 0) ? y : y + aw * kprev;
+            for (int i = tid; i < 3 * CNF_H; i += 512) {
+                const float gt = sigmoid_fast(hy[GOFF + i] + t * a.tcol[GOFF + i]);
+                const float hb = hy[BOFF + i] + t * a.tcol[BOFF + i];
+                const float bl = (i < CNF_H) ? a.b0[i] : (i < 2 * CNF_H ? a.b1[i - CNF_H] : a.b2[i - 2 * CNF_H]);
+                s_gate[i] = gt;
+                s_hb[i] = bl * gt + hb;
+            }
+            if (tid < 3) {
+                const float gt = sigmoid_fast(hy[GOFF + 3 * CNF_H + tid] + t * a.tcol[GOFF + 3 * CNF_H + tid]);
+                const float hb = hy[BOFF + 3 * CNF_H + tid] + t * a.tcol[BOFF + 3 * CNF_H + tid];
+                s_g3[tid] = gt;
+                s_g3[4 + tid] = a.b3[tid] * gt + hb;
+            }
+            __syncthreads();
+            // ---- input layer 3 -> 512 straight into the B-tile (diffeq_layers.py:83-90 + softplus)
+            {
+                float gt[4], hb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gt[q] = s_gate[kq0 * 4 + q];
+                    hb[q] = s_hb[kq0 * 4 + q];
+                }
+#pragma unroll 4
+                for (int c = 0; c < 16; ++c) {
+                    const int col = cg0 * 16 + c;
+                    const f32x4 in = ld4(s_ys + col * 4);
+                    f32x4 v;
+                    if (!WITH_DIV || col < PT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float pre = (w0r[q][0] * in[0] + w0r[q][1] * in[1] + w0r[q][2] * in[2]) * gt[q] + hb[q];
+                            v[q] = softplus_fast(pre);
+                        }
+                    } else {
+                        const f32x4 yv = ld4(s_ys + (col - PT) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float pre = (w0r[q][0] * yv[0] + w0r[q][1] * yv[1] + w0r[q][2] * yv[2]) * gt[q] + hb[q];
+                            const float tg = (w0r[q][0] * in[0] + w0r[q][1] * in[1] + w0r[q][2] * in[2]) * gt[q];
+                            v[q] = tg * sigmoid_fast(pre);
+                        }
+                    }
+                    st4(Hbuf + btile_off(kq0, col, CNF_NCOL), v);
+                }
+            }
+            __syncthreads();
+
+            f32x4 acc[4][4];
+            // ---- hidden layer 1
+            cnf_mfma_layer(a.w1p, Hbuf, wave, lane, acc);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int co = (wave * 4 + mi) * 16 + 4 * g;
+                const f32x4 gt = ld4(s_gate + CNF_H + co), hb = ld4(s_hb + CNF_H + co);
+#pragma unroll
+                for (int ct = 0; ct < (WITH_DIV ? 2 : 4); ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pre = acc[mi][ct][r] * gt[r] + hb[r];
+                        acc[mi][ct][r] = softplus_fast(pre);
+                        if (WITH_DIV) acc[mi][ct + 2][r] = acc[mi][ct + 2][r] * gt[r] * sigmoid_fast(pre);
+                    }
+            }
+            __syncthreads();  // every wave has finished reading Hbuf
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    st4(Hbuf + btile_off((wave * 4 + mi) * 4 + g, ct * 16 + j, CNF_NCOL), acc[mi][ct]);
+            __syncthreads();
+            // ---- hidden layer 2 + fused output layer 512 -> 3
+            cnf_mfma_layer(a.w2p, Hbuf, wave, lane, acc);
+            float part[3][4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) part[d][ct] = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int co = (wave * 4 + mi) * 16 + 4 * g;
+                const f32x4 gt = ld4(s_gate + 2 * CNF_H + co), hb = ld4(s_hb + 2 * CNF_H + co);
+                const f32x4 wx = ld4(s_w3 + co), wy = ld4(s_w3 + CNF_H + co), wz = ld4(s_w3 + 2 * CNF_H + co);
+#pragma unroll
+                for (int ct = 0; ct < (WITH_DIV ? 2 : 4); ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pre = acc[mi][ct][r] * gt[r] + hb[r];
+                        const float hv = softplus_fast(pre);
+                        part[0][ct] += wx[r] * hv;
+                        part[1][ct] += wy[r] * hv;
+                        part[2][ct] += wz[r] * hv;
+                        if (WITH_DIV) {
+                            const float tv = acc[mi][ct + 2][r] * gt[r] * sigmoid_fast(pre);
+                            part[0][ct + 2] += wx[r] * tv;
+                            part[1][ct + 2] += wy[r] * tv;
+                            part[2][ct + 2] += wz[r] * tv;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    float v = part[d][ct];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (g == 0) s_red[(wave * 3 + d) * CNF_NCOL + ct * 16 + j] = v;
+                }
+            __syncthreads();
+            // ---- combine the 8 wave partials, apply the output ConcatSquash (no softplus: odefunc.py:103)
+            if (tid < 192) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s += s_red[(w * 3 + sd) * CNF_NCOL + scol];
+                float o;
+                if (!WITH_DIV || scol < PT) o = s * s_g3[sd] + s_g3[4 + sd];
+                else o = s * s_g3[sd];
+                if (WITH_DIV) s_out[sd * CNF_NCOL + scol] = o;
+                if (is_state) {
+                    kprev = o;
+                    kacc = (stage == 0) ? o : ((stage == 3) ? kacc + o : kacc + 2.0f * o);
+                }
+            }
+            if (WITH_DIV) {
+                __syncthreads();
+                if (tid < PT) {
+                    // -divergence = -(e . J e)   (odefunc.py:26,136)
+                    float dv = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) dv += s_ys[(PT + tid) * 4 + d] * s_out[d * CNF_NCOL + PT + tid];
+                    const float o = -dv;
+                    lacc = (stage == 0) ? o : ((stage == 3) ? lacc + o : lacc + 2.0f * o);
+                }
+            }
+            __syncthreads();
+        }
+        if (is_state) y = y + h6 * kacc;
+        if (WITH_DIV && tid < PT) lp = lp + h6 * lacc;
+    }
+
+    if (pvalid) {
+        float v = y;
+        if (a.mbn_out) {
+            const float w = a.mbn_out[sd], bb = a.mbn_out[3 + sd], mean = a.mbn_out[6 + sd], var = a.mbn_out[9 + sd];
+            if (a.reverse) v = (v - bb) * expf(-w) * expf(0.5f * logf(var + 1e-4f)) + mean;
+            else v = (v - mean) * expf(-0.5f * logf(var + 1e-4f)) * expf(w) + bb;
+        }
+        a.y_out[((long)bt * a.n + spt) * 3 + sd] = v;
+    }
+    if (WITH_DIV && tid < PT && p0 + tid < a.n) {
+        if (a.mbn_out) {
+            float ld = 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) ld += -0.5f * logf(a.mbn_out[9 + d] + 1e-4f) + a.mbn_out[d];
+            lp = a.reverse ? lp + ld : lp - ld;
+        }
+        a.logp_out[(long)bt * a.n + p0 + tid] = lp;
+    }
+}
+
+extern "C" int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const float *tcol, const float *w0,
+                                 const float *b0, const float *w1p, const float *b1, const float *w2p, const float *b2,
+                                 const float *w3, const float *b3, int H, float t_end, int steps, int reverse,
+                                 const float *mbn_in, const float *mbn_out, const float *e, const float *logp_in,
+                                 float *logp_out, float *y_out, int BT, int n, void *stream)
+{
+    CASPR_REQUIRE(y_in && hyper && tcol && w0 && b0 && w1p && b1 && w2p && b2 && w3 && b3 && y_out, "cnf_rk4: null pointer");
+    CASPR_REQUIRE(H == CNF_H, "cnf_rk4: hidden width %d unsupported (kernel is built for 512-512-512, flow.py:89)", H);
+    CASPR_REQUIRE(BT > 0 && BT <= 65535 && n > 0 && steps > 0 && ldh >= 2 * (3 * H + 3), "cnf_rk4: bad sizes");
+    CASPR_REQUIRE((e == nullptr) == (logp_out == nullptr), "cnf_rk4: e and logp_out must be given together");
+    CASPR_REQUIRE(((uintptr_t)w1p % 16) == 0 && ((uintptr_t)w2p % 16) == 0, "cnf_rk4: packed weights must be 16-byte aligned");
+    CnfArgs a;
+    a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.w1p = w1p; a.b1 = b1; a.w2p = w2p; a.b2 = b2;
+    a.w3 = w3; a.b3 = b3; a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.e = e; a.logp_in = logp_in; a.logp_out = logp_out;
+    a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
+    const size_t shmem = ((size_t)(CNF_H / 4) * CNF_NCOL * 4 + 9 * CNF_H + 8 * 3 * CNF_NCOL + CNF_NCOL * 4 + 3 * CNF_NCOL + 8) * 4;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err;
+    if (e) {
+        auto kern = cnf_rk4_kernel<true>;
+        err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (err == hipSuccess) kern<<<dim3(ceil_div(n, 32), BT), dim3(512), shmem, st>>>(a);
+    } else {
+        auto kern = cnf_rk4_kernel<false>;
+        err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (err == hipSuccess) kern<<<dim3(ceil_div(n, 64), BT), dim3(512), shmem, st>>>(a);
+    }
+    if (err != hipSuccess) {
+        caspr_set_error("cnf_rk4: hipFuncSetAttribute(%zu) failed: %s", shmem, hipGetErrorString(err));
+        return CASPR_ELAUNCH;
+    }
+    CASPR_CHECK_LAUNCH("cnf_rk4");
+    return CASPR_OK;
+}

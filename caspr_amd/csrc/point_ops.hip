@@ -1,0 +1,454 @@
+// point_ops.hip -- index / gather kernels of the TPointNet++ set-abstraction and feature-propagation
+// stack for gfx950: farthest point sampling, ball query, grouping, three-NN, three-interpolate,
+// Chamfer, input preparation.  HBM/LDS-bound integer + f32-compare work: wave64 ballot / shuffle
+// reductions, clouds resident in registers / LDS.  Compiled with -ffp-contract=off: the squared
+// distances must round exactly like oracle/point_ops.c (every op rounded to f32, no FMA) because
+// the integer outputs are compared bit-exactly.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void caspr_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *caspr_last_error_string(void) { return g_err; }
+extern "C" int caspr_abi_version(void) { return 1; }
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// input preparation (tpointnet2.py:79-90)
+// ---------------------------------------------------------------------------------------------
+__global__ void prep_input_kernel(const float *__restrict__ x, long total, int quad, int pairs,
+                                  float *__restrict__ xyz, float *__restrict__ feat)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const f32x4 v = ld4(x + i * 4);
+    xyz[i * 3 + 0] = v[0];
+    xyz[i * 3 + 1] = v[1];
+    xyz[i * 3 + 2] = v[2];
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int c = 0;
+    if (quad) {
+        f[0] = v[0] * v[0];
+        f[1] = v[1] * v[1];
+        f[2] = v[2] * v[2];
+        c = 3;
+    }
+    if (pairs) {
+        f[c + 0] = v[0] * v[2];  // xz
+        f[c + 1] = v[0] * v[1];  // xy
+        f[c + 2] = v[2] * v[1];  // yz
+    }
+    f32x4 a = {f[0], f[1], f[2], f[3]}, b = {f[4], f[5], f[6], f[7]};
+    st4(feat + i * 8, a);
+    st4(feat + i * 8 + 4, b);
+}
+
+extern "C" int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int pairs, float *xyz,
+                                    float *feat, void *stream)
+{
+    CASPR_REQUIRE(x && xyz && feat && BT > 0 && N > 0, "prep_input: bad arguments");
+    const long total = (long)BT * N;
+    prep_input_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        x, total, quad, pairs, xyz, feat);
+    CASPR_CHECK_LAUNCH("prep_input");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// farthest point sampling (pointnet2.py:384).  One 256-thread workgroup per cloud; the cloud and
+// the running min-distance live in registers (PPT points per thread, point k = tid + 256*i), a
+// copy of xyz in LDS serves the "last selected point" broadcast.  Arg-max key = 64-bit
+// (f32 bits of the distance + 1) << 32 | ~((k mod bs) << 16 | k): max over keys reproduces the
+// oracle's total order (value desc, k mod bs asc, k asc); 0 is the identity (best=-1, besti=0).
+// Wave reduction by xor-shuffles, 4 wave results through a double-buffered LDS slot: one
+// barrier per round.
+// ---------------------------------------------------------------------------------------------
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz, int n, int M, int bs,
+                                                  int guard, int32_t *__restrict__ idx,
+                                                  float *__restrict__ new_xyz)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sx = smem;  // n*3
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(smem + ((n * 3 + 3) & ~3));  // [2][4]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *p = xyz + (long)b * n * 3;
+    for (int i = tid; i < n * 3; i += 256) sx[i] = p[i];
+    __syncthreads();
+
+    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    bool ok[PPT];
+    unsigned kkey[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + 256 * i;
+        const bool in = k < n;
+        px[i] = in ? sx[k * 3 + 0] : 0.f;
+        py[i] = in ? sx[k * 3 + 1] : 0.f;
+        pz[i] = in ? sx[k * 3 + 2] : 0.f;
+        tmp[i] = 1e10f;
+        const float xx = px[i] * px[i], yy = py[i] * py[i], zz = pz[i] * pz[i];
+        const float m0 = xx + yy;
+        const float mag = m0 + zz;
+        ok[i] = in && !(guard && mag <= 1e-3f);
+        kkey[i] = ~((((unsigned)k & (unsigned)(bs - 1)) << 16) | (unsigned)k);
+    }
+    int32_t *out = idx + (long)b * M;
+    float *oxyz = new_xyz ? new_xyz + (long)b * M * 3 : nullptr;
+    int old = 0;
+    if (tid == 0) {
+        out[0] = 0;
+        if (oxyz) { oxyz[0] = sx[0]; oxyz[1] = sx[1]; oxyz[2] = sx[2]; }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = 1; j < M; ++j) {
+        const float x1 = sx[old * 3 + 0], y1 = sx[old * 3 + 1], z1 = sx[old * 3 + 2];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            if (ok[i]) {
+                const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
+                const float d2 = d < tmp[i] ? d : tmp[i];
+                tmp[i] = d2;
+                const unsigned long long key =
+                    ((unsigned long long)(__float_as_uint(d2) + 1u) << 32) | (unsigned long long)kkey[i];
+                best = key > best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)best, off);
+            const unsigned hi = __shfl_xor((unsigned)(best >> 32), off);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            best = o > best ? o : best;
+        }
+        unsigned long long *s = slot + (j & 1) * 4;
+        if (lane == 0) s[wave] = best;
+        __syncthreads();
+        unsigned long long m = s[0];
+        m = s[1] > m ? s[1] : m;
+        m = s[2] > m ? s[2] : m;
+        m = s[3] > m ? s[3] : m;
+        old = (m == 0ull) ? 0 : (int)((~(unsigned)m) & 0xffffu);
+        if (tid == 0) {
+            out[j] = old;
+            if (oxyz) {
+                oxyz[j * 3 + 0] = sx[old * 3 + 0];
+                oxyz[j * 3 + 1] = sx[old * 3 + 1];
+                oxyz[j * 3 + 2] = sx[old * 3 + 2];
+            }
+        }
+    }
+}
+
+static int fps_block_size(int n)
+{
+    int bs = 1;
+    while (bs * 2 <= n && bs * 2 <= 512) bs *= 2;
+    return bs;
+}
+
+extern "C" int caspr_fps_f32(const float *xyz, int B, int n, int M, int guard, int32_t *idx,
+                             float *new_xyz, void *stream)
+{
+    CASPR_REQUIRE(xyz && idx && B > 0 && n > 0 && M > 0, "fps: bad arguments");
+    CASPR_REQUIRE(n <= 4096, "fps: n=%d > 4096 unsupported", n);
+    const int bs = fps_block_size(n);
+    const size_t sh = (size_t)((n * 3 + 3) & ~3) * 4 + 64;
+    hipStream_t st = (hipStream_t)stream;
+    const int ppt = ceil_div(n, 256);
+#define FPS_LAUNCH(P) fps_kernel<P><<<dim3(B), dim3(256), sh, st>>>(xyz, n, M, bs, guard, idx, new_xyz)
+    if (ppt <= 1) FPS_LAUNCH(1);
+    else if (ppt <= 2) FPS_LAUNCH(2);
+    else if (ppt <= 4) FPS_LAUNCH(4);
+    else if (ppt <= 8) FPS_LAUNCH(8);
+    else FPS_LAUNCH(16);
+#undef FPS_LAUNCH
+    CASPR_CHECK_LAUNCH("fps");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather rows of a point-major feature tensor (pointnet2.py:385)
+// ---------------------------------------------------------------------------------------------
+__global__ void gather_points_kernel(const float *__restrict__ feat, int ldf, const int32_t *__restrict__ idx,
+                                     int n, int M, int C, float *__restrict__ out, int ldo, long total)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C);
+    const long bm = t / C;
+    const int b = (int)(bm / M);
+    const int k = idx[bm];
+    out[bm * ldo + c] = feat[((long)b * n + k) * ldf + c];
+}
+
+extern "C" int caspr_gather_points_f32(const float *feat, int ldf, const int32_t *idx, int B, int n, int M,
+                                       int C, float *out, int ldo, void *stream)
+{
+    CASPR_REQUIRE(feat && idx && out && B > 0 && n > 0 && M > 0 && C > 0 && ldf >= C && ldo >= C,
+                  "gather_points: bad arguments");
+    const long total = (long)B * M * C;
+    gather_points_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        feat, ldf, idx, n, M, C, out, ldo, total);
+    CASPR_CHECK_LAUNCH("gather_points");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ball query (pointnet2.py:391).  One wave per centre scans the cloud 64 points at a time in index
+// order; ballot + prefix popcount assign output slots in ascending-k order; the remaining slots
+// keep the first hit (upstream fills all ns slots on the first hit).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ xyz,
+                                                         const float *__restrict__ new_xyz, int n, int M,
+                                                         float r2, int ns, int32_t *__restrict__ idx,
+                                                         long centres)
+{
+    const int lane = threadIdx.x & 63;
+    const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= centres) return;
+    const int b = (int)(c / M);
+    const float *p = xyz + (long)b * n * 3;
+    const float cx = new_xyz[c * 3 + 0], cy = new_xyz[c * 3 + 1], cz = new_xyz[c * 3 + 2];
+    int32_t *o = idx + c * ns;
+    int cnt = 0, first = 0;
+    for (int base = 0; base < n && cnt < ns; base += 64) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < n) {
+            const float d2 = sqdist3(cx, cy, cz, p[k * 3 + 0], p[k * 3 + 1], p[k * 3 + 2]);
+            hit = d2 < r2;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
+            const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && slot < ns) o[slot] = k;
+            cnt += __popcll(mask);
+        }
+    }
+    cnt = cnt < ns ? cnt : ns;
+    for (int s = cnt + lane; s < ns; s += 64) o[s] = first;  // first == 0 when there was no hit
+}
+
+extern "C" int caspr_ball_query_f32(const float *xyz, const float *new_xyz, int B, int n, int M, float radius,
+                                    int ns, int32_t *idx, void *stream)
+{
+    CASPR_REQUIRE(xyz && new_xyz && idx && B > 0 && n > 0 && M > 0 && ns > 0, "ball_query: bad arguments");
+    const long centres = (long)B * M;
+    volatile float r2 = radius * radius;
+    ball_query_kernel<<<dim3((unsigned)((centres + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        xyz, new_xyz, n, M, r2, ns, idx, centres);
+    CASPR_CHECK_LAUNCH("ball_query");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone grouping (pointnet2.py:391-398) -- reference-shaped (B,M,3+C,ns) output; the
+// production path uses the fused caspr_sa_mlp_max_f32 instead.
+// ---------------------------------------------------------------------------------------------
+__global__ void group_points_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                    const float *__restrict__ feat, int ldf, const int32_t *__restrict__ idx,
+                                    int n, int M, int C, int ns, float *__restrict__ out, long total)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int s = (int)(t % ns);
+    const int ch = (int)((t / ns) % (C + 3));
+    const long bm = t / ((long)ns * (C + 3));
+    const int b = (int)(bm / M);
+    const int k = idx[bm * ns + s];
+    float v;
+    if (ch < 3) v = xyz[((long)b * n + k) * 3 + ch] - new_xyz[bm * 3 + ch];
+    else v = feat[((long)b * n + k) * ldf + (ch - 3)];
+    out[t] = v;
+}
+
+extern "C" int caspr_group_points_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                                      const int32_t *idx, int B, int n, int M, int C, int ns, float *out,
+                                      void *stream)
+{
+    CASPR_REQUIRE(xyz && new_xyz && idx && out && (C == 0 || feat), "group_points: bad arguments");
+    const long total = (long)B * M * (C + 3) * ns;
+    group_points_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        xyz, new_xyz, feat, ldf, idx, n, M, C, ns, out, total);
+    CASPR_CHECK_LAUNCH("group_points");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// three_nn (pointnet2.py:514-518): one thread per unknown point, the known cloud staged in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ unknown,
+                                                       const float *__restrict__ known, int n, int m,
+                                                       float *__restrict__ dist, int32_t *__restrict__ idx,
+                                                       float *__restrict__ weight)
+{
+    extern __shared__ __attribute__((aligned(16))) float sk[];
+    const int b = blockIdx.y;
+    const float *kp = known + (long)b * m * 3;
+    for (int i = threadIdx.x; i < m * 3; i += 256) sk[i] = kp[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long row = (long)b * n + i;
+    const float ux = unknown[row * 3 + 0], uy = unknown[row * 3 + 1], uz = unknown[row * 3 + 2];
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;  // upstream starts at 1e40 (double) == +inf as f32
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int k = 0; k < m; ++k) {
+        const float d = sqdist3(ux, uy, uz, sk[k * 3 + 0], sk[k * 3 + 1], sk[k * 3 + 2]);
+        if (d < b1) {
+            b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
+        } else if (d < b2) {
+            b3 = b2; i3 = i2; b2 = d; i2 = k;
+        } else if (d < b3) {
+            b3 = d; i3 = k;
+        }
+    }
+    const float d1 = __fsqrt_rn(b1), d2 = __fsqrt_rn(b2), d3 = __fsqrt_rn(b3);
+    dist[row * 3 + 0] = d1; dist[row * 3 + 1] = d2; dist[row * 3 + 2] = d3;
+    idx[row * 3 + 0] = i1; idx[row * 3 + 1] = i2; idx[row * 3 + 2] = i3;
+    if (weight) {
+        const float v1 = __fdiv_rn(1.0f, d1 + 1e-8f), v2 = __fdiv_rn(1.0f, d2 + 1e-8f), v3 = __fdiv_rn(1.0f, d3 + 1e-8f);
+        const float t0 = v1 + v2;
+        const float tot = t0 + v3;
+        weight[row * 3 + 0] = __fdiv_rn(v1, tot);
+        weight[row * 3 + 1] = __fdiv_rn(v2, tot);
+        weight[row * 3 + 2] = __fdiv_rn(v3, tot);
+    }
+}
+
+extern "C" int caspr_three_nn_f32(const float *unknown, const float *known, int B, int n, int m, float *dist,
+                                  int32_t *idx, float *weight, void *stream)
+{
+    CASPR_REQUIRE(unknown && known && dist && idx && B > 0 && n > 0 && m > 0, "three_nn: bad arguments");
+    CASPR_REQUIRE(m <= 8192, "three_nn: m=%d > 8192 unsupported", m);
+    three_nn_kernel<<<dim3(ceil_div(n, 256), B), dim3(256), (size_t)m * 12, (hipStream_t)stream>>>(
+        unknown, known, n, m, dist, idx, weight);
+    CASPR_CHECK_LAUNCH("three_nn");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// three_interpolate + concat with the skip features (pointnet2.py:519-523), point-major rows:
+// one 64-lane wave per output row, 16-byte loads of the three neighbour rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void three_interp_kernel(const float *__restrict__ feat, int ldf,
+                                                           const int32_t *__restrict__ idx,
+                                                           const float *__restrict__ weight,
+                                                           const float *__restrict__ in_scale,
+                                                           const float *__restrict__ in_shift, int in_relu,
+                                                           const float *__restrict__ skip, int lds, int m,
+                                                           int n, int C, int C2, float *__restrict__ out,
+                                                           int ldo, long rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row / n);
+    const int i0 = idx[row * 3 + 0], i1 = idx[row * 3 + 1], i2 = idx[row * 3 + 2];
+    const float w0 = weight[row * 3 + 0], w1 = weight[row * 3 + 1], w2 = weight[row * 3 + 2];
+    const float *f0 = feat + ((long)b * m + i0) * ldf, *f1 = feat + ((long)b * m + i1) * ldf,
+                *f2 = feat + ((long)b * m + i2) * ldf;
+    float *o = out + row * ldo;
+    for (int c = lane * 4; c < C; c += 256) {  // C % 4 == 0 checked by the host
+        f32x4 a = ld4(f0 + c), bb = ld4(f1 + c), cc = ld4(f2 + c);
+        if (in_scale) {  // previous layer's GroupNorm(+ReLU) folded into the load
+            const f32x4 s4 = ld4(in_scale + (long)b * C + c), t4 = ld4(in_shift + (long)b * C + c);
+            a = a * s4 + t4;
+            bb = bb * s4 + t4;
+            cc = cc * s4 + t4;
+            if (in_relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = a[q] > 0.f ? a[q] : 0.f;
+                    bb[q] = bb[q] > 0.f ? bb[q] : 0.f;
+                    cc[q] = cc[q] > 0.f ? cc[q] : 0.f;
+                }
+            }
+        }
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t0 = w0 * a[q], t1 = w1 * bb[q], t2 = w2 * cc[q];
+            const float s = t0 + t1;
+            r[q] = s + t2;
+        }
+        st4(o + c, r);
+    }
+    const float *sk = skip ? skip + row * lds : nullptr;
+    for (int c = C + lane; c < ldo; c += 64) o[c] = (c - C < C2) ? sk[c - C] : 0.0f;
+}
+
+extern "C" int caspr_three_interp_f32(const float *feat, int ldf, const int32_t *idx, const float *weight,
+                                      const float *in_scale, const float *in_shift, int in_relu, const float *skip,
+                                      int lds, int B, int m, int n, int C, int C2, float *out, int ldo, void *stream)
+{
+    CASPR_REQUIRE(feat && idx && weight && out && B > 0 && m > 0 && n > 0, "three_interp: bad arguments");
+    CASPR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "three_interp: in_scale/in_shift must be given together");
+    CASPR_REQUIRE(C % 4 == 0 && ldf % 4 == 0 && ldo % 4 == 0 && ldo >= C + C2 && (C2 == 0 || skip),
+                  "three_interp: C=%d ldf=%d ldo=%d C2=%d: need C,ldf,ldo %% 4 == 0 and ldo >= C+C2", C, ldf, ldo, C2);
+    const long rows = (long)B * n;
+    three_interp_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        feat, ldf, idx, weight, in_scale, in_shift, in_relu, skip, lds, m, n, C, C2, out, ldo, rows);
+    CASPR_CHECK_LAUNCH("three_interp");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chamfer (evaluations.py:40): thread per query point, the other cloud tiled through LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ p, const float *__restrict__ q,
+                                                      int n, int m, float *__restrict__ dist)
+{
+    __shared__ float sq[1024 * 3];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float *pb = p + (long)b * n * 3, *qb = q + (long)b * m * 3;
+    float px = 0, py = 0, pz = 0;
+    if (i < n) { px = pb[i * 3]; py = pb[i * 3 + 1]; pz = pb[i * 3 + 2]; }
+    float best = INFINITY;
+    for (int base = 0; base < m; base += 1024) {
+        const int cnt = (m - base) < 1024 ? (m - base) : 1024;
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * 3; t += 256) sq[t] = qb[base * 3 + t];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const float d = sqdist3(px, py, pz, sq[j * 3], sq[j * 3 + 1], sq[j * 3 + 2]);
+            best = d < best ? d : best;
+        }
+    }
+    if (i < n) dist[(long)b * n + i] = best;
+}
+
+extern "C" int caspr_chamfer_f32(const float *p, const float *q, int B, int n, int m, float *dist1, float *dist2,
+                                 void *stream)
+{
+    CASPR_REQUIRE(p && q && dist1 && dist2 && B > 0 && n > 0 && m > 0, "chamfer: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    chamfer_kernel<<<dim3(ceil_div(n, 256), B), dim3(256), 0, st>>>(p, q, n, m, dist1);
+    chamfer_kernel<<<dim3(ceil_div(m, 256), B), dim3(256), 0, st>>>(q, p, m, n, dist2);
+    CASPR_CHECK_LAUNCH("chamfer");
+    return CASPR_OK;
+}

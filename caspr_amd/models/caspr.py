@@ -1,0 +1,146 @@
+"""CaSPR model surface (reference: caspr/models/caspr.py) on the MI355X HIP kernels.
+
+Drop-in for `caspr.models.caspr.CaSPR`: same constructor arguments, methods, return tuples and
+state_dict keys, so train.py / test.py / viz.py-style callers and reference
+checkpoints work unchanged.  Extra keyword-only knobs of this build: `cnf_rk4_steps`,
+`latent_rk4_steps` (fixed-step RK4 replaces torchdiffeq's adaptive dopri5).
+
+This round implements inference (`encode`, `reconstruct`, `decode`, and `forward` for NLL / T-NOCS loss
+VALUES); there is no backward pass yet, so `forward` runs under no_grad.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .tpointnet2 import TPointNet2
+from .latent_ode_model import LatentODE
+from .flow import get_point_cnf, count_nfe, PointCNFArgs
+from .utils import standard_normal_logprob, sample_gaussian, sphere_surface_points
+
+
+class CaSPR(nn.Module):
+    def __init__(self, radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], local_feat_size=512, latent_feat_size=1600,
+                 ode_hidden_size=512, motion_feat_size=64, pretrain_tnocs=False, augment_quad=True, augment_pairs=True,
+                 cnf_blocks=1, regress_tnocs=True, *, cnf_rk4_steps=8, latent_rk4_steps=4):
+        super(CaSPR, self).__init__()
+        self.pretrain_tnocs = pretrain_tnocs
+        self.augment_quad = augment_quad
+        self.augment_pairs = augment_pairs
+        self.motion_feat_size = motion_feat_size
+        self.regress_tnocs = regress_tnocs
+        self.tnocs_point_size = 4
+        self.encoder = TPointNet2(radii_list, local_feat_size=local_feat_size, out_feat_size=latent_feat_size,
+                                  augment_quad=self.augment_quad, augment_pairs=self.augment_pairs,
+                                  tnocs_point_size=self.tnocs_point_size, regress_tnocs=self.regress_tnocs)
+        if self.pretrain_tnocs:
+            return
+        self.latent_ode = LatentODE(input_size=self.motion_feat_size, hidden_size=ode_hidden_size, num_layers=2,
+                                    nonlinearity=nn.Tanh, rk4_steps=latent_rk4_steps)
+        self.cnf_args = PointCNFArgs()
+        self.cnf_args.zdim = latent_feat_size
+        self.cnf_args.num_blocks = cnf_blocks
+        self.cnf_args.rk4_steps = cnf_rk4_steps
+        self.point_cnf = get_point_cnf(self.cnf_args)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x, sample_points, aggregate_points=None, e=None):
+        """caspr.py:76-122.  x, sample_points (B,T,N,4) -> (recon_loss (B,T,N), tnocs_loss (B,T,N,4)).
+        `e` (B*T,N,3) optionally fixes the Hutchinson noise (odefunc.py:115-117); loss VALUES only."""
+        with torch.no_grad():
+            z0, tnocs_pred = self.encode(x)
+            B, H = z0.size()
+            _, T, N, _ = sample_points.size()
+            tnocs_loss = None
+            if self.regress_tnocs:
+                tnocs_loss = self.encoder.loss(tnocs_pred[:, :, :, :self.tnocs_point_size],
+                                               sample_points[:, :, :, :self.tnocs_point_size])
+            if self.pretrain_tnocs:
+                return tuple([tnocs_loss])
+            ode_feat_dim = self.cnf_args.zdim
+            all_times = sample_points[:, :, 0, 3]                                               # :106
+            sample_feats = self.aggregate_and_solve_latent(z0, all_times)
+            z = sample_feats.reshape(B * T, ode_feat_dim)
+            pts = sample_points.reshape(B * T, N, 4)[:, :, :3].contiguous()                     # :112
+            init_logprob = torch.zeros(B * T, N, 1, device=pts.device, dtype=pts.dtype)
+            cnf_result = self.point_cnf(pts, z, init_logprob, e=e)
+            recon_loss = self.get_nll_loss(cnf_result, B, T)
+            return tuple([recon_loss, tnocs_loss])
+
+    def get_nll_loss(self, cnf_result_list, B, T):
+        """caspr.py:124-146."""
+        batch_size = B * T
+        y, delta_log_py = cnf_result_list
+        cloud_dim = y.size()[1]
+        log_py = standard_normal_logprob(y).sum(2)
+        delta_log_py = delta_log_py.view(batch_size, cloud_dim)
+        log_px = log_py - delta_log_py
+        return (-log_px).view((B, T, -1))
+
+    def encode(self, x):
+        """caspr.py:148-155."""
+        return self.encoder(x)
+
+    def aggregate_and_solve_latent(self, z0, time_tensor):
+        """caspr.py:157-183: unique sorted times -> latent ODE -> map back -> concat the static feature."""
+        B, T = time_tensor.size()
+        solve_t, time_map = torch.unique(time_tensor, sorted=True, return_inverse=True)
+        z_init = z0[:, :self.latent_ode.input_size]
+        z_global = z0[:, self.latent_ode.input_size:]
+        pred_z = self.gen_latent(z_init, solve_t)
+        batch_inds = torch.arange(B, device=z0.device).view((-1, 1)).repeat((1, T))
+        sample_feats = pred_z[batch_inds, time_map, :]
+        B_global, H_global = z_global.size()
+        z_global = z_global.unsqueeze(1).expand(B_global, sample_feats.size()[1], H_global)
+        return torch.cat([sample_feats, z_global], dim=2)
+
+    def gen_latent(self, z0, timestamps):
+        """caspr.py:185-196."""
+        return self.latent_ode(z0, timestamps)
+
+    def get_nfe(self):
+        """caspr.py:198-202."""
+        return np.array([count_nfe(self.latent_ode), count_nfe(self.point_cnf)])
+
+    def decode(self, z, num_points=1024, constant_in_time=False, truncate_std=None, sample_contours=None, y=None):
+        """caspr.py:204-267.  `y` (B,T,num_points,3) optionally supplies the base samples."""
+        B, T, H = z.size()
+        samp_batch = B if constant_in_time else B * T
+        input_dim = self.cnf_args.input_dim
+        samp_size = (samp_batch, num_points, input_dim)
+        if y is not None:
+            y = y.to(z).reshape(B * T, num_points, input_dim)
+            constant_in_time = False
+        elif sample_contours is not None:
+            radii = sample_contours
+            contours = []
+            nsamp_pts = 0
+            for radius in radii:
+                last = radius == radii[-1]
+                cnt = (num_points - nsamp_pts) if last else (num_points // len(radii))
+                pts = sphere_surface_points(samp_batch * cnt, radius=radius).reshape((samp_batch, cnt, 3))
+                contours.append(pts)
+                nsamp_pts += num_points // len(radii)
+            y = torch.from_numpy(np.concatenate(contours, axis=1)).to(z).view(samp_size)
+        else:
+            y = sample_gaussian(samp_size, truncate_std, device=z.device)
+        if constant_in_time:
+            y = y.view((B, 1, num_points, input_dim)).expand((B, T, num_points, input_dim)).reshape((B * T, num_points, input_dim))
+        y = y.contiguous()
+        logp_y = standard_normal_logprob(y).view(B * T, num_points, -1).sum(2)
+        z = z.reshape((B * T, H))
+        x = self.point_cnf(y, z, reverse=True)
+        return y.view((B, T, num_points, input_dim)), logp_y.view((B, T, num_points)), x.view((B, T, num_points, input_dim))
+
+    def reconstruct(self, x, num_points=1024, constant_in_time=False, timestamps=None, max_timestamp=5.0,
+                    truncate_std=None, sample_contours=None, y=None):
+        """caspr.py:269-308 -> (y, logp_y, x, tnocs_pred)."""
+        with torch.no_grad():
+            B, T, N, _ = x.size()
+            z0, tnocs_pred = self.encode(x)
+            if timestamps is None:
+                all_times = x[:, :, 0, 3] / max_timestamp
+            else:
+                all_times = timestamps.view((1, -1)).repeat((B, 1)).to(x)
+            z = self.aggregate_and_solve_latent(z0, all_times)
+            y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y)
+            return y, logp_y, x, tnocs_pred

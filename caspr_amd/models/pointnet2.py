@@ -1,0 +1,318 @@
+"""PointNet++ MSG feature extractor (reference: caspr/models/pointnet2.py) on the HIP kernels.
+
+Same module / parameter tree as the reference (`set_abstractions.{l}.pointnet_modules.{s}.conv_layers`,
+`.bn_layers`, `feature_propagators.{l}.unit_pointnet.{0,1,3,4}`, `final_layers.{0,1,3}`), so reference
+checkpoints load unchanged.  The Kaolin operators (pointnet2.py:7) are replaced by `caspr_amd.ops`;
+grouping + per-neighbourhood MLP is one fused kernel; GroupNorm+ReLU between pointwise convs is
+folded into the consumer's operand load (`Lazy`).
+Internally everything is point-major (B, P, C); the sub-module `forward`s keep the reference's
+channels-first signatures by transposing at the boundary.
+"""
+from typing import Iterable
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.weight_cache import WeightCache
+from .lazy import Lazy
+
+NUM_GROUPS = 16  # for group norm (pointnet2.py:12)
+
+
+def separate_xyz_and_features(points):
+    """Kaolin helper (pointnet2.py:228): (B,n,3+C) -> xyz (B,n,3), features (B,C,n) | None."""
+    xyz = points[..., 0:3].contiguous()
+    features = points[..., 3:].transpose(1, 2).contiguous() if points.size(-1) > 3 else None
+    return xyz, features
+
+
+class PointNet2GroupingLayer(nn.Module):
+    """Parameter-free grouper (ball query + gather + centre subtraction + xyz||feat), pointnet2.py:340-342."""
+
+    def __init__(self, radius, num_samples, use_xyz_feature=True, use_random_ball_query=False):
+        super(PointNet2GroupingLayer, self).__init__()
+        if use_random_ball_query:
+            raise ValueError("use_random_ball_query=True is not supported (the reference runs with False, tpointnet2.py:49)")
+        if not use_xyz_feature:
+            raise ValueError("use_xyz_feature=False is not supported (the reference runs with True, tpointnet2.py:48)")
+        self.radius = radius
+        self.num_samples = num_samples
+
+    def forward(self, xyz, new_xyz, features=None):
+        """xyz (B,n,3), new_xyz (B,M,3), features (B,C,n) -> (B, M, 3+C, ns) (reference layout)."""
+        idx = ops.ball_query(self.radius, self.num_samples, xyz.contiguous(), new_xyz.contiguous())
+        feat_pm = None if features is None else features.transpose(1, 2).contiguous()
+        return ops.group_points(xyz.contiguous(), new_xyz.contiguous(), feat_pm, idx)
+
+
+class PointNetFeatureExtractor(nn.Module):
+    """Per-neighbourhood PointNet (pointnet2.py:527-703); only the configuration the reference
+    instantiates (global_feat=True, transposed_input=True, GroupNorm) runs on the fused kernel."""
+
+    def __init__(self, in_channels: int = 3, feat_size: int = 1024, layer_dims: Iterable[int] = [64, 128],
+                 global_feat: bool = True, activation=F.relu, batchnorm: bool = True, transposed_input: bool = False):
+        super(PointNetFeatureExtractor, self).__init__()
+        if not isinstance(in_channels, int):
+            raise TypeError('Argument in_channels expected to be of type int. Got {0} instead.'.format(type(in_channels)))
+        if not isinstance(feat_size, int):
+            raise TypeError('Argument feat_size expected to be of type int. Got {0} instead.'.format(type(feat_size)))
+        if not hasattr(layer_dims, '__iter__'):
+            raise TypeError('Argument layer_dims is not iterable.')
+        for idx, layer_dim in enumerate(layer_dims):
+            if not isinstance(layer_dim, int):
+                raise TypeError('Elements of layer_dims must be of type int. Found type {0} at index {1}.'.format(type(layer_dim), idx))
+        if not isinstance(global_feat, bool):
+            raise TypeError('Argument global_feat expected to be of type bool. Got {0} instead.'.format(type(global_feat)))
+        if batchnorm:
+            raise ValueError("batchnorm=True is not supported: the reference uses GroupNorm (tpointnet2.py:47)")
+        self.feat_size = feat_size
+        self.global_feat = global_feat
+        layer_dims = list(layer_dims)
+        layer_dims.insert(0, in_channels)
+        layer_dims.append(feat_size)
+        self.conv_layers = nn.ModuleList()
+        self.bn_layers = nn.ModuleList()
+        for idx in range(len(layer_dims) - 1):
+            self.conv_layers.append(nn.Conv1d(layer_dims[idx], layer_dims[idx + 1], 1))
+            self.bn_layers.append(nn.GroupNorm(NUM_GROUPS, layer_dims[idx + 1]))
+        self.batchnorm = batchnorm
+        self.transposed_input = transposed_input
+        self.in_channels = in_channels
+        self._cache = WeightCache()
+
+    def kernel_layers(self):
+        """3 x (PackedWeight, bias, gamma, beta).  The first layer's K is permuted to the gather order
+        of caspr_sa_mlp_max_f32: [features (C, zero-padded to a multiple of 4) | dx dy dz]."""
+        if len(self.conv_layers) != 3:
+            raise ValueError("the fused set-abstraction kernel runs 3-layer point MLPs (pointnet2.py:62-146)")
+        out = []
+        for l, (conv, gn) in enumerate(zip(self.conv_layers, self.bn_layers)):
+            def build(conv=conv, l=l):
+                w = conv.weight.detach()[:, :, 0]
+                if l == 0:
+                    C = w.shape[1] - 3
+                    pad = (-C) % 4
+                    w = torch.cat([w[:, 3:], w.new_zeros(w.shape[0], pad), w[:, :3]], dim=1)
+                return ops.PackedWeight(w.contiguous())
+            out.append((self._cache.get("l%d" % l, [conv.weight], build), conv.bias, gn.weight, gn.bias))
+        return out
+
+    def forward(self, x):
+        """Reference signature (B', C, ns) -> (B', feat_size): one neighbourhood per row."""
+        if not (self.global_feat and self.transposed_input):
+            raise ValueError("only global_feat=True, transposed_input=True is supported (pointnet2.py:352-359)")
+        Bp, C, ns = x.shape
+        # neighbourhood tensor -> fake cloud: every sample is a point, centre at the origin
+        pts = x.transpose(1, 2).contiguous()                      # (B', ns, C)
+        xyz = pts[:, :, :3].contiguous()
+        Cf = C - 3
+        ldf = (Cf + 3) // 4 * 4
+        feat = None
+        if Cf > 0:
+            feat = pts.new_zeros(Bp, ns, ldf)
+            feat[:, :, :Cf] = pts[:, :, 3:]
+        idx = torch.arange(ns, device=x.device, dtype=torch.int32).view(1, 1, ns).repeat(Bp, 1, 1).contiguous()
+        centre = torch.zeros(Bp, 1, 3, device=x.device, dtype=torch.float32)
+        out = torch.empty(Bp, 1, self.feat_size, device=x.device, dtype=torch.float32)
+        ops.sa_mlp_max(xyz, centre, feat, idx, Cf, self.kernel_layers(), out, 0)
+        return out.view(Bp, self.feat_size)
+
+
+class PointNet2SetAbstraction(nn.Module):
+    """Set-abstraction level with multi-scale grouping (pointnet2.py:253-422)."""
+
+    def __init__(self, num_points_out, pointnet_in_features, pointnet_layer_dims_list, radii_list=None,
+                 num_samples_list=None, batchnorm=True, use_xyz_feature=True, use_random_ball_query=False):
+        super(PointNet2SetAbstraction, self).__init__()
+        if num_points_out is None:
+            raise ValueError("num_points_out=None (group-all) is not used by the reference model and not supported")
+        assert isinstance(radii_list, list) and isinstance(num_samples_list, list), 'radii_list and num_samples_list must be lists'
+        assert (len(radii_list) == len(num_samples_list) == len(pointnet_layer_dims_list)), (
+            'Dimension of radii_list ({}), num_samples_list ({}), pointnet_layer_dims_list ({}) must match'
+            .format(len(radii_list), len(num_samples_list), len(pointnet_layer_dims_list)))
+        self.num_points_out = num_points_out
+        self.pointnet_layer_dims_list = pointnet_layer_dims_list
+        self.grouper_modules = nn.ModuleList()
+        self.pointnet_modules = nn.ModuleList()
+        self.layers = []
+        self.pointnet_in_channels = pointnet_in_features + (3 if use_xyz_feature else 0)
+        for i in range(len(radii_list)):
+            pointnet_layer_dims = pointnet_layer_dims_list[i]
+            assert isinstance(pointnet_layer_dims, list), 'Each pointnet_layer_dims must be a list, got {} instead'.format(pointnet_layer_dims)
+            assert len(pointnet_layer_dims) > 0, 'Each pointnet_layer_dims must have at least one element'
+            self.grouper_modules.append(PointNet2GroupingLayer(radii_list[i], num_samples_list[i], use_xyz_feature=use_xyz_feature,
+                                                               use_random_ball_query=use_random_ball_query))
+            self.pointnet_modules.append(PointNetFeatureExtractor(in_channels=self.pointnet_in_channels, feat_size=pointnet_layer_dims[-1],
+                                                                  layer_dims=pointnet_layer_dims[:-1], global_feat=True,
+                                                                  batchnorm=batchnorm, transposed_input=True))
+            self.layers.append(num_samples_list[i])
+
+    def get_num_features_out(self):
+        return sum([lst[-1] for lst in self.pointnet_layer_dims_list])
+
+    def run(self, xyz, feat, C, record=None):
+        """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels (or None).
+        -> new_xyz (B,M,3), new_feat (B,M,Cout)."""
+        B = xyz.shape[0]
+        M = self.num_points_out
+        fps_idx, new_xyz = ops.furthest_point_sampling(xyz, M, return_xyz=True)                 # pointnet2.py:384-387
+        out = torch.empty(B, M, self.get_num_features_out(), device=xyz.device, dtype=torch.float32)
+        off = 0
+        ball = []
+        for i, ns in enumerate(self.layers):
+            g = self.grouper_modules[i]
+            bidx = ops.ball_query(g.radius, ns, xyz, new_xyz)                                   # :391
+            ball.append(bidx)
+            ops.sa_mlp_max(xyz, new_xyz, feat, bidx, C, self.pointnet_modules[i].kernel_layers(), out, off)  # :391-409
+            off += self.pointnet_layer_dims_list[i][-1]
+        if record is not None:
+            record.append({"fps_idx": fps_idx, "ball_idx": ball, "new_xyz": new_xyz})
+        return new_xyz, out
+
+    def forward(self, xyz, features=None):
+        """Reference signature: xyz (B,n,3), features (B,C,n) -> new_xyz (B,M,3), new_features (B,Cout,M)."""
+        feat, C = None, 0
+        if features is not None:
+            C = features.shape[1]
+            feat = features.new_zeros(features.shape[0], features.shape[2], (C + 3) // 4 * 4)
+            feat[:, :, :C] = features.transpose(1, 2)
+        new_xyz, out = self.run(xyz.contiguous(), feat, C)
+        return new_xyz, out.transpose(1, 2)
+
+
+class PointNet2FeaturePropagator(nn.Module):
+    """Feature propagation level (pointnet2.py:424-528)."""
+
+    def __init__(self, num_features, num_features_prev, layer_dims, batchnorm=True):
+        super(PointNet2FeaturePropagator, self).__init__()
+        if batchnorm:
+            raise ValueError("batchnorm=True is not supported: the reference uses GroupNorm (tpointnet2.py:47)")
+        self.layer_dims = layer_dims
+        unit_pointnets = []
+        in_features = num_features + num_features_prev
+        for out_features in layer_dims:
+            unit_pointnets.append(nn.Conv1d(in_features, out_features, 1))
+            unit_pointnets.append(nn.GroupNorm(NUM_GROUPS, out_features))
+            unit_pointnets.append(nn.ReLU())
+            in_features = out_features
+        self.unit_pointnet = nn.Sequential(*unit_pointnets)
+        self._cache = WeightCache()
+
+    def get_num_features_out(self):
+        return self.layer_dims[-1]
+
+    def _packed(self, i):
+        conv = self.unit_pointnet[i]
+        return self._cache.get(i, [conv.weight], lambda: ops.PackedWeight(conv.weight.detach()[:, :, 0].contiguous()))
+
+    def run(self, xyz, xyz_prev, feat, C, prev: Lazy):
+        """Point-major core.  feat (B,n,ldf) skip features with C valid channels (or None); prev = Lazy
+        features of the coarser level.  -> Lazy (B,n,Cout)."""
+        _, idx, w = ops.three_nn(xyz, xyz_prev, with_weights=True)                              # pointnet2.py:514-518
+        x = ops.three_interpolate(prev.raw, idx, w, skip=feat, skip_channels=C, in_scale=prev.scale,
+                                  in_shift=prev.shift, in_relu=prev.relu, C=prev.channels)      # :519-523
+        cur = Lazy(x, prev.channels + C)
+        n_layers = len(self.layer_dims)
+        for l in range(n_layers):                                                               # :525
+            conv, gn = self.unit_pointnet[3 * l], self.unit_pointnet[3 * l + 1]
+            y = ops.conv1x1(self._packed(3 * l), conv.bias, cur.raw, in_scale=cur.scale, in_shift=cur.shift, in_relu=cur.relu)
+            s, t = ops.gn_stats(y, conv.out_channels, gn.weight, gn.bias)
+            cur = Lazy(y, conv.out_channels, s, t, True)
+        return cur
+
+    def forward(self, xyz, xyz_prev, features=None, features_prev=None):
+        """Reference signature (channels-first features) -> (B, Cout, n)."""
+        if xyz_prev is None:
+            raise ValueError("xyz_prev=None (global feature broadcast) is not used by the reference model and not supported")
+        feat, C = None, 0
+        if features is not None:
+            C = features.shape[1]
+            feat = features.new_zeros(features.shape[0], features.shape[2], (C + 3) // 4 * 4)
+            feat[:, :, :C] = features.transpose(1, 2)
+        fp = features_prev.transpose(1, 2).contiguous()
+        out = self.run(xyz.contiguous(), xyz_prev.contiguous(), feat, C, Lazy(fp, fp.shape[2]))
+        return out.materialize().transpose(1, 2)
+
+
+class PointNet2feat(nn.Module):
+    """Modified PointNet++ segmentation network giving per-point features (pointnet2.py:14-249)."""
+
+    def __init__(self, in_features=0, num_classes=2, batchnorm=True, use_xyz_feature=True, use_random_ball_query=False,
+                 radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], max_feat_prop_size=512):
+        super(PointNet2feat, self).__init__()
+        if len(radii_list) != 6:
+            raise ValueError('Radii list must be length 6, not %d!' % (len(radii_list)))
+        self.in_features = in_features
+        # (num_points_out, [mlp scale A, mlp scale B]) -- pointnet2.py:62-146 with batchnorm=False
+        specs = [
+            (1024, [[16, 16, 32], [32, 32, 64]]),
+            (512, [[32, 32, 64], [32, 32, 64]]),
+            (256, [[64, 64, 128], [64, 96, 128]]),
+            (64, [[128, 196, 256] if batchnorm else [128, 256, 256], [128, 196, 256] if batchnorm else [128, 256, 256]]),
+            (16, [[256, 256, 512], [256, 384, 512] if batchnorm else [256, 256, 512]]),
+        ]
+        self.set_abstractions = nn.ModuleList()
+        feats = in_features
+        for l, (m, dims) in enumerate(specs):
+            sa = PointNet2SetAbstraction(num_points_out=m, pointnet_in_features=feats, pointnet_layer_dims_list=dims,
+                                         radii_list=[radii_list[l], radii_list[l + 1]], num_samples_list=[16, 32],
+                                         batchnorm=batchnorm, use_xyz_feature=use_xyz_feature,
+                                         use_random_ball_query=use_random_ball_query)
+            self.set_abstractions.append(sa)
+            feats = sa.get_num_features_out()
+
+        self.feature_propagators = nn.ModuleList()
+        fp_div = [1, 1, 2, 2, 4]                                                                # pointnet2.py:150-193
+        prev = self.set_abstractions[-1].get_num_features_out()
+        for l in range(5):
+            layer_dims = [max([max_feat_prop_size // fp_div[l], num_classes])] * 2
+            nf = self.set_abstractions[-2 - l].get_num_features_out() if l < 4 else in_features
+            fp = PointNet2FeaturePropagator(num_features=nf, num_features_prev=prev, layer_dims=layer_dims, batchnorm=batchnorm)
+            self.feature_propagators.append(fp)
+            prev = fp.get_num_features_out()
+
+        final_dim = layer_dims[0]
+        self.final_layers = nn.Sequential(
+            nn.Conv1d(self.feature_propagators[-1].get_num_features_out(), final_dim, 1),
+            nn.GroupNorm(NUM_GROUPS, final_dim),
+            nn.ReLU(),
+            nn.Conv1d(final_dim, num_classes, 1))
+        self.num_classes = num_classes
+        self._cache = WeightCache()
+
+    def _packed_final(self, i):
+        conv = self.final_layers[i]
+        return self._cache.get(i, [conv.weight], lambda: ops.PackedWeight(conv.weight.detach()[:, :, 0].contiguous()))
+
+    def run(self, xyz, feat, C, out=None, record=None):
+        """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels.  -> (B,n,num_classes)
+        written into `out` (may be a column slice of a wider buffer) if given."""
+        xyz_list, feat_list, ch_list = [xyz], [feat], [C]
+        for sa in self.set_abstractions:                                                        # pointnet2.py:232
+            xyz, feat = sa.run(xyz, feat, C, record)
+            C = feat.shape[2]
+            xyz_list.append(xyz)
+            feat_list.append(feat)
+            ch_list.append(C)
+        prev = Lazy(feat_list[-1], ch_list[-1])
+        target = -2
+        for fp in self.feature_propagators:                                                     # :238-245
+            prev = fp.run(xyz_list[target], xyz_list[target + 1], feat_list[target], ch_list[target], prev)
+            target -= 1
+        c0, gn, c3 = self.final_layers[0], self.final_layers[1], self.final_layers[3]
+        y = ops.conv1x1(self._packed_final(0), c0.bias, prev.raw, in_scale=prev.scale, in_shift=prev.shift, in_relu=prev.relu)
+        s, t = ops.gn_stats(y, c0.out_channels, gn.weight, gn.bias)
+        return ops.conv1x1(self._packed_final(3), c3.bias, y, in_scale=s, in_shift=t, in_relu=True, out=out)  # :247
+
+    def forward(self, points):
+        """Reference signature: points (B,n,3+in_features) -> (B,n,num_classes)."""
+        xyz = points[..., 0:3].contiguous()
+        C = points.shape[-1] - 3
+        feat = None
+        if C > 0:
+            feat = points.new_zeros(points.shape[0], points.shape[1], (C + 3) // 4 * 4)
+            feat[:, :, :C] = points[..., 3:]
+        out = self.run(xyz, feat, C)
+        return out[:, :, :self.num_classes].contiguous()

@@ -1,0 +1,111 @@
+"""TPointNet++ encoder (reference: caspr/models/tpointnet2.py) on the HIP kernels.
+
+Same parameter tree (`local_extract`, `global_extract`, `conv1`, `conv2`, `bn1`, `bn2`, `conv3`).
+Differences in *how* (not what) it computes, all documented in DESIGN.md:
+  * the (B,1088,T*N) tiled global feature (pointnet.py:44-46) is never built: its 1024 constant
+    channels become a per-sequence bias of conv1 (W[:,512:1536] . g_b), the 64-channel point
+    feature is read in place from the global PointNet's conv1 output;
+  * GroupNorm+ReLU between the 1600-wide convs is folded into the next conv's operand load;
+  * z0 = max over points of bn2(conv2(.)) comes out of the GroupNorm statistics pass.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.weight_cache import WeightCache
+from .pointnet import PointNetfeat
+from .pointnet2 import PointNet2feat as PointNet2
+
+
+class TPointNet2(nn.Module):
+    def __init__(self, radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], local_feat_size=512, out_feat_size=1600,
+                 augment_quad=True, augment_pairs=True, tnocs_point_size=4, regress_tnocs=True):
+        super(TPointNet2, self).__init__()
+        self.augment_quad = augment_quad
+        self.augment_pairs = augment_pairs
+        self.tnocs_point_size = tnocs_point_size
+        self.local_feat_size = local_feat_size
+        self.local_bottleneck_size = self.local_feat_size
+        self.global_feat_size = 1024
+        self.space_time_pt_feat = 64
+        self.latent_feat_size = out_feat_size
+
+        in_features = 0
+        if self.augment_quad:
+            in_features += 3
+        if self.augment_pairs:
+            in_features += 3
+        self.local_extract = PointNet2(in_features=in_features, num_classes=self.local_feat_size, batchnorm=False,
+                                       use_xyz_feature=True, use_random_ball_query=False, radii_list=radii_list,
+                                       max_feat_prop_size=self.local_bottleneck_size)
+        self.global_extract = PointNetfeat(input_dim=4, out_size=self.global_feat_size)
+
+        per_point_out_size = self.global_feat_size + self.space_time_pt_feat + self.local_feat_size
+        self.conv1 = torch.nn.Conv1d(per_point_out_size, per_point_out_size, 1)
+        self.conv2 = torch.nn.Conv1d(per_point_out_size, self.latent_feat_size, 1)
+        self.bn1 = nn.GroupNorm(16, per_point_out_size)
+        self.bn2 = nn.GroupNorm(16, self.latent_feat_size)
+        self.regress_tnocs = regress_tnocs
+        if self.regress_tnocs:
+            self.conv3 = torch.nn.Conv1d(self.latent_feat_size, self.tnocs_point_size, 1)
+            self.loss_func = torch.nn.L1Loss(reduction='none')   # reference: L1Loss(reduce=False), tpointnet2.py:68
+        self._cache = WeightCache()
+        self.record = None  # set to a list to capture FPS / ball-query indices (parity tests)
+
+    def _head_weights(self):
+        L, G, S = self.local_feat_size, self.global_feat_size, self.space_time_pt_feat
+
+        def build():
+            w = self.conv1.weight.detach()[:, :, 0]
+            w_pt = torch.cat([w[:, :L], w[:, L + G:]], dim=1).contiguous()       # columns of [local | point feature]
+            w_g = w[:, L:L + G].contiguous()                                     # columns of the tiled global feature
+            return ops.PackedWeight(w_pt), ops.PackedWeight(w_g)
+        p1 = self._cache.get("conv1", [self.conv1.weight], build)
+        p2 = self._cache.get("conv2", [self.conv2.weight],
+                             lambda: ops.PackedWeight(self.conv2.weight.detach()[:, :, 0].contiguous()))
+        p3 = None
+        if self.regress_tnocs:
+            p3 = self._cache.get("conv3", [self.conv3.weight],
+                                 lambda: ops.PackedWeight(self.conv3.weight.detach()[:, :, 0].contiguous()))
+        return p1, p2, p3
+
+    def forward(self, x):
+        """x (B,T,N,4) -> z0 (B, out_feat_size), tnocs (B,T,N,4) | None   (tpointnet2.py:70-115)."""
+        if not x.is_cuda:
+            raise ValueError("caspr_amd.TPointNet2 runs on the GPU only (HIP kernels); got a %s tensor" % x.device)
+        B, T, N, _ = x.size()
+        x = x.contiguous().float()
+        L, S = self.local_feat_size, self.space_time_pt_feat
+        P = T * N
+        # one buffer holds the head's input [local (L) | raw global conv1 output (S)]
+        X1 = torch.empty(B, P, L + S, device=x.device, dtype=torch.float32)
+        # global spatio-temporal feature (tpointnet2.py:75-76)
+        pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
+        # local spatial feature per time step (tpointnet2.py:79-93)
+        xyz, feat = ops.prep_input(x, self.augment_quad, self.augment_pairs)
+        C = (3 if self.augment_quad else 0) + (3 if self.augment_pairs else 0)
+        if C == 0:
+            feat = None
+        self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record)
+
+        (w_pt, w_g), p2, p3 = self._head_weights()
+        # conv1 over [local | global max (tiled) | point feature]  (tpointnet2.py:96-99)
+        bbias = ops.conv1x1(w_g, self.conv1.bias, gmax.view(B, 1, -1))                        # (B,1,1600)
+        ones = torch.ones(B, L, device=x.device, dtype=torch.float32)
+        in_scale = torch.cat([ones, pf.scale], dim=1).contiguous()
+        in_shift = torch.cat([torch.zeros_like(ones), pf.shift], dim=1).contiguous()
+        y1 = ops.conv1x1(w_pt, None, X1, bbias=bbias.view(B, -1), in_scale=in_scale, in_shift=in_shift,
+                         in_relu=True, in_relu_from=L)
+        s1, t1 = ops.gn_stats(y1, self.conv1.out_channels, self.bn1.weight, self.bn1.bias)
+        y2 = ops.conv1x1(p2, self.conv2.bias, y1, in_scale=s1, in_shift=t1, in_relu=True)     # :99-100
+        del y1
+        s2, t2, z0 = ops.gn_stats(y2, self.conv2.out_channels, self.bn2.weight, self.bn2.bias, want_max=True)  # :100,111
+        tnocs_regression = None
+        if self.regress_tnocs:
+            t = ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1)  # :105-106
+            tnocs_regression = t[:, :, :self.tnocs_point_size].reshape(B, T, N, self.tnocs_point_size)
+        return z0, tnocs_regression
+
+    def loss(self, outputs, gt):
+        """Per-element L1 (tpointnet2.py:117-122)."""
+        return self.loss_func(outputs, gt)

@@ -1,0 +1,262 @@
+"""Python front-end of the C-ABI kernels (include/caspr_hip.h) on torch tensors.
+
+Mirrors the operator surface the reference imports from Kaolin at models/pointnet2.py:7
+(`furthest_point_sampling`, `fps_gather_by_index`, `ball_query`, `three_nn`, `three_interpolate`)
+plus the fused / MFMA kernels of this build.  PyTorch only owns memory and streams here; every
+tensor must live on a HIP device -- there is no CPU fallback (calls raise instead).
+
+Layouts: activations are point-major (B, P, C) float32 with row stride = last-dim size unless a
+leading-dimension is given; index tensors are int32.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ValueError("caspr_amd kernels need tensors on the GPU (got %s): there is no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError("expected float32, got %s" % t.dtype)
+        if not t.is_contiguous():
+            raise ValueError("expected a contiguous tensor")
+
+
+def _chk_rows(t):
+    """(B,P,C) float32 GPU tensor whose rows may be a column slice of a wider buffer: returns the row stride."""
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise ValueError("caspr_amd kernels need tensors on the GPU (got %s): there is no CPU fallback" % t.device)
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+        raise ValueError("expected a float32 (B,P,C) tensor with unit channel stride and packed rows")
+    if t.stride(1) % 4 != 0 or t.data_ptr() % 16 != 0:
+        raise ValueError("row stride must be a multiple of 4 floats and the base 16-byte aligned")
+    return t.stride(1)
+
+
+def _chk_i32(*ts):
+    for t in ts:
+        if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+            raise ValueError("expected a contiguous int32 GPU tensor")
+
+
+# ---------------------------------------------------------------------------------------------
+def prep_input(x, quad=True, pairs=True):
+    """x (B,T,N,4) -> xyz (B*T,N,3), feat (B*T,N,8) [x2,y2,z2,xz,xy,yz,0,0]  (tpointnet2.py:79-90)."""
+    _chk_f32(x)
+    B, T, N, _ = x.shape
+    xyz = torch.empty(B * T, N, 3, device=x.device, dtype=torch.float32)
+    feat = torch.empty(B * T, N, 8, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().caspr_prep_input_f32(_p(x), B * T, N, int(quad), int(pairs), _p(xyz), _p(feat), _stream()),
+               "caspr_prep_input_f32")
+    return xyz, feat
+
+
+def furthest_point_sampling(xyz, M, guard=True, return_xyz=False):
+    """Kaolin `furthest_point_sampling(xyz, M)` (pointnet2.py:384): (B,n,3) -> (B,M) int32."""
+    _chk_f32(xyz)
+    B, n, _ = xyz.shape
+    idx = torch.empty(B, M, device=xyz.device, dtype=torch.int32)
+    new_xyz = torch.empty(B, M, 3, device=xyz.device, dtype=torch.float32) if return_xyz else None
+    _lib.check(_lib.load().caspr_fps_f32(_p(xyz), B, n, M, int(bool(guard)), _p(idx), _p(new_xyz), _stream()), "caspr_fps_f32")
+    return (idx, new_xyz) if return_xyz else idx
+
+
+def gather_points(feat, idx):
+    """Point-major `fps_gather_by_index`: feat (B,n,C), idx (B,M) -> (B,M,C)  (pointnet2.py:385)."""
+    _chk_f32(feat)
+    _chk_i32(idx)
+    B, n, C = feat.shape
+    M = idx.shape[1]
+    out = torch.empty(B, M, C, device=feat.device, dtype=torch.float32)
+    _lib.check(_lib.load().caspr_gather_points_f32(_p(feat), C, _p(idx), B, n, M, C, _p(out), C, _stream()), "caspr_gather_points_f32")
+    return out
+
+
+def fps_gather_by_index(feat_cf, idx):
+    """Reference-shaped `fps_gather_by_index`: feat (B,C,n) channels-first -> (B,C,M)."""
+    return gather_points(feat_cf.transpose(1, 2).contiguous(), idx).transpose(1, 2)
+
+
+def ball_query(radius, ns, xyz, new_xyz):
+    """Kaolin `ball_query(radius, ns, xyz, new_xyz)` (pointnet2.py:340-342,391) -> (B,M,ns) int32."""
+    _chk_f32(xyz, new_xyz)
+    B, n, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty(B, M, ns, device=xyz.device, dtype=torch.int32)
+    _lib.check(_lib.load().caspr_ball_query_f32(_p(xyz), _p(new_xyz), B, n, M, float(radius), ns, _p(idx), _stream()), "caspr_ball_query_f32")
+    return idx
+
+
+def group_points(xyz, new_xyz, feat, idx):
+    """Reference-shaped grouper output (B,M,3+C,ns) (pointnet2.py:391-398); feat point-major (B,n,C) or None."""
+    _chk_f32(xyz, new_xyz, feat)
+    _chk_i32(idx)
+    B, n, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    C = 0 if feat is None else feat.shape[2]
+    out = torch.empty(B, M, 3 + C, ns, device=xyz.device, dtype=torch.float32)
+    _lib.check(_lib.load().caspr_group_points_f32(_p(xyz), _p(new_xyz), _p(feat), C, _p(idx), B, n, M, C, ns, _p(out), _stream()),
+               "caspr_group_points_f32")
+    return out
+
+
+def three_nn(unknown, known, with_weights=False):
+    """Kaolin `three_nn` (pointnet2.py:514): -> dist (B,n,3) [sqrt], idx (B,n,3) [, normalised inverse-distance weights :516-518]."""
+    _chk_f32(unknown, known)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist = torch.empty(B, n, 3, device=unknown.device, dtype=torch.float32)
+    idx = torch.empty(B, n, 3, device=unknown.device, dtype=torch.int32)
+    w = torch.empty(B, n, 3, device=unknown.device, dtype=torch.float32) if with_weights else None
+    _lib.check(_lib.load().caspr_three_nn_f32(_p(unknown), _p(known), B, n, m, _p(dist), _p(idx), _p(w), _stream()), "caspr_three_nn_f32")
+    return (dist, idx, w) if with_weights else (dist, idx)
+
+
+def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale=None, in_shift=None, in_relu=False, C=None):
+    """Point-major `three_interpolate` (+ concat of skip features): feat (B,m,>=C) -> (B,n,roundup4(C+C2))
+    (pointnet2.py:519-523).  in_scale/in_shift (B,C): feat is read as relu(feat*scale+shift)."""
+    _chk_f32(weight, in_scale, in_shift)
+    _chk_i32(idx)
+    ldf = _chk_rows(feat)
+    lds = _chk_rows(skip)
+    B, m, _ = feat.shape
+    C = feat.shape[2] if C is None else C
+    n = idx.shape[1]
+    C2 = 0 if skip is None else (skip.shape[2] if skip_channels is None else skip_channels)
+    ldo = (C + C2 + 3) // 4 * 4
+    out = torch.empty(B, n, ldo, device=feat.device, dtype=torch.float32)
+    _lib.check(_lib.load().caspr_three_interp_f32(_p(feat), ldf, _p(idx), _p(weight), _p(in_scale), _p(in_shift), int(in_relu),
+                                                  _p(skip), lds, B, m, n, C, C2, _p(out), ldo, _stream()),
+               "caspr_three_interp_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+class PackedWeight:
+    """A (Cout, Cin) weight matrix in MFMA A-fragment order (see csrc/common.h)."""
+
+    def __init__(self, w2d, col0=0, ncols=None):
+        _chk_f32(w2d)
+        self.cout, ldw = w2d.shape
+        self.cin = ldw - col0 if ncols is None else ncols
+        size = _lib.load().caspr_packed_size(self.cout, self.cin)
+        self.data = torch.empty(size, device=w2d.device, dtype=torch.float32)
+        _lib.check(_lib.load().caspr_pack_weight_f32(_p(w2d), ldw, self.cout, col0, self.cin, _p(self.data), _stream()),
+                   "caspr_pack_weight_f32")
+
+
+def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, act=0, out=None):
+    """Pointwise conv on MFMA: x (B,P,>=Cin) point-major (may be a column slice of a wider buffer) ->
+    (B,P,roundup4(Cout)) or into `out` (same rules).  See caspr_conv1x1_f32."""
+    _chk_f32(bias, bbias, in_scale, in_shift)
+    ldx = _chk_rows(x)
+    B, P, _ = x.shape
+    if x.shape[2] < pw.cin and ldx < (pw.cin + 3) // 4 * 4:
+        raise ValueError("conv1x1: input rows hold %d channels, weight needs %d" % (x.shape[2], pw.cin))
+    if out is None:
+        out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
+    ldy = _chk_rows(out)
+    _lib.check(_lib.load().caspr_conv1x1_f32(_p(pw.data), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                             int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()), "caspr_conv1x1_f32")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def gn_stats(y, C, gamma, beta, groups=16, eps=1e-5, want_max=False):
+    """GroupNorm statistics of y (B,P,ldy) -> scale (B,C), shift (B,C) [, max over points of the normalised output (B,C)]."""
+    _chk_f32(gamma, beta)
+    ldy = _chk_rows(y)
+    B, P, _ = y.shape
+    scale = torch.empty(B, C, device=y.device, dtype=torch.float32)
+    shift = torch.empty(B, C, device=y.device, dtype=torch.float32)
+    pmax = torch.empty(B, C, device=y.device, dtype=torch.float32) if want_max else None
+    nbytes = _lib.load().caspr_gn_ws_bytes(B, P, C, groups)
+    ws = _workspace(nbytes, y.device)
+    _lib.check(_lib.load().caspr_gn_stats_f32(_p(y), ldy, B, P, C, groups, _p(gamma), _p(beta), float(eps), _p(scale), _p(shift), _p(pmax),
+                                              _p(ws), ws.numel(), _stream()), "caspr_gn_stats_f32")
+    return (scale, shift, pmax) if want_max else (scale, shift)
+
+
+def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off):
+    """Fused grouper + 3-layer point MLP + GroupNorm + max (pointnet2.py:391-409,649-703).
+    feat (B,n,ldf) point-major with C valid channels; layers = 3 x (PackedWeight, bias, gamma, beta)."""
+    _chk_f32(xyz, new_xyz, feat, out)
+    _chk_i32(idx)
+    B, n, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    ldf = 0 if feat is None else feat.shape[2]
+    args = []
+    for (pw, b, g, be) in layers:
+        _chk_f32(b, g, be)
+        args += [_p(pw.data), _p(b), _p(g), _p(be), pw.cout]
+    _lib.check(_lib.load().caspr_sa_mlp_max_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, *args,
+                                                _p(out), out.shape[2], out_off, _stream()), "caspr_sa_mlp_max_f32")
+    return out
+
+
+def latent_rk4(z0, times, steps, wts):
+    """Fixed-step RK4 of the latent dynamics (latent_ode_model.py:45-70): z0 (B,D) (rows may be a column
+    slice of a wider tensor); wts = [w0t,b0,w1t,b1,w2t,b2,w3t,b3] with transposed weights.  -> (B,Tu,D)."""
+    _chk_f32(times, *wts)
+    if not z0.is_cuda or z0.dtype != torch.float32 or z0.dim() != 2 or z0.stride(1) != 1:
+        raise ValueError("latent_rk4: z0 must be a float32 GPU (B,D) tensor with unit column stride")
+    B = z0.shape[0]
+    D, H = wts[0].shape
+    if z0.shape[1] != D:
+        raise ValueError("latent_rk4: z0 has %d columns, the dynamics net expects %d" % (z0.shape[1], D))
+    Tu = times.shape[0]
+    out = torch.empty(B, Tu, D, device=z0.device, dtype=torch.float32)
+    _lib.check(_lib.load().caspr_latent_rk4_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *[_p(w) for w in wts], _p(out), _stream()),
+               "caspr_latent_rk4_f32")
+    return out
+
+
+def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reverse, mbn_in=None, mbn_out=None,
+            e=None, logp=None):
+    """Fixed-step RK4 of one CNF block (cnf.py:70-128).  y (BT,n,3); hyper (BT,ldh).  Returns x or (x, logp)."""
+    _chk_f32(y, hyper, tcol, w0, b0, b1, b2, w3, b3, mbn_in, mbn_out, e, logp)
+    BT, n, _ = y.shape
+    out = torch.empty_like(y)
+    lp_out = torch.empty(BT, n, 1, device=y.device, dtype=torch.float32) if e is not None else None
+    _lib.check(_lib.load().caspr_cnf_rk4_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1p.data), _p(b1),
+                                             _p(w2p.data), _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps), int(bool(reverse)),
+                                             _p(mbn_in), _p(mbn_out), _p(e), _p(logp), _p(lp_out), _p(out), BT, n, _stream()),
+               "caspr_cnf_rk4_f32")
+    return out if e is None else (out, lp_out)
+
+
+def chamfer_distance(p, q):
+    """tk3dv `ChamferDistance()(pred, gt)` (evaluations.py:40): -> dist1 (B,n), dist2 (B,m) squared NN distances."""
+    _chk_f32(p, q)
+    B, n, _ = p.shape
+    m = q.shape[1]
+    d1 = torch.empty(B, n, device=p.device, dtype=torch.float32)
+    d2 = torch.empty(B, m, device=p.device, dtype=torch.float32)
+    _lib.check(_lib.load().caspr_chamfer_f32(_p(p), _p(q), B, n, m, _p(d1), _p(d2), _stream()), "caspr_chamfer_f32")
+    return d1, d2

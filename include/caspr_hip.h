@@ -1,0 +1,151 @@
+/*
+ * caspr_hip.h -- C ABI of libcaspr_hip.so: the MI355X (gfx950) kernels behind the CaSPR
+ * encode -> advect -> sample path.
+ *
+ * The reference (davrempe/caspr) has no FFI layer of its own: its operator boundary is the set of
+ * Python symbols it imports from third-party CUDA extensions.  Each entry point below names the
+ * reference call site (file:line under /root/reference/caspr) whose operator it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (PyTorch tensors); the library
+ *     never allocates, frees or retains pointers; no global state apart from the last-error string;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - functions are re-entrant and never call hipSetDevice (one process per GPU);
+ *   - return 0 on success, a negative CASPR_E* code otherwise (caspr_last_error_string() explains);
+ *   - activations are POINT-MAJOR f32: (batch, points, channels) with an explicit row stride `ld*`
+ *     (multiple of 4 floats).  The reference's channels-first (B,C,P) tensors are the transposed
+ *     view of the same data;
+ *   - index tensors are int32, row-major, contiguous;
+ *   - "packed" weights are produced by caspr_pack_weight_f32 (MFMA A-fragment order).
+ */
+#ifndef CASPR_HIP_H
+#define CASPR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CASPR_OK 0
+#define CASPR_EINVAL (-1)   /* bad argument (shape / alignment / null pointer)         */
+#define CASPR_ELAUNCH (-2)  /* hipLaunchKernel / hipGetLastError reported a failure    */
+#define CASPR_EUNSUP (-3)   /* shape outside what the kernels are instantiated for     */
+
+const char *caspr_last_error_string(void);
+int caspr_abi_version(void);
+
+/* ---------------- input preparation: models/tpointnet2.py:75,79-90 ------------------------------
+ * x (B,T,N,4) [x,y,z,t] -> xyz (B*T,N,3) ; feat (B*T,N,8) = [x^2,y^2,z^2,xz,xy,yz,0,0] (or fewer
+ * terms: quad/pairs flags as TPointNet2.augment_quad / augment_pairs; row stride 8, zero padded).
+ * The global PointNet reads x itself (point-major (B, T*N, 4)).                                   */
+int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int pairs, float *xyz, float *feat,
+                         void *stream);
+
+/* ---------------- Kaolin furthest_point_sampling + fps_gather_by_index: models/pointnet2.py:384-387
+ * xyz (B,n,3) -> idx (B,M) int32 and (optionally, may be NULL) new_xyz (B,M,3) = xyz[idx].
+ * Contract = oracle/point_ops.c:oracle_fps (start index 0, temp=1e10, padding guard, tie rule). */
+int caspr_fps_f32(const float *xyz, int B, int n, int M, int guard, int32_t *idx, float *new_xyz,
+                  void *stream);
+
+/* Kaolin fps_gather_by_index on point-major features: out[b,j,:] = feat[b,idx[b,j],:]  (pointnet2.py:385) */
+int caspr_gather_points_f32(const float *feat, int ldf, const int32_t *idx, int B, int n, int M, int C,
+                            float *out, int ldo, void *stream);
+
+/* ---------------- Kaolin ball_query inside PointNet2GroupingLayer: models/pointnet2.py:340-342,391
+ * xyz (B,n,3), new_xyz (B,M,3) -> idx (B,M,ns) int32.  Contract = oracle_ball_query.              */
+int caspr_ball_query_f32(const float *xyz, const float *new_xyz, int B, int n, int M, float radius,
+                         int ns, int32_t *idx, void *stream);
+
+/* Kaolin group_gather_by_index + centre subtraction + xyz||feat concat (pointnet2.py:391-398):
+ * out (B,M,3+C,ns) exactly as the reference's grouper returns it.  feat point-major (B,n,C), may be NULL. */
+int caspr_group_points_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                           const int32_t *idx, int B, int n, int M, int C, int ns, float *out,
+                           void *stream);
+
+/* ---------------- fused grouper + PointNetFeatureExtractor: models/pointnet2.py:391-409,649-703
+ * For every centre: gather the ns neighbours (xyz - centre || feat), run 3 x (conv1d k=1 ->
+ * GroupNorm(16) per neighbourhood -> ReLU [not after the last]) and max over the ns samples.
+ * Weights are packed with caspr_pack_weight_f32 from the K-permuted matrix [feat (C, padded to 4) |
+ * xyz (3) | 0...].  out[b, m, out_off : out_off+C3] (row stride ldo).              */
+int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                         const int32_t *idx, int B, int n, int M, int C, int ns,
+                         const float *w1p, const float *b1, const float *g1, const float *be1, int C1,
+                         const float *w2p, const float *b2, const float *g2, const float *be2, int C2,
+                         const float *w3p, const float *b3, const float *g3, const float *be3, int C3,
+                         float *out, int ldo, int out_off, void *stream);
+
+/* ---------------- Kaolin three_nn + inverse-distance weights: models/pointnet2.py:514-518
+ * unknown (B,n,3), known (B,m,3) -> dist (B,n,3) [sqrt], idx (B,n,3), weight (B,n,3) (may be NULL) */
+int caspr_three_nn_f32(const float *unknown, const float *known, int B, int n, int m, float *dist,
+                       int32_t *idx, float *weight, void *stream);
+
+/* Kaolin three_interpolate + the concat with the skip features (pointnet2.py:519-523), point-major:
+ * out[b,i,0:C] = sum_k w[b,i,k] * feat[b,idx[b,i,k],0:C] ; out[b,i,C:C+C2] = skip[b,i,0:C2] ;
+ * columns up to ldo are zero-filled.  skip may be NULL (C2 = 0).  in_scale/in_shift (B,C) (may be
+ * NULL): feat is read as max(feat*scale+shift, 0) (in_relu) -- the producer's GroupNorm+ReLU.       */
+int caspr_three_interp_f32(const float *feat, int ldf, const int32_t *idx, const float *weight,
+                           const float *in_scale, const float *in_shift, int in_relu, const float *skip,
+                           int lds, int B, int m, int n, int C, int C2, float *out, int ldo, void *stream);
+
+/* ---------------- pointwise conv (nn.Conv1d k=1 / nn.Linear) on MFMA f32 --------------------------
+ * Replaces the cuDNN/cuBLAS calls behind pointnet.py:37-41, pointnet2.py:525,247,
+ * tpointnet2.py:99-105.   Y[b,p,co] = act( sum_k W[co,k] * in(X[b,p,k]) + bias[co] + bbias[b,co] )
+ *   in(x) = x                                   if in_scale == NULL
+ *         = max(x*in_scale[b,k]+in_shift[b,k],0) (in_relu, for k >= in_relu_from) or without the max -- the previous
+ *           layer's GroupNorm(+ReLU) folded into the operand load (scale/shift from caspr_gn_stats_f32)
+ *   act  = identity (0) or sigmoid (1).
+ * caspr_pack_weight_f32: W (Cout,Cin) row-major [+ column offset/count to pack a slice] -> packed
+ * buffer of caspr_packed_size(Cout, ncols) floats.                                                 */
+long caspr_packed_size(int Cout, int Cin);
+int caspr_pack_weight_f32(const float *w, int ldw, int Cout, int col0, int ncols, float *packed,
+                          void *stream);
+int caspr_conv1x1_f32(const float *wp, const float *bias, const float *bbias, const float *X, int ldx,
+                      const float *in_scale, const float *in_shift, int in_relu, int in_relu_from,
+                      float *Y, int ldy, int B, int P, int Cin, int Cout, int act, void *stream);
+
+/* GroupNorm statistics of Y (B,P,C) (nn.GroupNorm(G,C), biased variance, eps):
+ *   scale[b,c] = gamma[c]*rstd[b,g(c)] ; shift[b,c] = beta[c] - mean[b,g(c)]*scale[b,c]
+ * and, when pmax != NULL, pmax[b,c] = max_p (Y[b,p,c]*scale+shift) (tpointnet2.py:111, pointnet.py:42).
+ * Two deterministic passes (f64 partial sums per 1024-point split, then a fixed-order combine);
+ * ws = caller-provided scratch of at least caspr_gn_ws_bytes(B,P,C,G) bytes.  C/G %% 4 == 0.       */
+long caspr_gn_ws_bytes(int B, int P, int C, int G);
+int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, int G, const float *gamma,
+                       const float *beta, float eps, float *scale, float *shift, float *pmax,
+                       void *ws, long ws_bytes, void *stream);
+
+/* ---------------- latent ODE: models/latent_ode_model.py:45-70,139-147 (fixed-step RK4) -----------
+ * z0 (B,64) rows at stride ldz ; times (Tu) ascending (made relative to times[0] as :58) ;
+ * w*t = TRANSPOSED Linear weights ([in][out]) ; out (B,Tu,D).  D<=64, H<=512.                       */
+int caspr_latent_rk4_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H,
+                         int steps, const float *w0t, const float *b0, const float *w1t, const float *b1,
+                         const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
+                         void *stream);
+
+/* ---------------- point CNF: models/cnf.py:70-128 + odefunc.py:119-142 + diffeq_layers.py:83-90
+ * + normalization.py:59-108 (fixed-step RK4 of the gated 3-512-512-512-3 ODE function).
+ * hyper (BT, 2*(3*H+3)) = per-frame context terms, columns [gate l0 | gate l1 | gate l2 | gate l3 |
+ *   bias l0 | .. | bias l3] = W_hyper[:,1:] . c (+ gate bias)  (from caspr_conv1x1_f32);
+ * tcol (2*(3*H+3)) = column 0 of the hyper weights (multiplies t), same order.
+ * w0 (H,3), b0 (H) ; w1p, w2p packed (H,H) ; w3 (3,H), b3 (3).
+ * mbn_in / mbn_out: 12 floats each [weight(3), bias(3), running_mean(3), running_var(3)] of the
+ *   MovingBatchNorm applied before / after the block in the direction of travel (NULL = none).
+ * reverse: integrate t: T_end -> 0 and use MBN._reverse (sampling); else 0 -> T_end and MBN._forward.
+ * e / logp_in / logp_out (BT,n,*) may be NULL together: no divergence is integrated (sampling).     */
+int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const float *tcol,
+                      const float *w0, const float *b0, const float *w1p, const float *b1,
+                      const float *w2p, const float *b2, const float *w3, const float *b3, int H,
+                      float t_end, int steps, int reverse, const float *mbn_in, const float *mbn_out,
+                      const float *e, const float *logp_in, float *logp_out, float *y_out, int BT,
+                      int n, void *stream);
+
+/* ---------------- Chamfer (tk3dv.extern.chamfer.ChamferDistance): utils/evaluations.py:40 --------
+ * p (B,n,3), q (B,m,3) -> dist1 (B,n) = min_j |p_i-q_j|^2 , dist2 (B,m).                            */
+int caspr_chamfer_f32(const float *p, const float *q, int B, int n, int m, float *dist1, float *dist2,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASPR_HIP_H */

@@ -1,0 +1,222 @@
+/*
+ * oracle/point_ops.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the third-party point-set operators the reference calls
+ * (Kaolin v0.1 `kaolin.cuda.*`, adapted from Pointnet2_PyTorch; tk3dv Chamfer).  The reference
+ * imports them at caspr/models/pointnet2.py:7 and calls them at pointnet2.py:384-387 (FPS +
+ * gather), :391 (ball query + group), :514 (three_nn), :519 (three_interpolate) and
+ * caspr/utils/evaluations.py:40 (Chamfer).  Their sources are NOT under /root/reference and are
+ * not pinned by any reference test: PARITY UNPINNED for these operators -- this file *defines*
+ * the contract that the HIP kernels are held to bit-exactly.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * All float arithmetic is single precision, evaluated left-to-right exactly as written,
+ * with no fused multiply-add (compile with -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    /* ((dx*dx) + (dy*dy)) + (dz*dz), every op rounded to f32 */
+    volatile float dx = ax - bx, dy = ay - by, dz = az - bz;
+    volatile float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    volatile float s = xx + yy;
+    return s + zz;
+}
+
+static int fps_block_size(int n)
+{
+    /* largest power of two <= n, clamped to [1, 512] (the upstream launch configuration) */
+    int bs = 1;
+    while (bs * 2 <= n && bs * 2 <= 512) bs *= 2;
+    return bs;
+}
+
+/*
+ * Farthest point sampling (call site pointnet2.py:384).
+ *   xyz (B,n,3) f32 -> idx (B,M) int32.  temp[] starts at 1e10, first index 0.
+ *   Points with x*x+y*y+z*z <= 1e-3 are skipped when guard != 0 (upstream "padding guard").
+ *   Arg-max tie rule = upstream block reduction: among equal maxima the winner has the
+ *   smallest (k mod blockDim), then the smallest k; blockDim = fps_block_size(n).
+ *   A thread that saw no admissible point contributes (best=-1, besti=0).
+ */
+void oracle_fps(const float *xyz, int B, int n, int M, int guard, int32_t *idx)
+{
+    float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    const int bs = fps_block_size(n);
+    for (int b = 0; b < B; ++b) {
+        const float *p = xyz + (size_t)b * n * 3;
+        int32_t *out = idx + (size_t)b * M;
+        if (M <= 0) continue;
+        for (int k = 0; k < n; ++k) temp[k] = 1e10f;
+        int old = 0;
+        out[0] = 0;
+        for (int j = 1; j < M; ++j) {
+            const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+            float best = -1.0f;
+            int besti = 0;
+            int best_tid = 0;
+            for (int k = 0; k < n; ++k) {
+                const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+                if (guard) {
+                    volatile float xx = x2 * x2, yy = y2 * y2, zz = z2 * z2;
+                    volatile float m0 = xx + yy;
+                    const float mag = m0 + zz;
+                    if (mag <= 1e-3f) continue;
+                }
+                const float d = sqdist3(x2, y2, z2, x1, y1, z1);
+                const float d2 = d < temp[k] ? d : temp[k];
+                temp[k] = d2;
+                const int tid = k % bs;
+                /* total order: value desc, tid asc, k asc.  (best=-1,besti=0,tid=0) is the
+                 * identity contributed by an empty thread 0. */
+                if (d2 > best || (d2 == best && (tid < best_tid || (tid == best_tid && k < besti)))) {
+                    best = d2;
+                    besti = k;
+                    best_tid = tid;
+                }
+            }
+            old = besti;
+            out[j] = old;
+        }
+    }
+    free(temp);
+}
+
+/* fps_gather_by_index (pointnet2.py:385): feat (B,C,n), idx (B,M) -> out (B,C,M) */
+void oracle_gather(const float *feat, const int32_t *idx, int B, int C, int n, int M, float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int j = 0; j < M; ++j)
+                out[((size_t)b * C + c) * M + j] = feat[((size_t)b * C + c) * n + idx[(size_t)b * M + j]];
+}
+
+/*
+ * Ball query (inside PointNet2GroupingLayer, pointnet2.py:340-342,391).
+ *   xyz (B,n,3), new_xyz (B,M,3) -> idx (B,M,ns) int32, zero-initialised.
+ *   Scan k ascending; hit iff d2 < radius*radius (f32, strict); the first hit fills all ns
+ *   slots; stop after ns hits.
+ */
+void oracle_ball_query(const float *xyz, const float *new_xyz, int B, int n, int M, float radius,
+                       int ns, int32_t *idx)
+{
+    volatile float r2v = radius * radius;
+    const float r2 = r2v;
+    memset(idx, 0, sizeof(int32_t) * (size_t)B * M * ns);
+    for (int b = 0; b < B; ++b) {
+        const float *p = xyz + (size_t)b * n * 3;
+        for (int j = 0; j < M; ++j) {
+            const float *c = new_xyz + ((size_t)b * M + j) * 3;
+            int32_t *o = idx + ((size_t)b * M + j) * ns;
+            int cnt = 0;
+            for (int k = 0; k < n && cnt < ns; ++k) {
+                const float d2 = sqdist3(c[0], c[1], c[2], p[k * 3], p[k * 3 + 1], p[k * 3 + 2]);
+                if (d2 < r2) {
+                    if (cnt == 0)
+                        for (int l = 0; l < ns; ++l) o[l] = k;
+                    o[cnt] = k;
+                    ++cnt;
+                }
+            }
+        }
+    }
+}
+
+/*
+ * Grouping layer output (pointnet2.py:391-398): (B, M, 3+C, ns):
+ *   rows 0..2 = xyz[idx] - centre, rows 3.. = feat[:, idx].  feat may be NULL (C = 0).
+ */
+void oracle_group(const float *xyz, const float *new_xyz, const float *feat, const int32_t *idx,
+                  int B, int n, int M, int C, int ns, float *out)
+{
+    const int CC = C + 3;
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < M; ++j) {
+            const float *c = new_xyz + ((size_t)b * M + j) * 3;
+            const int32_t *id = idx + ((size_t)b * M + j) * ns;
+            float *o = out + ((size_t)b * M + j) * CC * ns;
+            for (int s = 0; s < ns; ++s) {
+                const int k = id[s];
+                for (int d = 0; d < 3; ++d) o[d * ns + s] = xyz[((size_t)b * n + k) * 3 + d] - c[d];
+                for (int ch = 0; ch < C; ++ch)
+                    o[(3 + ch) * ns + s] = feat[((size_t)b * C + ch) * n + k];
+            }
+        }
+}
+
+/*
+ * three_nn (pointnet2.py:514): unknown (B,n,3), known (B,m,3) -> dist (B,n,3) = sqrt of the three
+ * smallest squared distances, idx (B,n,3) int32.  Strict '<' insertion: ties keep the earlier k.
+ */
+void oracle_three_nn(const float *unknown, const float *known, int B, int n, int m, float *dist,
+                     int32_t *idx)
+{
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < n; ++i) {
+            const float *u = unknown + ((size_t)b * n + i) * 3;
+            double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+            int i1 = 0, i2 = 0, i3 = 0;
+            for (int k = 0; k < m; ++k) {
+                const float *q = known + ((size_t)b * m + k) * 3;
+                const float d = sqdist3(u[0], u[1], u[2], q[0], q[1], q[2]);
+                if (d < best1) {
+                    best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = k;
+                } else if (d < best2) {
+                    best3 = best2; i3 = i2; best2 = d; i2 = k;
+                } else if (d < best3) {
+                    best3 = d; i3 = k;
+                }
+            }
+            float *dd = dist + ((size_t)b * n + i) * 3;
+            int32_t *ii = idx + ((size_t)b * n + i) * 3;
+            dd[0] = sqrtf((float)best1); dd[1] = sqrtf((float)best2); dd[2] = sqrtf((float)best3);
+            ii[0] = i1; ii[1] = i2; ii[2] = i3;
+        }
+}
+
+/* three_interpolate (pointnet2.py:519): out[b,c,i] = sum_{k=0..2} w[b,i,k] * feat[b,c,idx[b,i,k]],
+ * accumulated in k order: ((w0*f0) + (w1*f1)) + (w2*f2). */
+void oracle_three_interp(const float *feat, const int32_t *idx, const float *w, int B, int C, int m,
+                         int n, float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float *f = feat + ((size_t)b * C + c) * m;
+            for (int i = 0; i < n; ++i) {
+                const int32_t *ii = idx + ((size_t)b * n + i) * 3;
+                const float *ww = w + ((size_t)b * n + i) * 3;
+                volatile float a = ww[0] * f[ii[0]], bb = ww[1] * f[ii[1]], cc = ww[2] * f[ii[2]];
+                volatile float s = a + bb;
+                out[((size_t)b * C + c) * n + i] = s + cc;
+            }
+        }
+}
+
+/* ChamferDistance (evaluations.py:40): dist1[b,i] = min_j |p_i - q_j|^2, dist2[b,j] = min_i. */
+void oracle_chamfer(const float *p, const float *q, int B, int n, int m, float *dist1, float *dist2)
+{
+    for (int b = 0; b < B; ++b) {
+        const float *pb = p + (size_t)b * n * 3, *qb = q + (size_t)b * m * 3;
+        for (int i = 0; i < n; ++i) {
+            float best = INFINITY;
+            for (int j = 0; j < m; ++j) {
+                const float d = sqdist3(pb[i * 3], pb[i * 3 + 1], pb[i * 3 + 2], qb[j * 3], qb[j * 3 + 1], qb[j * 3 + 2]);
+                if (d < best) best = d;
+            }
+            dist1[(size_t)b * n + i] = best;
+        }
+        for (int j = 0; j < m; ++j) {
+            float best = INFINITY;
+            for (int i = 0; i < n; ++i) {
+                const float d = sqdist3(qb[j * 3], qb[j * 3 + 1], qb[j * 3 + 2], pb[i * 3], pb[i * 3 + 1], pb[i * 3 + 2]);
+                if (d < best) best = d;
+            }
+            dist2[(size_t)b * m + j] = best;
+        }
+    }
+}

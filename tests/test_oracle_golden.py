@@ -1,0 +1,153 @@
+"""The CPU oracle (oracle/model.py + oracle/point_ops.c) against fixtures produced by the REAL
+reference modules (tests/golden/gen_golden.py, run where /root/reference exists).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import model as O
+from oracle import point_ops as P
+from caspr_amd.utils.synthetic import car_sequences
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).normal(0, 1, shape) * scale).astype(np.float32))
+
+
+def close(a, b, tol):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    err = np.abs(a - np.asarray(b)).max()
+    assert err <= tol, "max abs err %.3e > %.1e" % (err, tol)
+
+
+def test_state_dict_surface(golden, seeded_sd):
+    assert list(seeded_sd.keys()) == [str(k) for k in golden["state_keys"]]
+    assert [str(tuple(v.shape)) for v in seeded_sd.values()] == [str(s) for s in golden["state_shapes"]]
+    assert len(seeded_sd) == 238
+    assert sum(v.numel() for v in seeded_sd.values()) == 16853630
+
+
+def test_pointnet_global(golden, seeded_sd):
+    out = O.pointnet_global(seeded_sd, rnd(11, 1, 4, 512))
+    close(out[0, :1024, 0], golden["pointnet_gmax"], 2e-6)
+    close(out[0, 1024:, :], golden["pointnet_pointfeat"], 2e-6)
+
+
+def test_feature_extractor(golden, seeded_sd):
+    for name, pre, cin in [("sa0_1", "encoder.local_extract.set_abstractions.0.pointnet_modules.1", 9),
+                           ("sa2_1", "encoder.local_extract.set_abstractions.2.pointnet_modules.1", 131)]:
+        close(O.feature_extractor(seeded_sd, pre, rnd(12, 6, cin, 32, scale=0.5)), golden["feat_extractor_%s" % name], 2e-6)
+
+
+def test_fp_and_final_layers(golden, seeded_sd):
+    sd = seeded_sd
+    x = rnd(13, 1, 518, 128)
+    pre = "encoder.local_extract.feature_propagators.4"
+    import torch.nn.functional as F
+    for l in (0, 3):
+        x = F.relu(O._gn(sd, "%s.unit_pointnet.%d" % (pre, l + 1), O._conv(sd, "%s.unit_pointnet.%d" % (pre, l), x)))
+    close(x[0, :, :16], golden["fp4_unit_pointnet"], 5e-6)
+    x = rnd(14, 1, 512, 128)
+    pre = "encoder.local_extract"
+    x = F.relu(O._gn(sd, pre + ".final_layers.1", O._conv(sd, pre + ".final_layers.0", x)))
+    close(O._conv(sd, pre + ".final_layers.3", x)[0, :, :16], golden["final_layers"], 5e-6)
+
+
+def test_head(golden, seeded_sd):
+    import torch.nn.functional as F
+    sd = seeded_sd
+    feat = rnd(15, 1, 1600, 256)
+    f1 = F.relu(O._gn(sd, "encoder.bn1", O._conv(sd, "encoder.conv1", feat)))
+    f2 = O._gn(sd, "encoder.bn2", O._conv(sd, "encoder.conv2", f1))
+    close(torch.max(f2, 2)[0][0], golden["head_z0"], 5e-6)
+    close(torch.sigmoid(O._conv(sd, "encoder.conv3", F.relu(f2)))[0], golden["head_tnocs"], 2e-6)
+
+
+def test_dynamics_and_mbn(golden, seeded_sd):
+    close(O.dynamics(seeded_sd, rnd(16, 4, 64)), golden["dynamics"], 2e-6)
+    x, lp = rnd(17, 3, 32, 3), rnd(18, 3, 32, 1)
+    y, lo = O.mbn_forward(seeded_sd, "point_cnf.chain.0", x, lp)
+    close(y, golden["mbn_fwd_y"], 1e-6)
+    close(lo, golden["mbn_fwd_logp"], 1e-6)
+    xr, lo = O.mbn_reverse(seeded_sd, "point_cnf.chain.0", x, lp)
+    close(xr, golden["mbn_rev_x"], 1e-6)
+    close(lo, golden["mbn_rev_logp"], 1e-6)
+
+
+def test_odefunc_with_divergence(golden, seeded_sd):
+    y, c, e = rnd(19, 2, 64, 3), rnd(20, 2, 1600), rnd(21, 2, 64, 3)
+    dy, ndiv = O.odefunc(seeded_sd, "point_cnf.chain.1.odefunc", 0.3, y, c, e)
+    close(dy, golden["odefunc_dy"], 2e-6)
+    close(ndiv, golden["odefunc_negdiv"], 5e-6)
+
+
+def test_pipeline_encode_latent_reconstruct(golden, seeded_sd):
+    sd = seeded_sd
+    x, sp = car_sequences(1, 2, 1024, seed=1234)
+    z0, tnocs = O.encode(sd, x)
+    close(z0, golden["pipe_z0"], 1e-5)
+    close(tnocs, golden["pipe_tnocs"], 1e-5)
+    tt = torch.from_numpy(golden["pipe_latent_times"])
+    lat = O.aggregate_and_solve_latent(sd, z0, tt, method="rk4", steps_per_interval=int(golden["latent_steps"]))
+    close(lat[:, :, :80], golden["pipe_latent"], 1e-5)
+    ybase = torch.from_numpy(golden["pipe_ybase"])
+    nfe = [0, 0]
+    _, logp_y, xr, _ = O.reconstruct(sd, x, ybase, timestamps=sp[0, :, 0, 3], cnf_steps=int(golden["cnf_steps"]),
+                                     latent_steps=int(golden["latent_steps"]), nfe=nfe)
+    close(logp_y, golden["pipe_logp_y"], 1e-5)
+    close(xr, golden["pipe_recon_x"], 1e-5)
+    assert nfe == [int(v) for v in golden["pipe_nfe"]]
+
+
+def test_forward_nll(golden, seeded_sd):
+    x, sp = car_sequences(1, 2, 1024, seed=1234)
+    e = rnd(23, 2, 1024, 3)
+    recon, tl = O.forward_nll(seeded_sd, x, sp, e, cnf_steps=int(golden["cnf_steps"]), latent_steps=int(golden["latent_steps"]))
+    close(tl, golden["fwd_tnocs_loss"], 1e-5)
+    err = np.abs(recon.numpy() - golden["fwd_recon_loss"]).max()
+    assert err <= 2e-4, err   # log-density accumulates ~1e3 f32 ops per point
+
+
+def test_point_ops_regression(golden):
+    x, _ = car_sequences(1, 2, 1024, seed=1234)
+    cloud = x.reshape(2, 1024, 4)[:, :, :3].contiguous()
+    idx = P.furthest_point_sampling(cloud, 256)
+    assert np.array_equal(idx.numpy(), golden["ops_fps_idx"])
+    new_xyz = P.fps_gather_by_index(cloud.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    assert np.array_equal(P.ball_query(0.1, 16, cloud, new_xyz).numpy(), golden["ops_ball_idx"])
+    d, i3 = P.three_nn(cloud, new_xyz)
+    assert np.array_equal(i3.numpy(), golden["ops_three_nn_idx"])
+    assert np.array_equal(d.numpy(), golden["ops_three_nn_dist"])
+
+
+def test_point_ops_semantics():
+    """Hand-checkable cases of the operator contracts."""
+    # FPS: start at 0, farthest next; duplicates -> tie broken by (k mod bs, k); M > n repeats index 0
+    pts = torch.tensor([[[1.0, 1, 1], [3.0, 1, 1], [2.0, 1, 1], [3.0, 1, 1]]])
+    assert P.furthest_point_sampling(pts, 3).tolist() == [[0, 1, 2]]
+    assert P.furthest_point_sampling(pts, 6).tolist()[0][:3] == [0, 1, 2]
+    assert P.furthest_point_sampling(pts, 6).tolist()[0][3:] == [0, 0, 0]
+    # padding guard: points with |p|^2 <= 1e-3 are never selected (and never update temp)
+    pts = torch.tensor([[[1.0, 0, 0], [0.0, 0, 0], [2.0, 0, 0], [-5.0, 0.0, 0.0]]])
+    assert P.furthest_point_sampling(pts, 3).tolist() == [[0, 3, 2]]
+    assert P.furthest_point_sampling(pts, 3, guard=False).tolist() == [[0, 3, 1]]   # tie (d=1): lower k mod bs wins
+    # ball query: first hit pads, strict <, ascending index order, at most ns
+    xyz = torch.tensor([[[0.0, 0, 0], [0.05, 0, 0], [0.2, 0, 0], [0.09, 0, 0], [0.1, 0, 0]]])
+    ctr = torch.tensor([[[0.0, 0, 0], [0.2, 0, 0]]])
+    assert P.ball_query(0.1, 4, xyz, ctr).tolist() == [[[0, 1, 3, 0], [2, 2, 2, 2]]]
+    assert P.ball_query(0.1, 2, xyz, ctr).tolist() == [[[0, 1], [2, 2]]]
+    # three_nn: ties keep the earlier index, sqrt distances
+    unk = torch.tensor([[[0.0, 0, 0]]])
+    kn = torch.tensor([[[1.0, 0, 0], [-1.0, 0, 0], [0.0, 2, 0], [0.0, 0, 3.0]]])
+    d, i = P.three_nn(unk, kn)
+    assert i.tolist() == [[[0, 1, 2]]] and d.tolist() == [[[1.0, 1.0, 2.0]]]
+
+
+def test_rk4_vs_dopri5_gap(seeded_sd):
+    """The reference integrates adaptively (flow.py:96-99); report/guard the fixed-step gap of the oracle."""
+    sd = seeded_sd
+    c = rnd(31, 2, 1600)
+    y = rnd(32, 2, 64, 3)
+    x8 = O.point_cnf(sd, y, c, None, True, "rk4", 8)
+    x32 = O.point_cnf(sd, y, c, None, True, "rk4", 32)
+    xd = O.point_cnf(sd, y, c, None, True, "dopri5", 0)
+    assert (x32 - xd).abs().max() < 5e-5      # both converge to the same flow
+    assert (x8 - x32).abs().max() < 5e-4      # 8 steps: discretisation error of the seeded dynamics
