@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""bench.py -- sequences/sec of CaSPR.reconstruct (encode -> latent advect -> CNF sample) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one reconstruct() pass over one batch of synthetic sequences already resident in HBM.
+Workload (BASELINE.json configs[1]): cars.cfg rigid reconstruction, B=16 sequences per GPU, T=10, N=2048,
+num_points=2048, all steps observed (evaluations.py:111-114), f32, fixed-step RK4 (8 CNF steps = 32
+function evaluations, 4 latent steps per interval).  Weak scaling: every rank owns its own 16 sequences
+(sequences are independent) -- no data-path collective; value = all ranks' sequences / max time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the dominant kernel (cnf_rk4_kernel) -- algorithmic FLOPs per launch / mean launch duration
+                 measured with HIP events on the launch stream inside the timed region, vs the dense f32 MFMA peak;
+  cpu_baseline : the CPU oracle (a port: the reference's own CPU path cannot run) timed on this
+                 box's host cores on ONE sequence of the same workload, plus the HIP-vs-oracle parity on that sequence.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+CNF_FLOP_PER_POINT_EVAL = 2 * (3 * 512 + 512 * 512 + 512 * 512 + 512 * 3)   # 1,054,720 (no divergence)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="sequences per GPU")
+    ap.add_argument("--seq-len", type=int, default=10)
+    ap.add_argument("--num-pts", type=int, default=2048)
+    ap.add_argument("--cnf-steps", type=int, default=8)
+    ap.add_argument("--latent-steps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")   # RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (there is no CPU execution path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from caspr_amd import ops
+    from caspr_amd.models import CaSPR
+    from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences
+    from caspr_amd.utils.sharding import max_over_ranks, shard_range
+
+    B, T, N = args.batch, args.seq_len, args.num_pts
+    model = CaSPR(cnf_rk4_steps=args.cnf_steps, latent_rk4_steps=args.latent_steps)
+    sd = seeded_state_dict(model.state_dict(), 0)      # random-init weights of the architecture (no checkpoint available)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+
+    # global batch = world * B sequences; this rank owns a contiguous block (weak scaling)
+    lo, hi = shard_range(world * B, rank, world)
+    x_all, sp_all = car_sequences(hi - lo, T, N, seed=1234 + lo)
+    x = x_all.to(dev)
+    ts = sp_all[0, :, 0, 3].to(dev)
+    torch.manual_seed(rank)
+    ybase = torch.randn(hi - lo, T, N, 3).to(dev)        # base samples (models/utils.py:25), resident before timing
+
+    def step():
+        return model.reconstruct(x, num_points=N, timestamps=ts, y=ybase)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.TIMERS.clear()
+    ops.TIMING = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.TIMING = False
+    elapsed = max_over_ranks(elapsed, dev)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        # ---- roofline of the dominant kernel (cnf_rk4_kernel), HIP events recorded on the launch stream
+        ev = ops.TIMERS.get("cnf_rk4", [])
+        cnf_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        flop = float((hi - lo) * T * N) * 4 * args.cnf_steps * CNF_FLOP_PER_POINT_EVAL
+        achieved = flop / (cnf_ms * 1e-3) / 1e12 if cnf_ms > 0 else 0.0
+        roofline = {"kernel": "cnf_rk4_kernel<false>", "bound": "mfma", "achieved": round(achieved, 3),
+                    "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
+                    "traffic": None, "launch_ms": round(cnf_ms, 3), "launches_timed": len(ev),
+                    "flop_per_launch": flop}
+        breakdown = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in ops.TIMERS.items()}
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import model as O
+            ncores = os.cpu_count() or 1
+            torch.set_num_threads(ncores)
+            xs, ys = x_all[:1], ybase[:1].cpu()
+            t1 = time.perf_counter()
+            _, _, wx, wt = O.reconstruct(sd, xs, ys, timestamps=sp_all[0, :, 0, 3], cnf_steps=args.cnf_steps,
+                                         latent_steps=args.latent_steps)
+            cpu_s = time.perf_counter() - t1
+            gx, gt = out[2][:1].cpu(), out[3][:1].cpu()
+            gt_pts = sp_all[:1, :, :, :3].reshape(T, N, 3).contiguous()
+            cd_cpu = O.chamfer_l2(wx.reshape(T, N, 3), gt_pts)
+            d1, d2 = ops.chamfer_distance(out[2][:1].reshape(T, N, 3).contiguous(), gt_pts.to(dev))
+            cd_gpu = (d1.mean(dim=1) + d2.mean(dim=1)).cpu()
+            cpu = {"value": round(1.0 / cpu_s, 5), "unit": "sequences/sec", "cores": ncores, "kind": "port",
+                   "sample": "1 sequence (T=%d, N=%d, num_points=%d) of the same workload through oracle.model.reconstruct "
+                             "(torch-CPU + C point ops, same RK4 steps), %.1f s" % (T, N, N, cpu_s),
+                   "parity": {"x_max_abs_err": float((gx - wx).abs().max()), "tnocs_max_abs_err": float((gt - wt).abs().max()),
+                              "chamfer_l2_mean": float(cd_gpu.mean()), "chamfer_l2_max_abs_diff": float((cd_gpu - cd_cpu).abs().max())}}
+
+        print(json.dumps({
+            "metric": "sequences/sec (CaSPR.reconstruct, rigid-cars T=10 N=2048)", "value": round(value, 3), "unit": "sequences/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cars.cfg rigid recon (BASELINE.json configs[1]): reconstruct(), B=%d sequences/GPU, T=%d, N=%d, "
+                                   "num_points=%d, all steps observed; seeded random-init weights" % (B, T, N, N),
+                       "global_batch": world * B, "seq_len": T, "num_pts": N, "cnf_rk4_steps": args.cnf_steps,
+                       "latent_rk4_steps": args.latent_steps, "cnf_divergence": "skipped (sampling)", "parallelism": "seq-shard x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_step": breakdown,
+        }))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

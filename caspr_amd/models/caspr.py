@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .tpointnet2 import TPointNet2
 from .latent_ode_model import LatentODE
 from .flow import get_point_cnf, count_nfe, PointCNFArgs
@@ -141,6 +142,8 @@ class CaSPR(nn.Module):
                 all_times = x[:, :, 0, 3] / max_timestamp
             else:
                 all_times = timestamps.view((1, -1)).repeat((B, 1)).to(x)
-            z = self.aggregate_and_solve_latent(z0, all_times)
-            y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y)
+            with ops.timed("latent"):
+                z = self.aggregate_and_solve_latent(z0, all_times)
+            with ops.timed("decode"):
+                y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y)
             return y, logp_y, x, tnocs_pred

@@ -80,13 +80,17 @@ class TPointNet2(nn.Module):
         # one buffer holds the head's input [local (L) | raw global conv1 output (S)]
         X1 = torch.empty(B, P, L + S, device=x.device, dtype=torch.float32)
         # global spatio-temporal feature (tpointnet2.py:75-76)
-        pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
+        with ops.timed("enc_global_pointnet"):
+            pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
         # local spatial feature per time step (tpointnet2.py:79-93)
         xyz, feat = ops.prep_input(x, self.augment_quad, self.augment_pairs)
         C = (3 if self.augment_quad else 0) + (3 if self.augment_pairs else 0)
         if C == 0:
             feat = None
-        self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record)
+        with ops.timed("enc_local_pointnet2"):
+            self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record)
+        t_head = ops.timed("enc_head")
+        t_head.__enter__()
 
         (w_pt, w_g), p2, p3 = self._head_weights()
         # conv1 over [local | global max (tiled) | point feature]  (tpointnet2.py:96-99)
@@ -104,6 +108,7 @@ class TPointNet2(nn.Module):
         if self.regress_tnocs:
             t = ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1)  # :105-106
             tnocs_regression = t[:, :, :self.tnocs_point_size].reshape(B, T, N, self.tnocs_point_size)
+        t_head.__exit__()
         return z0, tnocs_regression
 
     def loss(self, outputs, gt):

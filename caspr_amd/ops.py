@@ -15,6 +15,31 @@ import torch
 from . import lib as _lib
 
 
+# Optional stage timing with HIP events recorded on the launch stream (bench.py's roofline numbers).
+TIMING = False
+TIMERS = {}
+
+
+class timed:
+    """with ops.timed("name"): ...  -> appends a (start, end) event pair to TIMERS[name] when TIMING is on."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMING:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(torch.cuda.current_stream())
+            TIMERS.setdefault(self.name, []).append((self.t0, t1))
+        return False
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -244,10 +269,11 @@ def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reve
     BT, n, _ = y.shape
     out = torch.empty_like(y)
     lp_out = torch.empty(BT, n, 1, device=y.device, dtype=torch.float32) if e is not None else None
-    _lib.check(_lib.load().caspr_cnf_rk4_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1p.data), _p(b1),
-                                             _p(w2p.data), _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps), int(bool(reverse)),
-                                             _p(mbn_in), _p(mbn_out), _p(e), _p(logp), _p(lp_out), _p(out), BT, n, _stream()),
-               "caspr_cnf_rk4_f32")
+    with timed("cnf_rk4"):
+        _lib.check(_lib.load().caspr_cnf_rk4_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1p.data), _p(b1),
+                                                 _p(w2p.data), _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps), int(bool(reverse)),
+                                                 _p(mbn_in), _p(mbn_out), _p(e), _p(logp), _p(lp_out), _p(out), BT, n, _stream()),
+                   "caspr_cnf_rk4_f32")
     return out if e is None else (out, lp_out)
 
 

@@ -1,0 +1,378 @@
+"""Parity of the HIP kernels (through the C-ABI, via caspr_amd.ops / caspr_amd.models) against the CPU
+oracle on identical seeded inputs.  Integer outputs (FPS / ball-query / three-NN indices) must be
+bit-exact; floating-point outputs within the tolerance written next to each check (north_star: 1e-5 abs
+for T-NOCS and CNF-sampled xyz).  Every measured error is also appended to gpurun_out/parity_report.json.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import model as O
+from oracle import point_ops as P
+from caspr_amd.utils.synthetic import car_sequences, random_clouds
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REPORT = {}
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).normal(0, 1, shape) * scale).astype(np.float32))
+
+
+def record(name, got, want, tol):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
+    want = want.detach().cpu().double().numpy() if torch.is_tensor(want) else np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
+    err = float(np.abs(got - want).max()) if got.size else 0.0
+    REPORT[name] = {"max_abs_err": err, "tol": tol, "ref_absmax": float(np.abs(want).max()) if want.size else 0.0}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+    assert np.isfinite(got).all(), "%s: non-finite output" % name
+    assert err <= tol, "%s: max abs err %.3e > %.1e (|ref|max %.3e)" % (name, err, tol, REPORT[name]["ref_absmax"])
+
+
+def exact(name, got, want):
+    got, want = got.cpu().numpy(), want.cpu().numpy()
+    bad = int((got != want).sum())
+    REPORT[name] = {"mismatches": bad, "count": int(want.size)}
+    assert bad == 0, "%s: %d / %d entries differ" % (name, bad, want.size)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need a ROCm GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from caspr_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def model(dev, seeded_sd):
+    from caspr_amd.models import CaSPR
+    m = CaSPR()
+    m.load_state_dict(seeded_sd)
+    return m.to(dev).eval()
+
+
+def clouds(B, n, seed=0, dup=False):
+    x, _ = car_sequences(B, 1, n, seed=100 + seed)
+    c = x[:, 0, :, :3].contiguous()
+    if dup:  # dataset padding duplicates leading points (caspr_dataset.py:188-195) -> exact ties
+        c[:, n // 2:] = c[:, : n - n // 2]
+    return c
+
+
+# ---------------------------------------------------------------------------------------------
+# index operators: bit-exact
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,M,dup", [(2048, 1024, False), (1024, 512, False), (512, 256, True), (256, 64, False),
+                                    (64, 16, False), (512, 1024, False), (4096, 1024, False), (100, 37, True)])
+def test_fps_bit_exact(ops, dev, n, M, dup):
+    c = clouds(3, n, seed=n + M, dup=dup)
+    want = P.furthest_point_sampling(c, M)
+    got, new_xyz = ops.furthest_point_sampling(c.to(dev), M, return_xyz=True)
+    exact("fps_idx_n%d_M%d" % (n, M), got, want)
+    exact("fps_newxyz_n%d_M%d" % (n, M), new_xyz, torch.gather(c, 1, want.long().unsqueeze(-1).expand(-1, -1, 3)))
+
+
+def test_fps_guard_and_origin(ops, dev):
+    c = clouds(2, 256, seed=5)
+    c[:, 10:40] = 0.0           # padded origin points are skipped by the guard
+    c[0, 0] = 0.0               # even the start index may be guarded
+    for guard in (True, False):
+        exact("fps_guard%d" % guard, ops.furthest_point_sampling(c.to(dev), 64, guard=guard), P.furthest_point_sampling(c, 64, guard=guard))
+
+
+@pytest.mark.parametrize("n,M,r,ns", [(2048, 1024, 0.02, 16), (2048, 1024, 0.05, 32), (1024, 512, 0.1, 32), (256, 64, 0.4, 32),
+                                     (64, 16, 0.8, 32), (64, 16, 0.4, 16), (300, 50, 0.2, 16)])
+def test_ball_query_bit_exact(ops, dev, n, M, r, ns):
+    c = clouds(2, n, seed=n, dup=(n == 300))
+    ctr = torch.gather(c, 1, P.furthest_point_sampling(c, M).long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    exact("ball_n%d_r%g_ns%d" % (n, r, ns), ops.ball_query(r, ns, c.to(dev), ctr.to(dev)), P.ball_query(r, ns, c, ctr))
+
+
+def test_ball_query_empty_ball(ops, dev):
+    c = clouds(1, 128)
+    ctr = torch.tensor([[[10.0, 10.0, 10.0], [c[0, 5, 0], c[0, 5, 1], c[0, 5, 2]]]])
+    exact("ball_empty", ops.ball_query(0.05, 16, c.to(dev), ctr.to(dev)), P.ball_query(0.05, 16, c, ctr))
+
+
+def test_group_and_gather(ops, dev):
+    c = clouds(2, 512, seed=3)
+    feat = rnd(1, 2, 512, 8)
+    idx = P.furthest_point_sampling(c, 128)
+    ctr = torch.gather(c, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    bidx = P.ball_query(0.2, 16, c, ctr)
+    want = P.group(c, ctr, feat.transpose(1, 2).contiguous(), bidx)
+    got = ops.group_points(c.to(dev), ctr.to(dev), feat.to(dev), bidx.to(dev))
+    exact("group_points", got, want)
+    exact("gather_points", ops.gather_points(feat.to(dev), idx.to(dev)), torch.gather(feat, 1, idx.long().unsqueeze(-1).expand(-1, -1, 8)))
+
+
+@pytest.mark.parametrize("n,m", [(2048, 1024), (1024, 512), (256, 64), (64, 16), (77, 33)])
+def test_three_nn(ops, dev, n, m):
+    c = clouds(2, n, seed=n, dup=(n == 77))
+    kn = c[:, :m].contiguous() if n != 77 else clouds(2, m, seed=9)
+    d, i = P.three_nn(c, kn)
+    gd, gi, gw = ops.three_nn(c.to(dev), kn.to(dev), with_weights=True)
+    exact("three_nn_idx_%d_%d" % (n, m), gi, i)
+    exact("three_nn_dist_%d_%d" % (n, m), gd, d)
+    inv = 1.0 / (d + 1e-8)
+    record("three_nn_weight_%d_%d" % (n, m), gw, inv / inv.sum(dim=2, keepdim=True), 1e-6)
+
+
+def test_three_interpolate(ops, dev):
+    c = clouds(2, 256, seed=1)
+    kn = c[:, :64].contiguous()
+    d, i = P.three_nn(c, kn)
+    inv = 1.0 / (d + 1e-8)
+    w = (inv / inv.sum(dim=2, keepdim=True)).contiguous()
+    feat = rnd(2, 2, 64, 512)
+    skip = rnd(3, 2, 256, 8)
+    want = P.three_interpolate(feat.transpose(1, 2).contiguous(), i, w).transpose(1, 2)
+    got = ops.three_interpolate(feat.to(dev), i.to(dev), w.to(dev), skip=skip.to(dev), skip_channels=6)
+    assert got.shape == (2, 256, 520)
+    record("three_interp", got[:, :, :512], want, 1e-6)
+    exact("three_interp_skip", got[:, :, 512:518], skip[:, :, :6])
+    assert float(got[:, :, 518:].abs().max()) == 0.0
+    # with the producer's GroupNorm+ReLU folded into the load
+    sc, sh = rnd(4, 2, 512).abs() + 0.5, rnd(5, 2, 512)
+    fa = torch.relu(feat * sc.unsqueeze(1) + sh.unsqueeze(1))
+    want = P.three_interpolate(fa.transpose(1, 2).contiguous(), i, w).transpose(1, 2)
+    got = ops.three_interpolate(feat.to(dev), i.to(dev), w.to(dev), in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)
+    record("three_interp_lazy", got, want, 2e-6)
+
+
+def test_chamfer(ops, dev):
+    p, q = clouds(3, 2048, seed=1), clouds(3, 1500, seed=2)
+    d1, d2 = P.chamfer(p, q)
+    g1, g2 = ops.chamfer_distance(p.to(dev), q.to(dev))
+    exact("chamfer_d1", g1, d1)
+    exact("chamfer_d2", g2, d2)
+    z1, _ = ops.chamfer_distance(p.to(dev), p.to(dev))
+    assert float(z1.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# MFMA pointwise conv + GroupNorm statistics
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 300, 4, 64), (2, 256, 64, 128), (1, 130, 128, 1024), (3, 64, 1536, 512),
+                                          (2, 200, 518, 512), (1, 256, 576, 1600), (1, 384, 1600, 1600), (2, 100, 1600, 4),
+                                          (1, 20, 1600, 3078), (1, 1, 1024, 1600)])
+def test_conv1x1(ops, dev, B, P_, Cin, Cout):
+    ldx = (Cin + 3) // 4 * 4
+    x = torch.zeros(B, P_, ldx)
+    x[:, :, :Cin] = rnd(Cin + Cout, B, P_, Cin)
+    x[:, :, Cin:] = 7.0  # padding columns must be ignored
+    w = rnd(1, Cout, Cin, scale=1.0 / np.sqrt(Cin))
+    b = rnd(2, Cout, scale=0.1)
+    want = (x[:, :, :Cin].double() @ w.double().t() + b.double())
+    pw = ops.PackedWeight(w.to(dev))
+    got = ops.conv1x1(pw, b.to(dev), x.to(dev))
+    assert got.shape == (B, P_, (Cout + 3) // 4 * 4)
+    record("conv1x1_%dx%d" % (Cin, Cout), got[:, :, :Cout], want, 2e-6 * max(1.0, float(want.abs().max())))
+
+
+def test_conv1x1_fused_input_and_epilogues(ops, dev):
+    B, P_, Cin, Cout = 2, 333, 576, 200
+    x = rnd(1, B, P_, Cin)
+    w, b = rnd(2, Cout, Cin, scale=0.05), rnd(3, Cout, scale=0.1)
+    sc, sh, bb = rnd(4, B, Cin).abs() + 0.5, rnd(5, B, Cin), rnd(6, B, Cout)
+    xin = x * sc.unsqueeze(1) + sh.unsqueeze(1)
+    xin[:, :, 512:] = torch.relu(xin[:, :, 512:])
+    want = torch.sigmoid(xin.double() @ w.double().t() + b.double() + bb.double().unsqueeze(1))
+    pw = ops.PackedWeight(w.to(dev))
+    buf = torch.zeros(B, P_, 256, device=dev)
+    got = ops.conv1x1(pw, b.to(dev), x.to(dev), bbias=bb.to(dev), in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True,
+                      in_relu_from=512, act=1, out=buf[:, :, 32:232])
+    record("conv1x1_fused", got, want, 2e-6)
+    assert float(buf[:, :, :32].abs().max()) == 0.0 and float(buf[:, :, 232:].abs().max()) == 0.0
+    # column-sliced packing == packing the slice
+    pw2 = ops.PackedWeight(torch.cat([torch.zeros(Cout, 1), w], 1).to(dev), col0=1)
+    assert torch.equal(pw2.data, pw.data)
+
+
+@pytest.mark.parametrize("B,P_,C", [(2, 2500, 64), (1, 1024, 1600), (3, 64, 512), (2, 1100, 1024), (2, 333, 128)])
+def test_gn_stats(ops, dev, B, P_, C):
+    y = rnd(C, B, P_, C) * 2.0 + 0.7
+    gamma, beta = rnd(1, C) * 0.2 + 1.0, rnd(2, C) * 0.1
+    gamma[::7] *= -1.0  # negative scales exercise the min branch of the fused max
+    want = F.group_norm(y.transpose(1, 2).double(), 16, gamma.double(), beta.double(), 1e-5).transpose(1, 2)
+    sc, sh, pm = ops.gn_stats(y.to(dev), C, gamma.to(dev), beta.to(dev), want_max=True)
+    got = y.to(dev) * sc.unsqueeze(1) + sh.unsqueeze(1)
+    record("gn_apply_C%d" % C, got, want, 5e-6)
+    record("gn_max_C%d" % C, pm, want.max(dim=1)[0], 5e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused set-abstraction scale
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("level,scale", [(0, 0), (0, 1), (1, 0), (2, 1), (3, 0), (4, 1)])
+def test_sa_mlp_max(dev, seeded_sd, model, level, scale):
+    from caspr_amd import ops
+    sa = model.encoder.local_extract.set_abstractions[level]
+    n_in = [2048, 1024, 512, 256, 64][level]
+    C = [6, 96, 128, 256, 512][level]
+    M = sa.num_points_out
+    c = clouds(2, n_in, seed=level)
+    if level > 0:
+        c = c * [1, 1.5, 2.0, 3.0, 4.0][level]  # coarser levels see sparser clouds
+    feat = rnd(level + 7, 2, n_in, C, scale=0.7)
+    idx = P.furthest_point_sampling(c, M)
+    ctr = torch.gather(c, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    g = sa.grouper_modules[scale]
+    bidx = P.ball_query(g.radius, g.num_samples, c, ctr)
+    grouped = P.group(c, ctr, feat.transpose(1, 2).contiguous(), bidx)
+    pre = "encoder.local_extract.set_abstractions.%d.pointnet_modules.%d" % (level, scale)
+    want = O.feature_extractor(seeded_sd, pre, grouped.view(-1, C + 3, g.num_samples)).view(2, M, -1)
+    ldf = (C + 3) // 4 * 4
+    fpad = torch.zeros(2, n_in, ldf)
+    fpad[:, :, :C] = feat
+    out = torch.zeros(2, M, want.shape[2] + 8, device=dev)
+    ops.sa_mlp_max(c.to(dev), ctr.to(dev), fpad.to(dev), bidx.to(dev), C, sa.pointnet_modules[scale].kernel_layers(), out, 8)
+    record("sa_mlp_l%d_s%d" % (level, scale), out[:, :, 8:], want, 1e-5)
+    assert float(out[:, :, :8].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# latent ODE and CNF
+# ---------------------------------------------------------------------------------------------
+def test_latent_rk4(dev, seeded_sd, model):
+    z0 = rnd(1, 5, 1600)
+    times = torch.tensor([0.0, 0.1, 0.35, 0.5, 1.0])
+    want = O.latent_solve(seeded_sd, z0[:, :64], times, "rk4", 4)
+    got = model.latent_ode(z0.to(dev)[:, :64], times.to(dev))
+    record("latent_rk4", got, want, 1e-5)
+    assert model.latent_ode.num_evals() == 4 * 4 * 4
+
+
+@pytest.mark.parametrize("n,steps", [(256, 8), (100, 3)])
+def test_cnf_sample(dev, seeded_sd, model, n, steps):
+    BT = 3
+    c, y = rnd(31, BT, 1600), rnd(32, BT, n, 3)
+    want = O.point_cnf(seeded_sd, y, c, None, True, "rk4", steps)
+    model.point_cnf.chain[1].rk4_steps = steps
+    got = model.point_cnf(y.to(dev), c.to(dev), reverse=True)
+    model.point_cnf.chain[1].rk4_steps = 8
+    record("cnf_sample_n%d_s%d" % (n, steps), got, want, 1e-5)
+
+
+def test_cnf_forward_with_divergence(dev, seeded_sd, model):
+    BT, n = 2, 96
+    c, x, e = rnd(41, BT, 1600), rnd(42, BT, n, 3, scale=0.5), rnd(43, BT, n, 3)
+    wy, wlp = O.point_cnf(seeded_sd, x, c, torch.zeros(BT, n, 1), False, "rk4", 8, e)
+    gy, glp = model.point_cnf(x.to(dev), c.to(dev), torch.zeros(BT, n, 1, device=dev), e=e.to(dev))
+    record("cnf_fwd_y", gy, wy, 1e-5)
+    record("cnf_fwd_logp", glp, wlp, 1e-4)
+    # sampling ignores the divergence: xyz of the with-div kernel == xyz of the plain kernel (same direction)
+    gy2 = model.point_cnf(x.to(dev), c.to(dev), reverse=False)
+    record("cnf_fwd_y_nodiv_vs_div", gy2, gy, 1e-6)
+    # flow then inverse flow returns to the start (fixed-step RK4 is reversible to O(h^5))
+    back = model.point_cnf(gy2, c.to(dev), reverse=True)
+    record("cnf_roundtrip", back, x, 2e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# end to end
+# ---------------------------------------------------------------------------------------------
+def test_encode_parity(dev, seeded_sd, model):
+    x, _ = car_sequences(2, 2, 1024, seed=1234)
+    inter = []
+    z0, tnocs = O.encode(seeded_sd, x, intermediates=inter)
+    model.encoder.record = []
+    gz0, gt = model.encode(x.to(dev))
+    rec, model.encoder.record = model.encoder.record, None
+    for l in range(5):
+        exact("enc_fps_l%d" % l, rec[l]["fps_idx"], inter[l]["fps_idx"])
+        for s in range(2):
+            exact("enc_ball_l%d_s%d" % (l, s), rec[l]["ball_idx"][s], inter[l]["ball_idx"][s])
+    record("enc_tnocs", gt, tnocs, 1e-5)
+    record("enc_z0", gz0, z0, 2e-5)
+
+
+def test_reconstruct_vs_golden_and_oracle(dev, seeded_sd, model, golden):
+    x, sp = car_sequences(1, 2, 1024, seed=1234)
+    ybase = torch.from_numpy(golden["pipe_ybase"])
+    gy, glp, gx, gt = model.reconstruct(x.to(dev), num_points=256, timestamps=sp[0, :, 0, 3].to(dev), y=ybase.to(dev))
+    record("recon_x_vs_reference_golden", gx, golden["pipe_recon_x"], 1e-5)
+    record("recon_tnocs_vs_reference_golden", gt, golden["pipe_tnocs"], 1e-5)
+    record("recon_logp_y", glp, golden["pipe_logp_y"], 1e-5)
+    assert [int(v) for v in model.get_nfe()] == [int(v) for v in golden["pipe_nfe"]]
+    # Chamfer-L2 (evaluations.py:40-43) of the reconstruction against the NOCS ground truth: HIP vs oracle
+    from caspr_amd import ops
+    gt_pts = sp[0, :, :256, :3].contiguous()
+    d1, d2 = ops.chamfer_distance(gx.view(2, 256, 3).contiguous(), gt_pts.to(dev))
+    cd = d1.mean(dim=1) + d2.mean(dim=1)
+    want = O.chamfer_l2(torch.from_numpy(golden["pipe_recon_x"]).view(2, 256, 3), gt_pts)
+    record("recon_chamfer_l2", cd, want, 1e-5)
+
+
+def test_reconstruct_base_samples_from_cpu_generator(dev, model):
+    """Base samples come from the CPU generator exactly as models/utils.py:25 (reproducible from manual_seed)."""
+    x, sp = car_sequences(1, 2, 1024, seed=7)
+    torch.manual_seed(0)
+    y1, _, x1, _ = model.reconstruct(x.to(dev), num_points=128, timestamps=sp[0, :, 0, 3].to(dev))
+    torch.manual_seed(0)
+    want = torch.randn(2, 128, 3).view(1, 2, 128, 3)
+    exact("decode_base_samples", y1, want)
+    torch.manual_seed(0)
+    y2, _, x2, _ = model.reconstruct(x.to(dev), num_points=128, timestamps=sp[0, :, 0, 3].to(dev))
+    exact("reconstruct_deterministic", x2, x1)
+
+
+def test_forward_nll_vs_golden(dev, model, golden):
+    x, sp = car_sequences(1, 2, 1024, seed=1234)
+    e = rnd(23, 2, 1024, 3)
+    recon, tl = model(x.to(dev), sp.to(dev), e=e.to(dev))
+    record("fwd_tnocs_loss", tl, golden["fwd_tnocs_loss"], 1e-5)
+    record("fwd_recon_loss", recon, golden["fwd_recon_loss"], 5e-4)
+
+
+def test_demo_config_shape(dev, seeded_sd, model):
+    """configs[0] of BASELINE.json: seq-len 5, 512 points (N < 1024 = SA1 centres: FPS repeats indices)."""
+    x, sp = car_sequences(1, 5, 512, seed=3)
+    z0, tnocs = O.encode(seeded_sd, x)
+    gz0, gt = model.encode(x.to(dev))
+    record("demo_tnocs", gt, tnocs, 1e-5)
+    record("demo_z0", gz0, z0, 2e-5)
+
+
+def test_full_size_properties(dev, model):
+    """cars.cfg recon shape (T=10, N=2048) through size-independent properties (the oracle is too slow here)."""
+    from caspr_amd import ops
+    B, T, N = 4, 10, 2048
+    x, sp = car_sequences(B, T, N, seed=99)
+    xd = x.to(dev)
+    xyz = xd.view(B * T, N, 4)[:, :, :3].contiguous()
+    # FPS: indices distinct, and the M=512 run is a prefix of the M=1024 run
+    i1024 = ops.furthest_point_sampling(xyz, 1024)
+    i512 = ops.furthest_point_sampling(xyz, 512)
+    assert torch.equal(i1024[:, :512], i512)
+    assert all(len(set(r.tolist())) == 1024 for r in i1024[:3].cpu())
+    # ball query: every neighbour lies inside the ball, valid prefix ascending
+    ctr = torch.gather(xyz, 1, i1024.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    bi = ops.ball_query(0.05, 32, xyz, ctr)
+    nb = torch.gather(xyz.unsqueeze(1).expand(-1, 1024, -1, -1)[:2], 2, bi[:2].long().unsqueeze(-1).expand(-1, -1, -1, 3))
+    d2 = ((nb - ctr[:2].unsqueeze(2)) ** 2).sum(-1)
+    assert float(d2.max()) < 0.05 * 0.05 * (1 + 1e-5)
+    # sequences are independent: reconstructing a batch == reconstructing its halves (sharding invariance)
+    torch.manual_seed(1)
+    ybase = torch.randn(B, T, N, 3)
+    ts = sp[0, :, 0, 3].to(dev)
+    _, _, xa, ta = model.reconstruct(xd, num_points=N, timestamps=ts, y=ybase.to(dev))
+    _, _, xb, tb = model.reconstruct(xd[2:], num_points=N, timestamps=ts, y=ybase[2:].to(dev))
+    exact("shard_invariance_x", xa[2:], xb)
+    exact("shard_invariance_tnocs", ta[2:], tb)
+    assert torch.isfinite(xa).all() and float(ta.min()) > 0.0 and float(ta.max()) < 1.0
+    assert [int(v) for v in model.get_nfe()] == [4 * 4 * 9, 32]
