@@ -18,99 +18,151 @@
 #define CNF_KC (CNF_H / 16)  // 32 chunks of 16 k
 
 // ---------------------------------------------------------------------------------------------
-// latent ODE
+// latent ODE.  The dynamics net is a GEMV per sequence -- latency-bound if run one sequence per
+// workgroup (each thread a 512-long dependent FMA chain on L2 loads).  Instead ONE 512-thread workgroup
+// advects up to 16 sequences at once: the batch is the N=16 column dimension of the f32 MFMA tile, the
+// hidden state is an LDS B-tile, each wave owns 64 of the 512 hidden units and streams its packed
+// weights from L2 (read once per evaluation for all 16 sequences).  RK4 state lives in LDS.
 // ---------------------------------------------------------------------------------------------
+#define LAT_NCOL 16
+
+// out rows [16*rt0, 16*(rt0+nrt)) of W (packed, KC chunks) times the B-tile `in`; epilogue(rt, acc)
+template <int NRT, typename Epi>
+__device__ __forceinline__ void lat_layer(const float *__restrict__ wp, int KC, int rt0, const float *in, int lane, Epi epi)
+{
+    const int g = lane >> 4, j = lane & 15;
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float *wb = wp + ((long)rt0 * KC) * 256 + lane * 4;
+#pragma unroll 4
+    for (int kc = 0; kc < KC; ++kc) {
+        const f32x4 bf = ld4(in + btile_off(kc * 4 + g, j, LAT_NCOL));
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const f32x4 af = ld4(wb + ((long)i * KC + kc) * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i] = mfma16(af[q], bf[q], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) epi(rt0 + i, acc[i]);
+}
+
 __global__ __launch_bounds__(512) void latent_rk4_kernel(const float *__restrict__ z0, int ldz,
-                                                         const float *__restrict__ times, int Tu, int D, int H,
-                                                         int steps, const float *__restrict__ w0t,
-                                                         const float *__restrict__ b0, const float *__restrict__ w1t,
-                                                         const float *__restrict__ b1, const float *__restrict__ w2t,
-                                                         const float *__restrict__ b2, const float *__restrict__ w3t,
+                                                         const float *__restrict__ times, int B, int Tu, int D, int H,
+                                                         int steps, const float *__restrict__ w0p,
+                                                         const float *__restrict__ b0, const float *__restrict__ w1p,
+                                                         const float *__restrict__ b1, const float *__restrict__ w2p,
+                                                         const float *__restrict__ b2, const float *__restrict__ w3p,
                                                          const float *__restrict__ b3, float *__restrict__ out)
 {
-    __shared__ float s_in[64], s_h1[512], s_h2[512], s_part[8][64];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int o = tid & 63, part = tid >> 6;
-    float z = 0.f, acc = 0.f, k = 0.f;
-    if (tid < D) {
-        z = z0[(long)b * ldz + tid];
-        out[((long)b * Tu) * D + tid] = z;
+    // B-tiles: stage input (64 x 16, padded to 32 k-rows of 4), two hidden buffers (512 x 16)
+    __shared__ __attribute__((aligned(16))) float s_in[16 * LAT_NCOL * 4];
+    __shared__ __attribute__((aligned(16))) float s_h1[128 * LAT_NCOL * 4], s_h2[128 * LAT_NCOL * 4];
+    __shared__ float s_z[64 * LAT_NCOL], s_acc[64 * LAT_NCOL], s_k[64 * LAT_NCOL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int b0i = blockIdx.x * LAT_NCOL;
+    const int KC0 = 2 * ((D + 31) / 32), KCH = 2 * ((H + 31) / 32);
+    const int RTH = (H + 15) / 16, RTD = (D + 15) / 16;
+
+    for (int i = tid; i < 64 * LAT_NCOL; i += 512) {
+        const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+        const float v = (d < D && b0i + c < B) ? z0[(long)(b0i + c) * ldz + d] : 0.f;
+        s_z[i] = v;
+        if (d < D && b0i + c < B) out[((long)(b0i + c) * Tu) * D + d] = v;
     }
-    auto dyn = [&]() {  // s_in -> k (valid for tid < D); all threads participate
-        __syncthreads();
-        if (tid < H) {
-            float s = 0.f;
-            for (int kk = 0; kk < D; ++kk) s += w0t[kk * H + tid] * s_in[kk];
-            s_h1[tid] = tanhf(s + b0[tid]);
-        }
-        __syncthreads();
-        if (tid < H) {
-            float s = 0.f;
-            for (int kk = 0; kk < H; ++kk) s += w1t[kk * H + tid] * s_h1[kk];
-            s_h2[tid] = tanhf(s + b1[tid]);
-        }
-        __syncthreads();
-        if (tid < H) {
-            float s = 0.f;
-            for (int kk = 0; kk < H; ++kk) s += w2t[kk * H + tid] * s_h2[kk];
-            s_h1[tid] = tanhf(s + b2[tid]);
-        }
-        __syncthreads();
-        {
-            float s = 0.f;
-            if (o < D) {
-                const int chunk = (H + 7) / 8;
-                const int k0 = part * chunk, k1 = (k0 + chunk) < H ? (k0 + chunk) : H;
-                for (int kk = k0; kk < k1; ++kk) s += w3t[kk * D + o] * s_h1[kk];
-            }
-            s_part[part][o] = s;
-        }
-        __syncthreads();
-        if (tid < D) {
-            float s = 0.f;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) s += s_part[p][tid];
-            k = s + b3[tid];
+    for (int i = tid; i < 16 * LAT_NCOL * 4; i += 512) s_in[i] = 0.f;   // K padding rows stay zero
+    for (int i = tid; i < 128 * LAT_NCOL * 4; i += 512) { s_h1[i] = 0.f; s_h2[i] = 0.f; }
+    __syncthreads();
+
+    auto write_in = [&](float a, const float *kv) {  // s_in = z + a*k as a B-tile (row d, col c)
+        for (int i = tid; i < 64 * LAT_NCOL; i += 512) {
+            const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+            if (d < D) s_in[btile_off(d >> 2, c, LAT_NCOL) + (d & 3)] = kv ? s_z[i] + a * kv[i] : s_z[i];
         }
     };
+    auto dyn = [&]() {  // s_in -> s_k ; latent_ode_model.py:139-147 (Linear-Tanh x3, Linear)
+        __syncthreads();
+        for (int rt = wave * 4; rt < RTH; rt += 32)
+            lat_layer<4>(w0p, KC0, rt, s_in, lane, [&](int r, f32x4 a) {
+                const f32x4 bb = ld4(b0 + r * 16 + 4 * g);
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = tanhf(a[q] + bb[q]);
+                st4(s_h1 + btile_off(r * 4 + g, j, LAT_NCOL), v);
+            });
+        __syncthreads();
+        for (int rt = wave * 4; rt < RTH; rt += 32)
+            lat_layer<4>(w1p, KCH, rt, s_h1, lane, [&](int r, f32x4 a) {
+                const f32x4 bb = ld4(b1 + r * 16 + 4 * g);
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = tanhf(a[q] + bb[q]);
+                st4(s_h2 + btile_off(r * 4 + g, j, LAT_NCOL), v);
+            });
+        __syncthreads();
+        for (int rt = wave * 4; rt < RTH; rt += 32)
+            lat_layer<4>(w2p, KCH, rt, s_h2, lane, [&](int r, f32x4 a) {
+                const f32x4 bb = ld4(b2 + r * 16 + 4 * g);
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = tanhf(a[q] + bb[q]);
+                st4(s_h1 + btile_off(r * 4 + g, j, LAT_NCOL), v);
+            });
+        __syncthreads();
+        if (wave < RTD)
+            lat_layer<1>(w3p, KCH, wave, s_h1, lane, [&](int r, f32x4 a) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int d = r * 16 + 4 * g + q;
+                    if (d < D) s_k[d * LAT_NCOL + j] = a[q] + b3[d];
+                }
+            });
+        __syncthreads();
+    };
+
     const float t_first = times[0];
     for (int ti = 1; ti < Tu; ++ti) {
         const float r0 = times[ti - 1] - t_first, r1 = times[ti] - t_first;  // latent_ode_model.py:58
         const double h = ((double)r1 - (double)r0) / (double)steps;
         const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
         for (int s = 0; s < steps; ++s) {
-            if (tid < D) s_in[tid] = z;
+            write_in(0.f, nullptr);
             dyn();
-            acc = k;
-            __syncthreads();
-            if (tid < D) s_in[tid] = z + h2 * k;
+            for (int i = tid; i < 64 * LAT_NCOL; i += 512) s_acc[i] = s_k[i];
+            write_in(h2, s_k);
             dyn();
-            acc = acc + 2.0f * k;
-            __syncthreads();
-            if (tid < D) s_in[tid] = z + h2 * k;
+            for (int i = tid; i < 64 * LAT_NCOL; i += 512) s_acc[i] = s_acc[i] + 2.0f * s_k[i];
+            write_in(h2, s_k);
             dyn();
-            acc = acc + 2.0f * k;
-            __syncthreads();
-            if (tid < D) s_in[tid] = z + hh * k;
+            for (int i = tid; i < 64 * LAT_NCOL; i += 512) s_acc[i] = s_acc[i] + 2.0f * s_k[i];
+            write_in(hh, s_k);
             dyn();
-            acc = acc + k;
-            z = z + h6 * acc;
+            for (int i = tid; i < 64 * LAT_NCOL; i += 512) {
+                const float a = s_acc[i] + s_k[i];
+                s_z[i] = s_z[i] + h6 * a;
+            }
             __syncthreads();
         }
-        if (tid < D) out[((long)b * Tu + ti) * D + tid] = z;
+        for (int i = tid; i < 64 * LAT_NCOL; i += 512) {
+            const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+            if (d < D && b0i + c < B) out[((long)(b0i + c) * Tu + ti) * D + d] = s_z[i];
+        }
     }
 }
 
 extern "C" int caspr_latent_rk4_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H,
-                                    int steps, const float *w0t, const float *b0, const float *w1t, const float *b1,
-                                    const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
+                                    int steps, const float *w0p, const float *b0, const float *w1p, const float *b1,
+                                    const float *w2p, const float *b2, const float *w3p, const float *b3, float *out,
                                     void *stream)
 {
-    CASPR_REQUIRE(z0 && times && out && w0t && w1t && w2t && w3t && b0 && b1 && b2 && b3, "latent_rk4: null pointer");
-    CASPR_REQUIRE(B > 0 && Tu > 0 && steps > 0 && D > 0 && D <= 64 && H > 0 && H <= 512 && ldz >= D,
-                  "latent_rk4: unsupported sizes D=%d H=%d (need D<=64, H<=512)", D, H);
-    latent_rk4_kernel<<<dim3(B), dim3(512), 0, (hipStream_t)stream>>>(z0, ldz, times, Tu, D, H, steps, w0t, b0, w1t, b1,
-                                                                      w2t, b2, w3t, b3, out);
+    CASPR_REQUIRE(z0 && times && out && w0p && w1p && w2p && w3p && b0 && b1 && b2 && b3, "latent_rk4: null pointer");
+    CASPR_REQUIRE(B > 0 && Tu > 0 && steps > 0 && D > 0 && D <= 64 && H > 0 && H <= 512 && H % 64 == 0 && ldz >= D,
+                  "latent_rk4: unsupported sizes D=%d H=%d (need D<=64, H<=512, H %% 64 == 0)", D, H);
+    latent_rk4_kernel<<<dim3(ceil_div(B, LAT_NCOL)), dim3(512), 0, (hipStream_t)stream>>>(z0, ldz, times, B, Tu, D, H, steps, w0p,
+                                                                                          b0, w1p, b1, w2p, b2, w3p, b3, out);
     CASPR_CHECK_LAUNCH("latent_rk4");
     return CASPR_OK;
 }

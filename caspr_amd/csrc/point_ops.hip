@@ -326,16 +326,16 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__
             b3 = d; i3 = k;
         }
     }
-    const float d1 = __fsqrt_rn(b1), d2 = __fsqrt_rn(b2), d3 = __fsqrt_rn(b3);
+    const float d1 = sqrtf(b1), d2 = sqrtf(b2), d3 = sqrtf(b3);  // correctly rounded (hipcc default)
     dist[row * 3 + 0] = d1; dist[row * 3 + 1] = d2; dist[row * 3 + 2] = d3;
     idx[row * 3 + 0] = i1; idx[row * 3 + 1] = i2; idx[row * 3 + 2] = i3;
     if (weight) {
-        const float v1 = __fdiv_rn(1.0f, d1 + 1e-8f), v2 = __fdiv_rn(1.0f, d2 + 1e-8f), v3 = __fdiv_rn(1.0f, d3 + 1e-8f);
+        const float v1 = 1.0f / (d1 + 1e-8f), v2 = 1.0f / (d2 + 1e-8f), v3 = 1.0f / (d3 + 1e-8f);
         const float t0 = v1 + v2;
         const float tot = t0 + v3;
-        weight[row * 3 + 0] = __fdiv_rn(v1, tot);
-        weight[row * 3 + 1] = __fdiv_rn(v2, tot);
-        weight[row * 3 + 2] = __fdiv_rn(v3, tot);
+        weight[row * 3 + 0] = v1 / tot;
+        weight[row * 3 + 1] = v2 / tot;
+        weight[row * 3 + 2] = v3 / tot;
     }
 }
 

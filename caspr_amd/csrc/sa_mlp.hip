@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *bufA = smem;
     float *bufB = bufA + a.rowsA * NCOL * 4;
-    float *s_mean = bufB + a.rowsB * NCOL * 4;  // [NSTAT]
-    float *s_rstd = s_mean + NSTAT;             // [NSTAT]
+    double *s_mean = reinterpret_cast<double *>(bufB + a.rowsB * NCOL * 4);  // [NSTAT] (f64: see the statistics pass)
+    float *s_rstd = reinterpret_cast<float *>(s_mean + NSTAT);              // [NSTAT]
     float *s_cen = s_rstd + NSTAT;              // [NCEN*4]
     int *s_idx = reinterpret_cast<int *>(s_cen + NCEN * 4);  // [NCOL]
 
@@ -130,31 +130,34 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
         }
         __syncthreads();
 
-        // ---- GroupNorm statistics per (centre, group): two-pass over cpg*NS elements in LDS
+        // ---- GroupNorm statistics per (centre, group): two-pass over cpg*NS elements in LDS, in f64.
+        // Most first-level neighbourhoods are padded with duplicates of one or two points; GroupNorm then
+        // divides near-zero deviations by sqrt(var + 1e-5) -> up to 316x amplification of any rounding in
+        // the mean.  f64 sums make mean/(x - mean) exact for such groups (the reference's f32 path is not).
         const int cpg = L.cout >> 4;
         {
             const int stat = tid / TPS, sub = tid % TPS;
             const int cen = stat >> 4, grp = stat & 15;
             const int cnt = cpg * NS;
-            float s = 0.f;
+            double s = 0.0;
             for (int e = sub; e < cnt; e += TPS) {
                 const int co = grp * cpg + e / NS, col = cen * NS + e % NS;
-                s += bout[btile_off(co >> 2, col, NCOL) + (co & 3)];
+                s += (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)];
             }
 #pragma unroll
             for (int off = TPS >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            const float mean = s / (float)cnt;
-            float v = 0.f;
+            const double mean = s / (double)cnt;
+            double v = 0.0;
             for (int e = sub; e < cnt; e += TPS) {
                 const int co = grp * cpg + e / NS, col = cen * NS + e % NS;
-                const float d = bout[btile_off(co >> 2, col, NCOL) + (co & 3)] - mean;
+                const double d = (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)] - mean;
                 v += d * d;
             }
 #pragma unroll
             for (int off = TPS >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off);
             if (sub == 0) {
                 s_mean[stat] = mean;
-                s_rstd[stat] = 1.0f / sqrtf(v / (float)cnt + 1e-5f);
+                s_rstd[stat] = (float)(1.0 / sqrt(v / (double)cnt + 1e-5));
             }
         }
         __syncthreads();
@@ -174,9 +177,8 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                     for (int q = 0; q < 4; ++q) {
                         const int co = kq * 4 + q;
                         const int st = cen * 16 + co / cpg;
-                        const float sc = s_rstd[st] * L.gamma[co];
-                        const float sf = L.beta[co] - s_mean[st] * sc;
-                        const float y = v[q] * sc + sf;
+                        // (x - mean) first: exact for the near-constant neighbourhoods where rstd -> 1/sqrt(eps)
+                        const float y = (float)((double)v[q] - s_mean[st]) * (s_rstd[st] * L.gamma[co]) + L.beta[co];
                         v[q] = y > 0.f ? y : 0.f;
                     }
                 }
@@ -192,11 +194,11 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                 const int co = it % L.cout, cen = it / L.cout;
                 if (m0 + cen >= a.M) continue;
                 const int st = cen * 16 + co / cpg;
-                const float sc = s_rstd[st] * L.gamma[co];
-                const float sf = L.beta[co] - s_mean[st] * sc;
+                const float sc = s_rstd[st] * L.gamma[co], be = L.beta[co];
+                const double mean = s_mean[st];
                 float mx = -INFINITY;
                 for (int s = 0; s < NS; ++s) {
-                    const float y = bout[btile_off(co >> 2, cen * NS + s, NCOL) + (co & 3)] * sc + sf;
+                    const float y = (float)((double)bout[btile_off(co >> 2, cen * NS + s, NCOL) + (co & 3)] - mean) * sc + be;
                     mx = y > mx ? y : mx;
                 }
                 a.out[((long)b * a.M + m0 + cen) * a.ldo + a.out_off + co] = mx;
@@ -250,7 +252,7 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
     if (a.rowsB < C1 / 4) a.rowsB = C1 / 4;
     const int bigK = (K0 > 160) || (C3 > 128);
     const int ncol = bigK ? 32 : 64;
-    const size_t shmem = (size_t)(a.rowsA + a.rowsB) * ncol * 16 + (2 * 64 + 16 + 64) * 4 + 64;
+    const size_t shmem = (size_t)(a.rowsA + a.rowsB) * ncol * 16 + (3 * 64 + 16 + 64) * 4 + 64;
     CASPR_REQUIRE(shmem <= 160 * 1024, "sa_mlp_max: needs %zu bytes of LDS (> 160 KiB)", shmem);
     hipStream_t st = (hipStream_t)stream;
     int rc;

@@ -37,7 +37,7 @@ class LatentODE(nn.Module):
         def build():
             out = []
             for l in lin:
-                out += [l.weight.detach().t().contiguous(), l.bias.detach().contiguous()]
+                out += [ops.PackedWeight(l.weight.detach().contiguous()), l.bias.detach().contiguous()]
             return out
         return self._cache.get("w", [l.weight for l in lin] + [l.bias for l in lin], build)
 

@@ -247,17 +247,18 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off):
 
 def latent_rk4(z0, times, steps, wts):
     """Fixed-step RK4 of the latent dynamics (latent_ode_model.py:45-70): z0 (B,D) (rows may be a column
-    slice of a wider tensor); wts = [w0t,b0,w1t,b1,w2t,b2,w3t,b3] with transposed weights.  -> (B,Tu,D)."""
-    _chk_f32(times, *wts)
+    slice of a wider tensor); wts = [PackedWeight0, b0, PackedWeight1, b1, PackedWeight2, b2, PackedWeight3, b3].  -> (B,Tu,D)."""
+    _chk_f32(times, *[w for w in wts[1::2]])
     if not z0.is_cuda or z0.dtype != torch.float32 or z0.dim() != 2 or z0.stride(1) != 1:
         raise ValueError("latent_rk4: z0 must be a float32 GPU (B,D) tensor with unit column stride")
     B = z0.shape[0]
-    D, H = wts[0].shape
+    D, H = wts[0].cin, wts[0].cout
     if z0.shape[1] != D:
         raise ValueError("latent_rk4: z0 has %d columns, the dynamics net expects %d" % (z0.shape[1], D))
     Tu = times.shape[0]
     out = torch.empty(B, Tu, D, device=z0.device, dtype=torch.float32)
-    _lib.check(_lib.load().caspr_latent_rk4_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *[_p(w) for w in wts], _p(out), _stream()),
+    ptrs = [_p(w.data) if isinstance(w, PackedWeight) else _p(w) for w in wts]
+    _lib.check(_lib.load().caspr_latent_rk4_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *ptrs, _p(out), _stream()),
                "caspr_latent_rk4_f32")
     return out
 

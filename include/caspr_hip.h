@@ -116,11 +116,12 @@ int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, int G, cons
                        void *ws, long ws_bytes, void *stream);
 
 /* ---------------- latent ODE: models/latent_ode_model.py:45-70,139-147 (fixed-step RK4) -----------
- * z0 (B,64) rows at stride ldz ; times (Tu) ascending (made relative to times[0] as :58) ;
- * w*t = TRANSPOSED Linear weights ([in][out]) ; out (B,Tu,D).  D<=64, H<=512.                       */
+ * z0 (B,D) rows at stride ldz ; times (Tu) ascending (made relative to times[0] as :58) ;
+ * w*p = the four Linear weights packed with caspr_pack_weight_f32 ; out (B,Tu,D).
+ * D <= 64, H <= 512, H % 64 == 0.  Up to 16 sequences share one workgroup (batch = MFMA columns). */
 int caspr_latent_rk4_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H,
-                         int steps, const float *w0t, const float *b0, const float *w1t, const float *b1,
-                         const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
+                         int steps, const float *w0p, const float *b0, const float *w1p, const float *b1,
+                         const float *w2p, const float *b2, const float *w3p, const float *b3, float *out,
                          void *stream);
 
 /* ---------------- point CNF: models/cnf.py:70-128 + odefunc.py:119-142 + diffeq_layers.py:83-90

@@ -91,6 +91,8 @@ def set_abstraction(sd, pre, xyz, feat, M, radii, intermediates=None):
 def feature_propagator(sd, pre, xyz, xyz_prev, feat, feat_prev):
     """models/pointnet2.py:483-525."""
     dist, idx = P.three_nn(xyz, xyz_prev)                                     # :514
+    if xyz.dtype == torch.float64:
+        dist = P.three_nn_f64(xyz, xyz_prev, idx)
     inverse_dist = 1.0 / (dist + 1e-8)                                        # :516
     total = torch.sum(inverse_dist, dim=2, keepdim=True)
     weights = inverse_dist / total                                            # :518

@@ -52,7 +52,13 @@ def furthest_point_sampling(xyz, M, guard=True):
     return idx
 
 
+def _bidx(idx):
+    return torch.arange(idx.shape[0]).view(-1, *([1] * (idx.dim() - 1))).expand_as(idx)
+
+
 def fps_gather_by_index(feat, idx):
+    if feat.dtype == torch.float64:   # f64 "truth" mode (conditioning studies): same indices, exact gather
+        return torch.gather(feat, 2, idx.long().unsqueeze(1).expand(-1, feat.shape[1], -1))
     feat = feat.detach().float().contiguous()
     idx = idx.contiguous()
     B, C, n = feat.shape
@@ -74,6 +80,14 @@ def ball_query(radius, ns, xyz, new_xyz):
 
 def group(xyz, new_xyz, feat, idx):
     """-> (B, M, 3+C, ns): centred xyz rows first, then feature rows."""
+    if xyz.dtype == torch.float64:
+        li = idx.long()
+        g = xyz[_bidx(li), li] - new_xyz.unsqueeze(2)                      # (B,M,ns,3)
+        g = g.permute(0, 1, 3, 2)
+        if feat is not None:
+            f = feat.transpose(1, 2)[_bidx(li), li].permute(0, 1, 3, 2)    # (B,M,C,ns)
+            g = torch.cat([g, f], dim=2)
+        return g.contiguous()
     xyz = xyz.detach().float().contiguous()
     new_xyz = new_xyz.detach().float().contiguous()
     B, n, _ = xyz.shape
@@ -96,7 +110,18 @@ def three_nn(unknown, known):
     return dist, idx
 
 
+def three_nn_f64(unknown, known, idx):
+    """Distances of the (f32-selected) neighbours recomputed in f64 (conditioning studies only)."""
+    li = idx.long()
+    d = unknown.unsqueeze(2) - known[_bidx(li), li]
+    return d.pow(2).sum(-1).sqrt()
+
+
 def three_interpolate(feat, idx, weight):
+    if feat.dtype == torch.float64:
+        li = idx.long()
+        f = feat.transpose(1, 2)[_bidx(li), li]                            # (B,n,3,C)
+        return (f * weight.unsqueeze(-1)).sum(dim=2).transpose(1, 2).contiguous()
     feat = feat.detach().float().contiguous()
     weight = weight.detach().float().contiguous()
     B, C, m = feat.shape
