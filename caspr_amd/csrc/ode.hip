@@ -2,15 +2,17 @@
 // (models/latent_ode_model.py:45-70,139-147) and of the point CNF's gated ODE function
 // (models/cnf.py:70-128, odefunc.py:98-142, diffeq_layers.py:83-90, normalization.py:59-108).
 //
-// cnf_rk4_kernel: ONE launch integrates the whole flow.  A 512-thread workgroup owns 64 columns of
-// one frame (64 points when sampling; 32 points + their 32 Hutchinson tangents when the divergence
-// is integrated).  The 512 x 64 hidden activation lives in LDS as an XOR-swizzled MFMA B-tile
-// (128 KiB); each of the 8 waves owns 64 hidden units x 64 columns (64 accumulator VGPRs) and
-// streams its slice of the packed 512x512 weights straight from L2 into A fragments (prefetched
-// one 16-k chunk ahead).  ConcatSquash gate/bias, softplus, the 3->512 input layer and the
+// cnf_rk4_kernel: ONE launch integrates the whole flow.  A 256-thread workgroup (one wave per SIMD) owns
+// 64 columns of one frame (64 points when sampling; 32 points + their 32 Hutchinson tangents when the
+// divergence is integrated).  The 512 x 64 hidden activation lives in LDS as an XOR-swizzled MFMA B-tile
+// (128 KiB); each of the 4 waves owns 128 hidden units x 64 columns (128 accumulator VGPRs) and streams
+// its slice of the packed 512x512 weights straight from L2 into A fragments (two register sets, prefetched
+// one 16-k chunk ahead, pinned with sched_barrier because hipcc sinks loads to their first use).  ConcatSquash gate/bias, softplus, the 3->512 input layer and the
 // 512->3 output layer (fused into the last hidden layer's epilogue as a register-level partial dot
 // product) never leave the CU.  The divergence uses the forward-mode identity
 // e^T (df/dy)^T e == e^T (df/dy) e: tangents ride along as 32 extra columns of the same GEMMs.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define CNF_H 512
@@ -30,19 +32,34 @@
 template <int NRT, typename Epi>
 __device__ __forceinline__ void lat_layer(const float *__restrict__ wp, int KC, int rt0, const float *in, int lane, Epi epi)
 {
+    // One CU streams the whole weight set from L2 every evaluation: keep 4 chunks (4 x NRT KiB per wave,
+    // 128 KiB per workgroup) of A fragments in flight in a register ring to cover the L2 latency.
     const int g = lane >> 4, j = lane & 15;
     f32x4 acc[NRT];
 #pragma unroll
     for (int i = 0; i < NRT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float *wb = wp + ((long)rt0 * KC) * 256 + lane * 4;
-#pragma unroll 4
-    for (int kc = 0; kc < KC; ++kc) {
-        const f32x4 bf = ld4(in + btile_off(kc * 4 + g, j, LAT_NCOL));
+    f32x4 ring[4][NRT];
 #pragma unroll
-        for (int i = 0; i < NRT; ++i) {
-            const f32x4 af = ld4(wb + ((long)i * KC + kc) * 256);
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[i] = mfma16(af[q], bf[q], acc[i]);
+        for (int i = 0; i < NRT; ++i) ring[s][i] = ld4(wb + ((long)i * KC + (s < KC ? s : 0)) * 256);
+    for (int kc0 = 0; kc0 < KC; kc0 += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kc = kc0 + s;
+            if (kc < KC) {
+                const f32x4 bf = ld4(in + btile_off(kc * 4 + g, j, LAT_NCOL));
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) {
+                    const f32x4 af = ring[s][i];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i] = mfma16(af[q], bf[q], acc[i]);
+                }
+                const int kn = (kc + 4 < KC) ? kc + 4 : kc;
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) ring[s][i] = ld4(wb + ((long)i * KC + kn) * 256);
+            }
         }
     }
 #pragma unroll
@@ -177,75 +194,100 @@ struct CnfArgs {
     float t_end;
 };
 
-// one hidden layer: acc[mi][ct] = sum_k W[64*wave + 16*mi + row][k] * Hbuf[k][16*ct + col]
+// Geometry (measured, profiles/r01_*): a 256-thread workgroup = 4 waves = ONE wave per SIMD owns CNF_NCOL = 64
+// columns of one frame and the whole CU (141 KB of LDS, ~300 VGPRs).  Two waves per SIMD -- whether one 8-wave
+// workgroup (67 % of the f32 MFMA peak) or two independent 4-wave workgroups (71 %) -- lost to one wave per
+// SIMD (80 % at 32 columns): co-resident waves only take matrix-pipe slots from each other, while a single
+// wave with 32 independent accumulators already saturates the pipe.  64 columns per wave then halve the
+// per-column cost of gates, barriers and weight streaming (128 MFMAs per 8 weight + 4 activation fragment loads).
+#define CNF_WAVES 4
+#define CNF_NT (CNF_WAVES * 64)
+#define CNF_MI 8   // 16-row tiles per wave: 128 hidden units
+#define CNF_CT 4   // 16-column tiles: 64 columns
+
+// one hidden layer: acc[mi][ct] = sum_k W[128*wave + 16*mi + row][k] * Hbuf[k][16*ct + col]
+// Software pipeline, two register sets: while the 64 MFMAs of chunk kc run on (a0,b0), the A fragments
+// (L2 -> VGPR) and B fragments (LDS -> VGPR) of chunk kc+1 are already in flight into (a1,b1), and vice versa.
 __device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, const float *Hbuf, int wave, int lane,
-                                               f32x4 (&acc)[4][4])
+                                               f32x4 (&acc)[CNF_MI][CNF_CT])
 {
     const int g = lane >> 4, j = lane & 15;
-    const float *wb = wp + ((long)(wave * 4) * CNF_KC) * 256 + lane * 4;
+    const float *wb = wp + ((long)(wave * CNF_MI) * CNF_KC) * 256 + lane * 4;
+    // B-tile read offsets: kq = 4*kc + g  ->  (kq & 15) = (4*kc + g) & 15 alternates with kc & 3
+    int boff[4][CNF_CT];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[mi][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 a_cur[4], a_nxt[4];
+        for (int ct = 0; ct < CNF_CT; ++ct) boff[r][ct] = btile_off(r * 4 + g, ct * 16 + j, CNF_NCOL);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) a_cur[mi] = ld4(wb + (long)mi * CNF_KC * 256);
+    for (int mi = 0; mi < CNF_MI; ++mi)
+#pragma unroll
+        for (int ct = 0; ct < CNF_CT; ++ct) acc[mi][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a0[CNF_MI], a1[CNF_MI], b0[CNF_CT], b1[CNF_CT];
+#pragma unroll
+    for (int mi = 0; mi < CNF_MI; ++mi) a0[mi] = ld4(wb + (long)mi * CNF_KC * 256);
+#pragma unroll
+    for (int ct = 0; ct < CNF_CT; ++ct) b0[ct] = ld4(Hbuf + boff[0][ct]);
 #pragma unroll 1
-    for (int kc = 0; kc < CNF_KC; ++kc) {
-        const int kn = (kc + 1 < CNF_KC) ? kc + 1 : kc;
+    for (int kc = 0; kc < CNF_KC; kc += 4) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a_nxt[mi] = ld4(wb + ((long)mi * CNF_KC + kn) * 256);
-        f32x4 bf[4];
+        for (int u = 0; u < 4; u += 2) {
+            const int k0 = kc + u;
+            // prefetch chunk k0+1 into set 1
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) bf[ct] = ld4(Hbuf + btile_off(kc * 4 + g, ct * 16 + j, CNF_NCOL));
+            for (int mi = 0; mi < CNF_MI; ++mi) a1[mi] = ld4(wb + ((long)mi * CNF_KC + k0 + 1) * 256);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int ct = 0; ct < CNF_CT; ++ct) b1[ct] = ld4(Hbuf + (k0 + 1 - (u + 1)) * 4 * CNF_NCOL * 4 + boff[u + 1][ct]);
+            __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks these loads to just before their use (no prefetch)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[mi][ct] = mfma16(a_cur[mi][q], bf[ct][q], acc[mi][ct]);
+                for (int mi = 0; mi < CNF_MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a_cur[mi] = a_nxt[mi];
+                    for (int ct = 0; ct < CNF_CT; ++ct) acc[mi][ct] = mfma16(a0[mi][q], b0[ct][q], acc[mi][ct]);
+            // prefetch chunk k0+2 into set 0 (clamped on the last pair)
+            const int kn = (k0 + 2 < CNF_KC) ? k0 + 2 : k0;
+            const int un = (u + 2) & 3;
+#pragma unroll
+            for (int mi = 0; mi < CNF_MI; ++mi) a0[mi] = ld4(wb + ((long)mi * CNF_KC + kn) * 256);
+#pragma unroll
+            for (int ct = 0; ct < CNF_CT; ++ct) b0[ct] = ld4(Hbuf + (kn - un) * 4 * CNF_NCOL * 4 + boff[un][ct]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < CNF_MI; ++mi)
+#pragma unroll
+                    for (int ct = 0; ct < CNF_CT; ++ct) acc[mi][ct] = mfma16(a1[mi][q], b1[ct][q], acc[mi][ct]);
+        }
     }
 }
 
 template <bool WITH_DIV>
-__global__ __launch_bounds__(512) void cnf_rk4_kernel(CnfArgs a)
+__global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
 {
-    constexpr int PT = WITH_DIV ? 32 : 64;  // points per workgroup (the other 32 columns are tangents)
+    constexpr int PT = WITH_DIV ? CNF_NCOL / 2 : CNF_NCOL;  // points per workgroup (the other half are tangents)
+    constexpr int NSTATE = 3 * CNF_NCOL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Hbuf = smem;                           // [128 kq][64 col][4]        128 KiB
-    float *s_gate = Hbuf + (CNF_H / 4) * CNF_NCOL * 4;  // [3][512] sigmoid gate per hidden layer
-    float *s_hb = s_gate + 3 * CNF_H;             // [3][512] layer bias*gate + hyper bias
-    float *s_w3 = s_hb + 3 * CNF_H;               // [3][512] output layer weights
-    float *s_red = s_w3 + 3 * CNF_H;              // [8][3][64] per-wave partial outputs
-    float *s_ys = s_red + 8 * 3 * CNF_NCOL;       // [64][4] stage input (value cols) / e (tangent cols)
-    float *s_out = s_ys + CNF_NCOL * 4;           // [3][64] stage output dy / J e
-    float *s_g3 = s_out + 3 * CNF_NCOL;           // [8]: gate3[3], hb3[3]
+    float *Hbuf = smem;                                   // [128 kq][32 col][4]   64 KiB
+    float *s_gate = Hbuf + (CNF_H / 4) * CNF_NCOL * 4;    // [2][512] sigmoid gate of hidden layers 1,2
+    float *s_hb = s_gate + 2 * CNF_H;                     // [2][512] layer bias*gate + hyper bias
+    float *s_red = s_hb + 2 * CNF_H;                      // [4][3][32] per-wave partial outputs
+    float *s_ys = s_red + CNF_WAVES * 3 * CNF_NCOL;       // [32][4] stage input (value cols) / e (tangent cols)
+    float *s_out = s_ys + CNF_NCOL * 4;                   // [3][32] stage output dy / J e
+    float *s_g3 = s_out + 3 * CNF_NCOL;                   // [8]: gate3[3], hb3[3]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, j = lane & 15;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // wave-uniform (SGPR)
     const int bt = blockIdx.y;
     const int p0 = blockIdx.x * PT;
     const float *hy = a.hyper + (long)bt * a.ldh;
     constexpr int GOFF = 0, BOFF = 3 * CNF_H + 3;  // column offsets of the gate / bias blocks
+    int tid = tid0;
 
-    // ---- per-thread constants: input layer rows 4*kq0 .. +3 (kq0 = tid & 127), column group tid >> 7
-    const int kq0 = tid & 127, cg0 = tid >> 7;
-    float w0r[4][3], b0r[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int co = kq0 * 4 + q;
-        w0r[q][0] = a.w0[co * 3 + 0];
-        w0r[q][1] = a.w0[co * 3 + 1];
-        w0r[q][2] = a.w0[co * 3 + 2];
-        b0r[q] = a.b0[co];
-    }
-    for (int i = tid; i < 3 * CNF_H; i += 512) s_w3[i] = a.w3[i];
-
-    // ---- state: thread (d = tid / 64, col = tid % 64), tid < 192
-    const int sd = tid >> 6, scol = tid & 63;
-    const bool is_state = tid < 192 && scol < PT;
+    // ---- state: thread (d = tid / 32, col = tid % 32), tid < 96
+    const int sd = tid0 / CNF_NCOL, scol = tid0 % CNF_NCOL;
+    const bool is_state = tid0 < NSTATE && scol < PT;
     const int spt = p0 + scol;
     const bool pvalid = is_state && spt < a.n;
     float y = 0.f, kacc = 0.f, ev = 0.f;
@@ -282,15 +324,22 @@ __global__ __launch_bounds__(512) void cnf_rk4_kernel(CnfArgs a)
     for (int step = 0; step < a.steps; ++step) {
 #pragma unroll 1
         for (int stage = 0; stage < 4; ++stage) {
+            // Opaque copy of the thread id: everything derived from it below (LDS / global addresses, XOR swizzles,
+            // input-layer weights) is recomputed per stage instead of being hoisted out of the 32-stage loop, where
+            // ~150 loop-invariant VGPRs were spilled and reloaded with exposed scratch latency in every epilogue.
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, g = lane >> 4, j = lane & 15;
+            const int kq0 = tid & 127, cg0 = tid >> 7;   // input layer: rows 4*kq0 .. +3, column group
             const double tc = (stage == 0) ? 0.0 : (stage == 3 ? 1.0 : 0.5);
             const float t = (float)(t0 + (double)step * h + tc * h);
             const float aw = (stage == 0) ? 0.f : (stage == 3 ? hh : h2);
             // ---- stage input + gates
             if (is_state) s_ys[scol * 4 + sd] = (stage == 0) ? y : y + aw * kprev;
-            for (int i = tid; i < 3 * CNF_H; i += 512) {
-                const float gt = sigmoid_fast(hy[GOFF + i] + t * a.tcol[GOFF + i]);
-                const float hb = hy[BOFF + i] + t * a.tcol[BOFF + i];
-                const float bl = (i < CNF_H) ? a.b0[i] : (i < 2 * CNF_H ? a.b1[i - CNF_H] : a.b2[i - 2 * CNF_H]);
+            for (int i = tid; i < 2 * CNF_H; i += CNF_NT) {   // hidden layers 1,2 (layer 0's gates live in registers)
+                const int c = CNF_H + i;
+                const float gt = sigmoid_fast(hy[GOFF + c] + t * a.tcol[GOFF + c]);
+                const float hb = hy[BOFF + c] + t * a.tcol[BOFF + c];
+                const float bl = (i < CNF_H) ? a.b1[i] : a.b2[i - CNF_H];
                 s_gate[i] = gt;
                 s_hb[i] = bl * gt + hb;
             }
@@ -303,15 +352,19 @@ __global__ __launch_bounds__(512) void cnf_rk4_kernel(CnfArgs a)
             __syncthreads();
             // ---- input layer 3 -> 512 straight into the B-tile (diffeq_layers.py:83-90 + softplus)
             {
-                float gt[4], hb[4];
+                float gt[4], hb[4], w0r[4][3];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    gt[q] = s_gate[kq0 * 4 + q];
-                    hb[q] = s_hb[kq0 * 4 + q];
+                    const int c = kq0 * 4 + q;
+                    w0r[q][0] = a.w0[c * 3 + 0];
+                    w0r[q][1] = a.w0[c * 3 + 1];
+                    w0r[q][2] = a.w0[c * 3 + 2];
+                    gt[q] = sigmoid_fast(hy[GOFF + c] + t * a.tcol[GOFF + c]);
+                    hb[q] = a.b0[c] * gt[q] + (hy[BOFF + c] + t * a.tcol[BOFF + c]);
                 }
 #pragma unroll 4
-                for (int c = 0; c < 16; ++c) {
-                    const int col = cg0 * 16 + c;
+                for (int c = 0; c < CNF_NCOL / 2; ++c) {
+                    const int col = cg0 * (CNF_NCOL / 2) + c;
                     const f32x4 in = ld4(s_ys + col * 4);
                     f32x4 v;
                     if (!WITH_DIV || col < PT) {
@@ -334,43 +387,44 @@ __global__ __launch_bounds__(512) void cnf_rk4_kernel(CnfArgs a)
             }
             __syncthreads();
 
-            f32x4 acc[4][4];
+            f32x4 acc[CNF_MI][CNF_CT];
             // ---- hidden layer 1
             cnf_mfma_layer(a.w1p, Hbuf, wave, lane, acc);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int co = (wave * 4 + mi) * 16 + 4 * g;
-                const f32x4 gt = ld4(s_gate + CNF_H + co), hb = ld4(s_hb + CNF_H + co);
+            for (int mi = 0; mi < CNF_MI; ++mi) {
+                const int co = (wave * CNF_MI + mi) * 16 + 4 * g;
+                const f32x4 gt = ld4(s_gate + co), hb = ld4(s_hb + co);
 #pragma unroll
-                for (int ct = 0; ct < (WITH_DIV ? 2 : 4); ++ct)
+                for (int ct = 0; ct < (WITH_DIV ? CNF_CT / 2 : CNF_CT); ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pre = acc[mi][ct][r] * gt[r] + hb[r];
                         acc[mi][ct][r] = softplus_fast(pre);
-                        if (WITH_DIV) acc[mi][ct + 2][r] = acc[mi][ct + 2][r] * gt[r] * sigmoid_fast(pre);
+                        if (WITH_DIV) acc[mi][ct + CNF_CT / 2][r] = acc[mi][ct + CNF_CT / 2][r] * gt[r] * sigmoid_fast(pre);
                     }
+                __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 8 tiles' gate loads (VGPR blow-up)
             }
             __syncthreads();  // every wave has finished reading Hbuf
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < CNF_MI; ++mi)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    st4(Hbuf + btile_off((wave * 4 + mi) * 4 + g, ct * 16 + j, CNF_NCOL), acc[mi][ct]);
+                for (int ct = 0; ct < CNF_CT; ++ct)
+                    st4(Hbuf + btile_off((wave * CNF_MI + mi) * 4 + g, ct * 16 + j, CNF_NCOL), acc[mi][ct]);
             __syncthreads();
             // ---- hidden layer 2 + fused output layer 512 -> 3
             cnf_mfma_layer(a.w2p, Hbuf, wave, lane, acc);
-            float part[3][4];
+            float part[3][CNF_CT];
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) part[d][ct] = 0.f;
+                for (int ct = 0; ct < CNF_CT; ++ct) part[d][ct] = 0.f;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int co = (wave * 4 + mi) * 16 + 4 * g;
-                const f32x4 gt = ld4(s_gate + 2 * CNF_H + co), hb = ld4(s_hb + 2 * CNF_H + co);
-                const f32x4 wx = ld4(s_w3 + co), wy = ld4(s_w3 + CNF_H + co), wz = ld4(s_w3 + 2 * CNF_H + co);
+            for (int mi = 0; mi < CNF_MI; ++mi) {
+                const int co = (wave * CNF_MI + mi) * 16 + 4 * g;
+                const f32x4 gt = ld4(s_gate + CNF_H + co), hb = ld4(s_hb + CNF_H + co);
+                const f32x4 wx = ld4(a.w3 + co), wy = ld4(a.w3 + CNF_H + co), wz = ld4(a.w3 + 2 * CNF_H + co);
 #pragma unroll
-                for (int ct = 0; ct < (WITH_DIV ? 2 : 4); ++ct)
+                for (int ct = 0; ct < (WITH_DIV ? CNF_CT / 2 : CNF_CT); ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pre = acc[mi][ct][r] * gt[r] + hb[r];
@@ -379,28 +433,29 @@ __global__ __launch_bounds__(512) void cnf_rk4_kernel(CnfArgs a)
                         part[1][ct] += wy[r] * hv;
                         part[2][ct] += wz[r] * hv;
                         if (WITH_DIV) {
-                            const float tv = acc[mi][ct + 2][r] * gt[r] * sigmoid_fast(pre);
-                            part[0][ct + 2] += wx[r] * tv;
-                            part[1][ct + 2] += wy[r] * tv;
-                            part[2][ct + 2] += wz[r] * tv;
+                            const float tv = acc[mi][ct + CNF_CT / 2][r] * gt[r] * sigmoid_fast(pre);
+                            part[0][ct + CNF_CT / 2] += wx[r] * tv;
+                            part[1][ct + CNF_CT / 2] += wy[r] * tv;
+                            part[2][ct + CNF_CT / 2] += wz[r] * tv;
                         }
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
+                for (int ct = 0; ct < CNF_CT; ++ct) {
                     float v = part[d][ct];
                     v += __shfl_xor(v, 16);
                     v += __shfl_xor(v, 32);
                     if (g == 0) s_red[(wave * 3 + d) * CNF_NCOL + ct * 16 + j] = v;
                 }
             __syncthreads();
-            // ---- combine the 8 wave partials, apply the output ConcatSquash (no softplus: odefunc.py:103)
-            if (tid < 192) {
+            // ---- combine the wave partials, apply the output ConcatSquash (no softplus: odefunc.py:103)
+            if (tid < NSTATE) {
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) s += s_red[(w * 3 + sd) * CNF_NCOL + scol];
+                for (int w = 0; w < CNF_WAVES; ++w) s += s_red[(w * 3 + sd) * CNF_NCOL + scol];
                 float o;
                 if (!WITH_DIV || scol < PT) o = s * s_g3[sd] + s_g3[4 + sd];
                 else o = s * s_g3[sd];
@@ -462,17 +517,18 @@ extern "C" int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh,
     a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.w1p = w1p; a.b1 = b1; a.w2p = w2p; a.b2 = b2;
     a.w3 = w3; a.b3 = b3; a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.e = e; a.logp_in = logp_in; a.logp_out = logp_out;
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
-    const size_t shmem = ((size_t)(CNF_H / 4) * CNF_NCOL * 4 + 9 * CNF_H + 8 * 3 * CNF_NCOL + CNF_NCOL * 4 + 3 * CNF_NCOL + 8) * 4;
+    size_t shmem = ((size_t)(CNF_H / 4) * CNF_NCOL * 4 + 4 * CNF_H + CNF_WAVES * 3 * CNF_NCOL + CNF_NCOL * 4 + 3 * CNF_NCOL + 8) * 4;
+    if (const char *pad = getenv("CASPR_CNF_LDS_PAD")) shmem += (size_t)atoi(pad) * 1024;  // occupancy experiments only
     hipStream_t st = (hipStream_t)stream;
     hipError_t err;
     if (e) {
         auto kern = cnf_rk4_kernel<true>;
         err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (err == hipSuccess) kern<<<dim3(ceil_div(n, 32), BT), dim3(512), shmem, st>>>(a);
+        if (err == hipSuccess) kern<<<dim3(ceil_div(n, CNF_NCOL / 2), BT), dim3(CNF_NT), shmem, st>>>(a);
     } else {
         auto kern = cnf_rk4_kernel<false>;
         err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (err == hipSuccess) kern<<<dim3(ceil_div(n, 64), BT), dim3(512), shmem, st>>>(a);
+        if (err == hipSuccess) kern<<<dim3(ceil_div(n, CNF_NCOL), BT), dim3(CNF_NT), shmem, st>>>(a);
     }
     if (err != hipSuccess) {
         caspr_set_error("cnf_rk4: hipFuncSetAttribute(%zu) failed: %s", shmem, hipGetErrorString(err));
