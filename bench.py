@@ -8,7 +8,7 @@
 One "step" = one reconstruct() pass over one batch of synthetic sequences already resident in HBM.
 Workload (BASELINE.json configs[1]): cars.cfg rigid reconstruction, B=16 sequences per GPU, T=10, N=2048,
 num_points=2048, all steps observed (evaluations.py:111-114), f32, fixed-step RK4 (8 CNF steps = 32
-function evaluations, 4 latent steps per interval).  Weak scaling: every rank owns its own 16 sequences
+function evaluations, 2 latent RK4 steps per interval).  Weak scaling: every rank owns its own 16 sequences
 (sequences are independent) -- no data-path collective; value = all ranks' sequences / max time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=10)
     ap.add_argument("--num-pts", type=int, default=2048)
     ap.add_argument("--cnf-steps", type=int, default=8)
-    ap.add_argument("--latent-steps", type=int, default=4)
+    ap.add_argument("--latent-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -22,7 +22,7 @@ from .utils import standard_normal_logprob, sample_gaussian, sphere_surface_poin
 class CaSPR(nn.Module):
     def __init__(self, radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], local_feat_size=512, latent_feat_size=1600,
                  ode_hidden_size=512, motion_feat_size=64, pretrain_tnocs=False, augment_quad=True, augment_pairs=True,
-                 cnf_blocks=1, regress_tnocs=True, *, cnf_rk4_steps=8, latent_rk4_steps=4):
+                 cnf_blocks=1, regress_tnocs=True, *, cnf_rk4_steps=8, latent_rk4_steps=2):
         super(CaSPR, self).__init__()
         self.pretrain_tnocs = pretrain_tnocs
         self.augment_quad = augment_quad

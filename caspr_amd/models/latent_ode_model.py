@@ -13,7 +13,7 @@ from ..utils.weight_cache import WeightCache
 
 
 class LatentODE(nn.Module):
-    def __init__(self, input_size=1024, hidden_size=1024, num_layers=2, nonlinearity=nn.Tanh, augment_size=0, rk4_steps=4):
+    def __init__(self, input_size=1024, hidden_size=1024, num_layers=2, nonlinearity=nn.Tanh, augment_size=0, rk4_steps=2):
         super(LatentODE, self).__init__()
         if nonlinearity is not nn.Tanh or num_layers != 2:
             raise ValueError("the latent RK4 kernel implements the reference configuration: 2 hidden layers, Tanh (caspr.py:61-64)")

@@ -77,7 +77,7 @@ def ops():
 @pytest.fixture(scope="module")
 def model(dev, seeded_sd):
     from caspr_amd.models import CaSPR
-    m = CaSPR()
+    m = CaSPR(cnf_rk4_steps=8, latent_rk4_steps=4)   # the step counts the golden fixtures were generated with
     m.load_state_dict(seeded_sd)
     return m.to(dev).eval()
 
