@@ -3,7 +3,7 @@
 // models/pointnet.py:37-41, models/pointnet2.py:525,247 and models/tpointnet2.py:99-105.
 //
 // conv1x1: Y[b,p,co] = act(sum_k W[co,k] * in(X[b,p,k]) + bias[co] + bbias[b,co]).
-//   Block tile 128 (co) x 128 (points), K tile 32, 256 threads = 2x2 waves of 64x64 (4x4 MFMA
+//   Block tile 128 (co) x 128 (points), K tile 32, 256 threads = 4x1 waves of 32x128 (2x8 MFMA
 //   16x16x4 tiles, 64 accumulator VGPRs).  The point operand is staged through a double-buffered,
 //   XOR-swizzled LDS B-tile (register staging, so the previous layer's GroupNorm+ReLU is applied
 //   on the fly: one pass over the activations instead of three).  Weights are read straight from
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
 {
     __shared__ __attribute__((aligned(16))) float sB[2][8 * GEMM_NT * 4];  // 2 x 16 KiB (K tile 32 = 2 chunks; K tile 64 measured slower: fewer blocks per CU)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    // 4 x 1 wave layout: each wave owns 32 output channels x all 128 points.  The weight fragments (streamed from
+    // L2, the scarce per-CU resource at ~10-12 B/clk) are then fetched exactly once per block; the activation
+    // fragments are re-read by all four waves, but from LDS.  (2 x 2 waves fetched every weight fragment twice.)
+    const int wm = wave;
     const int g = lane >> 4, j = lane & 15;
     const int b = blockIdx.z;
     const int p0 = blockIdx.y * GEMM_NT;
@@ -77,20 +80,20 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     const float *sh = in_scale ? in_shift + (long)b * Cin : nullptr;
 
     // which 16-row tiles of the packed stream this wave owns (wave-uniform validity)
-    const int mt0 = (co0 >> 4) + wm * 4;
-    const float *wbase[4];
-    bool mvalid[4];
+    const int mt0 = (co0 >> 4) + wm * 2;
+    const float *wbase[2];
+    bool mvalid[2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < 2; ++mi) {
         mvalid[mi] = (mt0 + mi) < MT16;
         wbase[mi] = wp + ((long)(mvalid[mi] ? mt0 + mi : 0) * KC) * 256 + lane * 4;
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[2][8];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // staging assignment: float4 f = tid + 256*i  ->  kq = f & 7, col = f >> 3
     f32x4 stage[4];
@@ -135,23 +138,23 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         }
     };
 
-    f32x4 a0[4], a1[4], b0[4], b1[4];
-    auto load_a = [&](f32x4(&a)[4], int kc) {
+    f32x4 a0[2], a1[2], b0[8], b1[8];
+    auto load_a = [&](f32x4(&a)[2], int kc) {
         const int kk = kc < KC ? kc : KC - 1;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a[mi] = ld4(wbase[mi] + (long)kk * 256);
+        for (int mi = 0; mi < 2; ++mi) a[mi] = ld4(wbase[mi] + (long)kk * 256);
     };
-    auto load_b = [&](f32x4(&bf)[4], int buf, int c) {
+    auto load_b = [&](f32x4(&bf)[8], int buf, int c) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bf[ni] = ld4(&sB[buf][btile_off(c * 4 + g, wn * 64 + ni * 16 + j, GEMM_NT)]);
+        for (int ni = 0; ni < 8; ++ni) bf[ni] = ld4(&sB[buf][btile_off(c * 4 + g, ni * 16 + j, GEMM_NT)]);
     };
-    auto mma = [&](const f32x4(&a)[4], const f32x4(&bf)[4]) {
+    auto mma = [&](const f32x4(&a)[2], const f32x4(&bf)[8]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(a[mi][q], bf[ni][q], acc[mi][ni]);
+                for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = mfma16(a[mi][q], bf[ni][q], acc[mi][ni]);
     };
 
     load_stage(0);
@@ -180,12 +183,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         }
     }
 
-    // epilogue: lane holds co = co0 + wm*64 + mi*16 + 4g + r (r = 0..3) for point p0 + wn*64 + ni*16 + j
+    // epilogue: lane holds co = co0 + wm*32 + mi*16 + 4g + r (r = 0..3) for point p0 + ni*16 + j
     const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < 2; ++mi) {
         if (!mvalid[mi]) continue;
-        const int co = co0 + wm * 64 + mi * 16 + 4 * g;
+        const int co = co0 + wm * 32 + mi * 16 + 4 * g;
         float add[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
             add[r] = v;
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int p = p0 + wn * 64 + ni * 16 + j;
+        for (int ni = 0; ni < 8; ++ni) {
+            const int p = p0 + ni * 16 + j;
             if (p >= P) continue;
             f32x4 v = acc[mi][ni];
 #pragma unroll

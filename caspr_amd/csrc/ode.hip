@@ -2,12 +2,13 @@
 // (models/latent_ode_model.py:45-70,139-147) and of the point CNF's gated ODE function
 // (models/cnf.py:70-128, odefunc.py:98-142, diffeq_layers.py:83-90, normalization.py:59-108).
 //
-// cnf_rk4_kernel: ONE launch integrates the whole flow.  A 256-thread workgroup (one wave per SIMD) owns
-// 64 columns of one frame (64 points when sampling; 32 points + their 32 Hutchinson tangents when the
-// divergence is integrated).  The 512 x 64 hidden activation lives in LDS as an XOR-swizzled MFMA B-tile
-// (128 KiB); each of the 4 waves owns 128 hidden units x 64 columns (128 accumulator VGPRs) and streams
-// its slice of the packed 512x512 weights straight from L2 into A fragments (two register sets, prefetched
-// one 16-k chunk ahead, pinned with sched_barrier because hipcc sinks loads to their first use).  ConcatSquash gate/bias, softplus, the 3->512 input layer and the
+// cnf_rk4_kernel: ONE launch integrates the whole flow.  A 256-thread workgroup owns 32 columns of one
+// frame (32 points when sampling; 16 points + their 16 Hutchinson tangents when the divergence is
+// integrated); two workgroups share a CU.  The 512 x 32 hidden activation lives in LDS as an XOR-swizzled
+// MFMA B-tile (64 KiB); each of the 4 waves owns 128 hidden units x 32 columns (64 accumulator VGPRs) and
+// streams its slice of the packed 512x512 weights straight from L2 into A fragments with buffer loads (two
+// register sets, prefetched one 16-k chunk ahead, pinned with sched_barrier because hipcc sinks loads to
+// their first use).  ConcatSquash gate/bias, softplus, the 3->512 input layer and the
 // 512->3 output layer (fused into the last hidden layer's epilogue as a register-level partial dot
 // product) never leave the CU.  The divergence uses the forward-mode identity
 // e^T (df/dy)^T e == e^T (df/dy) e: tangents ride along as 32 extra columns of the same GEMMs.
@@ -16,7 +17,7 @@
 #include "common.h"
 
 #define CNF_H 512
-#define CNF_NCOL 64
+#define CNF_NCOL 32
 #define CNF_KC (CNF_H / 16)  // 32 chunks of 16 k
 
 // ---------------------------------------------------------------------------------------------
@@ -192,27 +193,44 @@ struct CnfArgs {
     float *logp_out, *y_out;
     int ldh, n, steps, reverse;
     float t_end;
+    unsigned long long *trace;   // debug: per-phase s_memtime stamps of workgroup (0,0), wave 0 (NULL in production)
 };
 
-// Geometry (measured, profiles/r01_*): a 256-thread workgroup = 4 waves = ONE wave per SIMD owns CNF_NCOL = 64
-// columns of one frame and the whole CU (141 KB of LDS, ~300 VGPRs).  Two waves per SIMD -- whether one 8-wave
-// workgroup (67 % of the f32 MFMA peak) or two independent 4-wave workgroups (71 %) -- lost to one wave per
-// SIMD (80 % at 32 columns): co-resident waves only take matrix-pipe slots from each other, while a single
-// wave with 32 independent accumulators already saturates the pipe.  64 columns per wave then halve the
-// per-column cost of gates, barriers and weight streaming (128 MFMAs per 8 weight + 4 activation fragment loads).
+// Geometry (every step measured on MI355X, profiles/r01_*): a 256-thread workgroup = 4 waves owns CNF_NCOL = 32
+// columns of one frame and 76 KB of LDS, so TWO workgroups share a CU and run unsynchronised: while one is in a
+// VALU epilogue (gate * acc + bias, softplus, output-layer dot: ~10 % of a stage) the other keeps the matrix pipe busy.
+//   8 waves x 64 columns, one workgroup per CU (both waves of a SIMD barrier-locked)          105 ms  0.67 of peak
+//   4 waves x 64 columns, one workgroup per CU (one wave per SIMD, epilogues exposed)           86 ms  0.82
+//   4 waves x 32 columns, two workgroups per CU, 64-bit VALU address arithmetic per load        98 ms  0.71
+//   4 waves x 32 columns, two workgroups per CU, buffer loads + per-tile k rotation (this)      81 ms  0.87
+// Co-resident MFMA streams only pay off once the loop carries no VALU address arithmetic (buffer loads with
+// SGPR offsets) and no register spills (the opaque thread id below); s_setprio around the MFMA loops: -1 %.
 #define CNF_WAVES 4
 #define CNF_NT (CNF_WAVES * 64)
 #define CNF_MI 8   // 16-row tiles per wave: 128 hidden units
-#define CNF_CT 4   // 16-column tiles: 64 columns
+#define CNF_CT 2   // 16-column tiles: 32 columns
 
 // one hidden layer: acc[mi][ct] = sum_k W[128*wave + 16*mi + row][k] * Hbuf[k][16*ct + col]
-// Software pipeline, two register sets: while the 64 MFMAs of chunk kc run on (a0,b0), the A fragments
+// Software pipeline, two register sets: while the 128 MFMAs of chunk kc run on (a0,b0), the A fragments
 // (L2 -> VGPR) and B fragments (LDS -> VGPR) of chunk kc+1 are already in flight into (a1,b1), and vice versa.
-__device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, const float *Hbuf, int wave, int lane,
+//  * A fragments come through buffer loads (SGPR resource + SGPR chunk offset + one lane-offset VGPR): no
+//    per-load 64-bit VALU address arithmetic in the MFMA shadow.
+//  * `rot` (a multiple of 4 chunks, taken from the tile index) rotates the k order per workgroup: all 1024
+//    waves of the chip otherwise walk the same 1 MiB weight matrix in lockstep and pile onto one L2 channel
+//    at a time.  fp32 sums are reassociated per tile position, deterministically (independent of the batch).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, const float *Hbuf, int wave, int lane, int rot,
                                                f32x4 (&acc)[CNF_MI][CNF_CT])
 {
     const int g = lane >> 4, j = lane & 15;
-    const float *wb = wp + ((long)(wave * CNF_MI) * CNF_KC) * 256 + lane * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, CNF_H * CNF_H * 4, 0x00020000);
+    const int voff = lane * 16;
+    const int sbase = (wave * CNF_MI) * CNF_KC * 1024;   // bytes; row tile mi adds mi*CNF_KC*1024, chunk kc adds kc*1024
     // B-tile read offsets: kq = 4*kc + g  ->  (kq & 15) = (4*kc + g) & 15 alternates with kc & 3
     int boff[4][CNF_CT];
 #pragma unroll
@@ -225,19 +243,18 @@ __device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, con
         for (int ct = 0; ct < CNF_CT; ++ct) acc[mi][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 a0[CNF_MI], a1[CNF_MI], b0[CNF_CT], b1[CNF_CT];
 #pragma unroll
-    for (int mi = 0; mi < CNF_MI; ++mi) a0[mi] = ld4(wb + (long)mi * CNF_KC * 256);
+    for (int mi = 0; mi < CNF_MI; ++mi) a0[mi] = buf_ld4(rs, voff, sbase + (mi * CNF_KC + rot) * 1024);
 #pragma unroll
-    for (int ct = 0; ct < CNF_CT; ++ct) b0[ct] = ld4(Hbuf + boff[0][ct]);
+    for (int ct = 0; ct < CNF_CT; ++ct) b0[ct] = ld4(Hbuf + rot * 4 * CNF_NCOL * 4 + boff[0][ct]);
 #pragma unroll 1
     for (int kc = 0; kc < CNF_KC; kc += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u += 2) {
-            const int k0 = kc + u;
-            // prefetch chunk k0+1 into set 1
+            const int k1 = (kc + u + 1 + rot) & (CNF_KC - 1);   // chunk prefetched into set 1
 #pragma unroll
-            for (int mi = 0; mi < CNF_MI; ++mi) a1[mi] = ld4(wb + ((long)mi * CNF_KC + k0 + 1) * 256);
+            for (int mi = 0; mi < CNF_MI; ++mi) a1[mi] = buf_ld4(rs, voff, sbase + (mi * CNF_KC + k1) * 1024);
 #pragma unroll
-            for (int ct = 0; ct < CNF_CT; ++ct) b1[ct] = ld4(Hbuf + (k0 + 1 - (u + 1)) * 4 * CNF_NCOL * 4 + boff[u + 1][ct]);
+            for (int ct = 0; ct < CNF_CT; ++ct) b1[ct] = ld4(Hbuf + (k1 - (u + 1)) * 4 * CNF_NCOL * 4 + boff[u + 1][ct]);
             __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks these loads to just before their use (no prefetch)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -245,13 +262,13 @@ __device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, con
                 for (int mi = 0; mi < CNF_MI; ++mi)
 #pragma unroll
                     for (int ct = 0; ct < CNF_CT; ++ct) acc[mi][ct] = mfma16(a0[mi][q], b0[ct][q], acc[mi][ct]);
-            // prefetch chunk k0+2 into set 0 (clamped on the last pair)
-            const int kn = (k0 + 2 < CNF_KC) ? k0 + 2 : k0;
+            // prefetch the chunk after that into set 0 (wraps harmlessly on the last pair)
             const int un = (u + 2) & 3;
+            const int k2 = (kc + u + 2 + rot) & (CNF_KC - 1);
 #pragma unroll
-            for (int mi = 0; mi < CNF_MI; ++mi) a0[mi] = ld4(wb + ((long)mi * CNF_KC + kn) * 256);
+            for (int mi = 0; mi < CNF_MI; ++mi) a0[mi] = buf_ld4(rs, voff, sbase + (mi * CNF_KC + k2) * 1024);
 #pragma unroll
-            for (int ct = 0; ct < CNF_CT; ++ct) b0[ct] = ld4(Hbuf + (kn - un) * 4 * CNF_NCOL * 4 + boff[un][ct]);
+            for (int ct = 0; ct < CNF_CT; ++ct) b0[ct] = ld4(Hbuf + (k2 - un) * 4 * CNF_NCOL * 4 + boff[un][ct]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -264,7 +281,7 @@ __device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, con
 }
 
 template <bool WITH_DIV>
-__global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
+__global__ __launch_bounds__(CNF_NT, 2) void cnf_rk4_kernel(CnfArgs a)
 {
     constexpr int PT = WITH_DIV ? CNF_NCOL / 2 : CNF_NCOL;  // points per workgroup (the other half are tangents)
     constexpr int NSTATE = 3 * CNF_NCOL;
@@ -284,6 +301,7 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
     const float *hy = a.hyper + (long)bt * a.ldh;
     constexpr int GOFF = 0, BOFF = 3 * CNF_H + 3;  // column offsets of the gate / bias blocks
     int tid = tid0;
+    const int rot = (blockIdx.x & 7) * 4;   // k-order rotation of this tile position (see cnf_mfma_layer)
 
     // ---- state: thread (d = tid / 32, col = tid % 32), tid < 96
     const int sd = tid0 / CNF_NCOL, scol = tid0 % CNF_NCOL;
@@ -328,6 +346,9 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
             // input-layer weights) is recomputed per stage instead of being hoisted out of the 32-stage loop, where
             // ~150 loop-invariant VGPRs were spilled and reloaded with exposed scratch latency in every epilogue.
             asm volatile("" : "+v"(tid));
+#define CNF_STAMP(i)                                                                                                   \
+    if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid0 == 0 && step == 0) a.trace[stage * 16 + (i)] = __builtin_amdgcn_s_memtime();
+            CNF_STAMP(0)
             const int lane = tid & 63, g = lane >> 4, j = lane & 15;
             const int kq0 = tid & 127, cg0 = tid >> 7;   // input layer: rows 4*kq0 .. +3, column group
             const double tc = (stage == 0) ? 0.0 : (stage == 3 ? 1.0 : 0.5);
@@ -349,7 +370,9 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
                 s_g3[tid] = gt;
                 s_g3[4 + tid] = a.b3[tid] * gt + hb;
             }
+            CNF_STAMP(1)
             __syncthreads();
+            CNF_STAMP(2)
             // ---- input layer 3 -> 512 straight into the B-tile (diffeq_layers.py:83-90 + softplus)
             {
                 float gt[4], hb[4], w0r[4][3];
@@ -385,11 +408,14 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
                     st4(Hbuf + btile_off(kq0, col, CNF_NCOL), v);
                 }
             }
+            CNF_STAMP(3)
             __syncthreads();
+            CNF_STAMP(4)
 
             f32x4 acc[CNF_MI][CNF_CT];
             // ---- hidden layer 1
-            cnf_mfma_layer(a.w1p, Hbuf, wave, lane, acc);
+            cnf_mfma_layer(a.w1p, Hbuf, wave, lane, rot, acc);
+            CNF_STAMP(5)
 #pragma unroll
             for (int mi = 0; mi < CNF_MI; ++mi) {
                 const int co = (wave * CNF_MI + mi) * 16 + 4 * g;
@@ -404,15 +430,20 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
                     }
                 __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 8 tiles' gate loads (VGPR blow-up)
             }
+            CNF_STAMP(6)
             __syncthreads();  // every wave has finished reading Hbuf
+            CNF_STAMP(7)
 #pragma unroll
             for (int mi = 0; mi < CNF_MI; ++mi)
 #pragma unroll
                 for (int ct = 0; ct < CNF_CT; ++ct)
                     st4(Hbuf + btile_off((wave * CNF_MI + mi) * 4 + g, ct * 16 + j, CNF_NCOL), acc[mi][ct]);
+            CNF_STAMP(8)
             __syncthreads();
+            CNF_STAMP(9)
             // ---- hidden layer 2 + fused output layer 512 -> 3
-            cnf_mfma_layer(a.w2p, Hbuf, wave, lane, acc);
+            cnf_mfma_layer(a.w2p, Hbuf, wave, lane, rot, acc);
+            CNF_STAMP(10)
             float part[3][CNF_CT];
 #pragma unroll
             for (int d = 0; d < 3; ++d)
@@ -450,7 +481,9 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
                     v += __shfl_xor(v, 32);
                     if (g == 0) s_red[(wave * 3 + d) * CNF_NCOL + ct * 16 + j] = v;
                 }
+            CNF_STAMP(11)
             __syncthreads();
+            CNF_STAMP(12)
             // ---- combine the wave partials, apply the output ConcatSquash (no softplus: odefunc.py:103)
             if (tid < NSTATE) {
                 float s = 0.f;
@@ -476,7 +509,9 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
                     lacc = (stage == 0) ? o : ((stage == 3) ? lacc + o : lacc + 2.0f * o);
                 }
             }
+            CNF_STAMP(13)
             __syncthreads();
+            CNF_STAMP(14)
         }
         if (is_state) y = y + h6 * kacc;
         if (WITH_DIV && tid < PT) lp = lp + h6 * lacc;
@@ -502,6 +537,10 @@ __global__ __launch_bounds__(CNF_NT) void cnf_rk4_kernel(CnfArgs a)
     }
 }
 
+static unsigned long long *g_cnf_trace = nullptr;
+// debug hook (not part of include/caspr_hip.h): device buffer of >= 64 u64 receiving per-phase cycle stamps
+extern "C" void caspr_debug_set_cnf_trace(unsigned long long *dev_buf) { g_cnf_trace = dev_buf; }
+
 extern "C" int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const float *tcol, const float *w0,
                                  const float *b0, const float *w1p, const float *b1, const float *w2p, const float *b2,
                                  const float *w3, const float *b3, int H, float t_end, int steps, int reverse,
@@ -517,6 +556,7 @@ extern "C" int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh,
     a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.w1p = w1p; a.b1 = b1; a.w2p = w2p; a.b2 = b2;
     a.w3 = w3; a.b3 = b3; a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.e = e; a.logp_in = logp_in; a.logp_out = logp_out;
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
+    a.trace = g_cnf_trace;
     size_t shmem = ((size_t)(CNF_H / 4) * CNF_NCOL * 4 + 4 * CNF_H + CNF_WAVES * 3 * CNF_NCOL + CNF_NCOL * 4 + 3 * CNF_NCOL + 8) * 4;
     if (const char *pad = getenv("CASPR_CNF_LDS_PAD")) shmem += (size_t)atoi(pad) * 1024;  // occupancy experiments only
     hipStream_t st = (hipStream_t)stream;
