@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
                                                       int Cout, int act)
 {
     __shared__ __attribute__((aligned(16))) float sB[2][8 * GEMM_NT * 4];  // 2 x 16 KiB (K tile 32 = 2 chunks; K tile 64 measured slower: fewer blocks per CU)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 4 x 1 wave layout: each wave owns 32 output channels x all 128 points.  The weight fragments (streamed from
     // L2, the scarce per-CU resource at ~10-12 B/clk) are then fetched exactly once per block; the activation
     // fragments are re-read by all four waves, but from LDS.  (2 x 2 waves fetched every weight fragment twice.)
@@ -80,14 +81,21 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     const float *sh = in_scale ? in_shift + (long)b * Cin : nullptr;
 
     // which 16-row tiles of the packed stream this wave owns (wave-uniform validity)
+    // Weight fragments: buffer loads (SGPR resource + SGPR tile/chunk offset + one lane-offset VGPR), no VALU
+    // address arithmetic in the MFMA shadow.  K tiles are walked in an order rotated by the point-tile index so
+    // that the blocks sharing a weight slab do not hit the same L2 channel in lockstep (fp32 sums reassociate
+    // per point tile, independent of the batch index).
     const int mt0 = (co0 >> 4) + wm * 2;
-    const float *wbase[2];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, MT16 * KC * 1024, 0x00020000);
+    const int wvoff = lane * 16;
+    int wsoff[2];
     bool mvalid[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         mvalid[mi] = (mt0 + mi) < MT16;
-        wbase[mi] = wp + ((long)(mvalid[mi] ? mt0 + mi : 0) * KC) * 256 + lane * 4;
+        wsoff[mi] = (mvalid[mi] ? mt0 + mi : 0) * KC * 1024;
     }
+    const int rot = blockIdx.y % ntiles;
 
     f32x4 acc[2][8];
 #pragma unroll
@@ -139,11 +147,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     };
 
     f32x4 a0[2], a1[2], b0[8], b1[8];
-    auto load_a = [&](f32x4(&a)[2], int kc) {
-        const int kk = kc < KC ? kc : KC - 1;
+    auto load_a = [&](f32x4(&a)[2], int kc) {   // kc = chunk index in the packed stream (already rotated)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a[mi] = ld4(wbase[mi] + (long)kk * 256);
+        for (int mi = 0; mi < 2; ++mi)
+            a[mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff[mi] + kc * 1024, 0));
     };
+    auto tile_of = [&](int it) { const int t = it + rot; return t >= ntiles ? t - ntiles : t; };
     auto load_b = [&](f32x4(&bf)[8], int buf, int c) {
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) bf[ni] = ld4(&sB[buf][btile_off(c * 4 + g, ni * 16 + j, GEMM_NT)]);
@@ -157,28 +166,28 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
                 for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = mfma16(a[mi][q], bf[ni][q], acc[mi][ni]);
     };
 
-    load_stage(0);
-    load_a(a0, 0);
-    store_stage(0, 0);
+    load_stage(tile_of(0));
+    load_a(a0, tile_of(0) * 2);
+    store_stage(0, tile_of(0));
     __syncthreads();
 
     // Two register sets per operand: chunk c+1's weight (L2) and activation (LDS) fragments are in flight while
     // chunk c's 64 MFMAs run.  sched_barrier pins the issue point: hipcc otherwise sinks loads to their first use.
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < ntiles;
-        const int kc = kt * 2;
-        if (more) load_stage(kt + 1);          // next tile's global loads stay in flight during this tile's MFMAs
+    for (int it = 0; it < ntiles; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < ntiles;
+        const int kt = tile_of(it), ktn = tile_of(more ? it + 1 : it);
+        if (more) load_stage(ktn);             // next tile's global loads stay in flight during this tile's MFMAs
         load_b(b0, buf, 0);
-        load_a(a1, kc + 1);
+        load_a(a1, kt * 2 + 1);
         load_b(b1, buf, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma(a0, b0);
-        load_a(a0, kc + 2);
+        load_a(a0, ktn * 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1);
         if (more) {
-            store_stage(buf ^ 1, kt + 1);
+            store_stage(buf ^ 1, ktn);
             __syncthreads();
         }
     }

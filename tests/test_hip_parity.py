@@ -418,6 +418,33 @@ def test_demo_config_shape(dev, seeded_sd, sd64, model):
     record_cond("demo_z0", gz0, z0, z64, 1e-5, factor=5.0)
 
 
+def test_real_demo_sequence_vs_reference_golden(dev, seeded_sd, sd64, model, golden):
+    """REAL data (data/demo, 5 steps x 512 points) through the real reference (fixture) vs the HIP path."""
+    x = torch.from_numpy(golden["demo_x"]).unsqueeze(0)
+    sp = torch.from_numpy(golden["demo_nocs"]).unsqueeze(0)
+    yb = torch.from_numpy(golden["demo_ybase"])
+    z64, t64 = O.encode(sd64, x.double())
+    _, _, x64, _ = O.reconstruct(sd64, x.double(), yb.double(), timestamps=sp[0, :, 0, 3].double())
+    _, _, gx, gt = model.reconstruct(x.to(dev), num_points=128, timestamps=sp[0, :, 0, 3].to(dev), y=yb.to(dev))
+    record_cond("realdemo_tnocs", gt, golden["demo_tnocs"], t64, 1e-5, factor=5.0)
+    record_cond("realdemo_recon_x", gx, golden["demo_recon_x"], x64, 1e-5, factor=5.0)
+
+
+def test_warping_config_no_tnocs(dev, seeded_sd):
+    """BASELINE.json configs[3] surface: regress_tnocs=False (no conv3, tnocs None) and max_timestamp=1.0 (warping_cars.cfg)."""
+    from caspr_amd.models import CaSPR
+    m = CaSPR(regress_tnocs=False, cnf_rk4_steps=8, latent_rk4_steps=4)
+    m.load_state_dict({k: v for k, v in seeded_sd.items() if not k.startswith("encoder.conv3")})
+    m = m.to(dev).eval()
+    x, sp = dense_sequences(1, 3, 1024, max_timestamp=1.0)
+    torch.manual_seed(0)
+    yb = torch.randn(1, 3, 256, 3)
+    _, _, wx, wt = O.reconstruct(seeded_sd, x, yb, max_timestamp=1.0, regress_tnocs=False)
+    _, _, gx, gt = m.reconstruct(x.to(dev), num_points=256, max_timestamp=1.0, y=yb.to(dev))
+    assert gt is None and wt is None
+    record("warping_recon_x", gx, wx, 2e-5)
+
+
 def test_full_size_properties(dev, model):
     """cars.cfg recon shape (T=10, N=2048) through size-independent properties (the oracle is too slow here)."""
     from caspr_amd import ops

@@ -151,3 +151,32 @@ def test_rk4_vs_dopri5_gap(seeded_sd):
     xd = O.point_cnf(sd, y, c, None, True, "dopri5", 0)
     assert (x32 - xd).abs().max() < 5e-5      # both converge to the same flow
     assert (x8 - x32).abs().max() < 5e-4      # 8 steps: discretisation error of the seeded dynamics
+
+
+def test_real_demo_sequence(golden, seeded_sd):
+    """data/demo (b28d1b3e.../seq_00000000, first 5 steps x first 512 points: BASELINE.json configs[0]) through the
+    reference's loader + model -> fixture; the oracle must reproduce the reference outputs on this REAL cloud."""
+    x = torch.from_numpy(golden["demo_x"]).unsqueeze(0)
+    sp = torch.from_numpy(golden["demo_nocs"]).unsqueeze(0)
+    assert x.shape == (1, 5, 512, 4) and abs(float(x[..., 3].max()) - 5.0 * 4 / 9) < 1e-6 and abs(float(sp[..., 3].max()) - 4 / 9) < 1e-7
+    z0, tn = O.encode(seeded_sd, x)
+    close(z0, golden["demo_z0"], 1e-5)
+    close(tn, golden["demo_tnocs"], 1e-5)
+    _, _, xr, _ = O.reconstruct(seeded_sd, x, torch.from_numpy(golden["demo_ybase"]), timestamps=sp[0, :, 0, 3],
+                                cnf_steps=int(golden["cnf_steps"]), latent_steps=int(golden["latent_steps"]))
+    close(xr, golden["demo_recon_x"], 1e-5)
+
+
+def test_npz_loader_matches_reference(golden, tmp_path):
+    """caspr_amd.data.load_seq_path against the reference's load_seq_path on frames that need padding and lack depth."""
+    from caspr_amd.data.caspr_dataset import load_seq_path, select_item
+    paths = []
+    for k in range(3):
+        p = tmp_path / ("frame_%08d.npz" % k)
+        np.savez(p, **{key: golden["loader_in_%d_%s" % (k, key)] for key in ("nocs_data", "depth_data", "obj_T")})
+        paths.append(str(p))
+    nocs, depth, pose = load_seq_path(paths, max_timestamp=1.0, expected_num_pts=128)
+    assert np.array_equal(nocs, golden["loader_nocs"]) and np.array_equal(depth, golden["loader_depth"]) and np.array_equal(pose, golden["loader_pose"])
+    xin, xout = select_item(nocs, depth, seq_len=2, num_pts=64)
+    assert xin.shape == (2, 64, 4) and xin.dtype == torch.float32
+    assert torch.equal(xout, torch.from_numpy(golden["loader_nocs"][:2, :64].astype(np.float32)))
