@@ -445,6 +445,40 @@ def test_warping_config_no_tnocs(dev, seeded_sd):
     record("warping_recon_x", gx, wx, 2e-5)
 
 
+@pytest.mark.parametrize("B,T,N,npts", [(1, 1, 200, 50), (3, 2, 333, 97)])
+def test_ragged_shapes(dev, seeded_sd, sd64, model, B, T, N, npts):
+    """Single-step sequences, point counts that are not multiples of any tile (N < every FPS target: repeated
+    indices; GEMM / CNF tail tiles) and a sample count that is not a multiple of the 32-column CNF tile."""
+    x, sp = dense_sequences(B, T, N, seed=B * 100 + N, side=0.2)
+    torch.manual_seed(B)
+    yb = torch.randn(B, T, npts, 3)
+    ts = sp[0, :, 0, 3]
+    _, wlp, wx, wt = O.reconstruct(seeded_sd, x, yb, timestamps=ts)
+    _, _, x64, t64 = O.reconstruct(sd64, x.double(), yb.double(), timestamps=ts.double())
+    _, glp, gx, gt = model.reconstruct(x.to(dev), num_points=npts, timestamps=ts.to(dev), y=yb.to(dev))
+    assert gx.shape == (B, T, npts, 3) and gt.shape == (B, T, N, 4)
+    # N < 1024: FPS repeats indices, neighbourhoods degenerate -> conditioning-aware bound (see record_cond)
+    record_cond("ragged_%dx%dx%d_tnocs" % (B, T, N), gt, wt, t64, 1e-5, factor=5.0)
+    record_cond("ragged_%dx%dx%d_x" % (B, T, N), gx, wx, x64, 1e-5, factor=5.0)
+    assert [int(v) for v in model.get_nfe()] == [4 * 4 * (T - 1), 32]
+
+
+def test_bad_arguments_raise(dev, model):
+    """Error behaviour: Python raises (the reference prints and exit()s), the C ABI reports through its error string."""
+    from caspr_amd import ops, lib
+    with pytest.raises(ValueError):
+        ops.conv1x1(ops.PackedWeight(torch.zeros(8, 8, device=dev)), None, torch.zeros(1, 4, 6, device=dev))   # row stride not a multiple of 4
+    with pytest.raises(lib.CasprHipError, match="ns="):
+        ops.sa_mlp_max(torch.zeros(1, 8, 3, device=dev), torch.zeros(1, 2, 3, device=dev), None,
+                       torch.zeros(1, 2, 8, dtype=torch.int32, device=dev), 0,
+                       model.encoder.local_extract.set_abstractions[0].pointnet_modules[0].kernel_layers(),
+                       torch.zeros(1, 2, 32, device=dev), 0)
+    with pytest.raises(lib.CasprHipError, match="n=5000"):
+        ops.furthest_point_sampling(torch.zeros(1, 5000, 3, device=dev), 16)
+    with pytest.raises(ValueError):
+        model.point_cnf(torch.zeros(2, 8, 3, device=dev), torch.zeros(2, 1600, device=dev), integration_times=torch.tensor([0.0, 1.0]))
+
+
 def test_full_size_properties(dev, model):
     """cars.cfg recon shape (T=10, N=2048) through size-independent properties (the oracle is too slow here)."""
     from caspr_amd import ops
