@@ -152,23 +152,27 @@ class PointNet2SetAbstraction(nn.Module):
     def get_num_features_out(self):
         return sum([lst[-1] for lst in self.pointnet_layer_dims_list])
 
-    def run(self, xyz, feat, C, record=None):
+    def indices(self, xyz):
+        """FPS centres + both ball queries of this level (depend on xyz only): -> dict(fps_idx, new_xyz, ball_idx)."""
+        fps_idx, new_xyz = ops.furthest_point_sampling(xyz, self.num_points_out, return_xyz=True)   # pointnet2.py:384-387
+        ball = [ops.ball_query(g.radius, ns, xyz, new_xyz) for g, ns in zip(self.grouper_modules, self.layers)]  # :391
+        return {"fps_idx": fps_idx, "new_xyz": new_xyz, "ball_idx": ball}
+
+    def run(self, xyz, feat, C, record=None, idx=None):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels (or None).
-        -> new_xyz (B,M,3), new_feat (B,M,Cout)."""
+        -> new_xyz (B,M,3), new_feat (B,M,Cout).  `idx` = precomputed self.indices(xyz)."""
         B = xyz.shape[0]
         M = self.num_points_out
-        fps_idx, new_xyz = ops.furthest_point_sampling(xyz, M, return_xyz=True)                 # pointnet2.py:384-387
+        if idx is None:
+            idx = self.indices(xyz)
+        new_xyz = idx["new_xyz"]
         out = torch.empty(B, M, self.get_num_features_out(), device=xyz.device, dtype=torch.float32)
         off = 0
-        ball = []
         for i, ns in enumerate(self.layers):
-            g = self.grouper_modules[i]
-            bidx = ops.ball_query(g.radius, ns, xyz, new_xyz)                                   # :391
-            ball.append(bidx)
-            ops.sa_mlp_max(xyz, new_xyz, feat, bidx, C, self.pointnet_modules[i].kernel_layers(), out, off)  # :391-409
+            ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off)  # :391-409
             off += self.pointnet_layer_dims_list[i][-1]
         if record is not None:
-            record.append({"fps_idx": fps_idx, "ball_idx": ball, "new_xyz": new_xyz})
+            record.append(idx)
         return new_xyz, out
 
     def forward(self, xyz, features=None):
@@ -207,10 +211,10 @@ class PointNet2FeaturePropagator(nn.Module):
         conv = self.unit_pointnet[i]
         return self._cache.get(i, [conv.weight], lambda: ops.PackedWeight(conv.weight.detach()[:, :, 0].contiguous()))
 
-    def run(self, xyz, xyz_prev, feat, C, prev: Lazy):
+    def run(self, xyz, xyz_prev, feat, C, prev: Lazy, nn=None):
         """Point-major core.  feat (B,n,ldf) skip features with C valid channels (or None); prev = Lazy
-        features of the coarser level.  -> Lazy (B,n,Cout)."""
-        _, idx, w = ops.three_nn(xyz, xyz_prev, with_weights=True)                              # pointnet2.py:514-518
+        features of the coarser level; nn = precomputed ops.three_nn(xyz, xyz_prev, with_weights=True).  -> Lazy (B,n,Cout)."""
+        _, idx, w = nn if nn is not None else ops.three_nn(xyz, xyz_prev, with_weights=True)    # pointnet2.py:514-518
         x = ops.three_interpolate(prev.raw, idx, w, skip=feat, skip_channels=C, in_scale=prev.scale,
                                   in_shift=prev.shift, in_relu=prev.relu, C=prev.channels)      # :519-523
         cur = Lazy(x, prev.channels + C)
@@ -286,20 +290,38 @@ class PointNet2feat(nn.Module):
         conv = self.final_layers[i]
         return self._cache.get(i, [conv.weight], lambda: ops.PackedWeight(conv.weight.detach()[:, :, 0].contiguous()))
 
-    def run(self, xyz, feat, C, out=None, record=None):
+    def indices(self, xyz):
+        """Every index tensor of the level stack -- FPS, ball queries, three-NN + weights -- depends on the
+        coordinates only.  Computing them up front lets the caller run this latency-bound chain (1,872 dependent
+        FPS rounds per frame, one small workgroup per frame) on a side stream under the MFMA-bound kernels."""
+        sa_idx, xyz_list = [], [xyz]
+        for sa in self.set_abstractions:
+            d = sa.indices(xyz_list[-1])
+            sa_idx.append(d)
+            xyz_list.append(d["new_xyz"])
+        nn = []
+        target = -2
+        for _ in self.feature_propagators:
+            nn.append(ops.three_nn(xyz_list[target], xyz_list[target + 1], with_weights=True))
+            target -= 1
+        return {"sa": sa_idx, "nn": nn}
+
+    def run(self, xyz, feat, C, out=None, record=None, idx=None):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels.  -> (B,n,num_classes)
-        written into `out` (may be a column slice of a wider buffer) if given."""
+        written into `out` (may be a column slice of a wider buffer) if given.  `idx` = precomputed self.indices(xyz)."""
+        if idx is None:
+            idx = self.indices(xyz)
         xyz_list, feat_list, ch_list = [xyz], [feat], [C]
-        for sa in self.set_abstractions:                                                        # pointnet2.py:232
-            xyz, feat = sa.run(xyz, feat, C, record)
+        for l, sa in enumerate(self.set_abstractions):                                          # pointnet2.py:232
+            xyz, feat = sa.run(xyz, feat, C, record, idx["sa"][l])
             C = feat.shape[2]
             xyz_list.append(xyz)
             feat_list.append(feat)
             ch_list.append(C)
         prev = Lazy(feat_list[-1], ch_list[-1])
         target = -2
-        for fp in self.feature_propagators:                                                     # :238-245
-            prev = fp.run(xyz_list[target], xyz_list[target + 1], feat_list[target], ch_list[target], prev)
+        for l, fp in enumerate(self.feature_propagators):                                       # :238-245
+            prev = fp.run(xyz_list[target], xyz_list[target + 1], feat_list[target], ch_list[target], prev, idx["nn"][l])
             target -= 1
         c0, gn, c3 = self.final_layers[0], self.final_layers[1], self.final_layers[3]
         y = ops.conv1x1(self._packed_final(0), c0.bias, prev.raw, in_scale=prev.scale, in_shift=prev.shift, in_relu=prev.relu)

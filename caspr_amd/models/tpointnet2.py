@@ -17,6 +17,17 @@ from .pointnet import PointNetfeat
 from .pointnet2 import PointNet2feat as PointNet2
 
 
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v)
+
+
 class TPointNet2(nn.Module):
     def __init__(self, radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], local_feat_size=512, out_feat_size=1600,
                  augment_quad=True, augment_pairs=True, tnocs_point_size=4, regress_tnocs=True):
@@ -52,6 +63,14 @@ class TPointNet2(nn.Module):
         self._cache = WeightCache()
         self.record = None  # set to a list to capture FPS / ball-query indices (parity tests)
 
+    def _side_stream(self, device):
+        key = (device.type, device.index)
+        if not hasattr(self, "_streams"):
+            self._streams = {}
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
+
     def _head_weights(self):
         L, G, S = self.local_feat_size, self.global_feat_size, self.space_time_pt_feat
 
@@ -79,16 +98,27 @@ class TPointNet2(nn.Module):
         P = T * N
         # one buffer holds the head's input [local (L) | raw global conv1 output (S)]
         X1 = torch.empty(B, P, L + S, device=x.device, dtype=torch.float32)
-        # global spatio-temporal feature (tpointnet2.py:75-76)
-        with ops.timed("enc_global_pointnet"):
-            pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
-        # local spatial feature per time step (tpointnet2.py:79-93)
+        # local branch, part 1: every index tensor (FPS / ball query / three-NN) depends on xyz only.  The chain is
+        # latency-bound (one 256-thread workgroup per frame, 1,872 dependent rounds), so it runs on a side stream
+        # underneath the MFMA-bound global PointNet below.
         xyz, feat = ops.prep_input(x, self.augment_quad, self.augment_pairs)
         C = (3 if self.augment_quad else 0) + (3 if self.augment_pairs else 0)
         if C == 0:
             feat = None
+        main = torch.cuda.current_stream()
+        side = self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            idx = self.local_extract.indices(xyz)
+        # global spatio-temporal feature (tpointnet2.py:75-76)
+        with ops.timed("enc_global_pointnet"):
+            pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
+        main.wait_stream(side)
+        for t_ in _tensors(idx):
+            t_.record_stream(main)
+        # local spatial feature per time step (tpointnet2.py:79-93)
         with ops.timed("enc_local_pointnet2"):
-            self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record)
+            self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record, idx=idx)
         t_head = ops.timed("enc_head")
         t_head.__enter__()
 
