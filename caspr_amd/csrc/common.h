@@ -81,4 +81,45 @@ __device__ __forceinline__ float sigmoid_fast(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
 }
 
+// ---------------------------------------------------------------------------------------------
+// All-reduce over W = 4 / 8 / 16 consecutive lanes (aligned groups inside one 16-lane DPP row) with DPP moves:
+// quad_perm [1,0,3,2] (xor 1), quad_perm [2,3,0,1] (xor 2), row_half_mirror (quads 0<->1, 2<->3), row_mirror
+// (halves).  A DPP move is one VALU op; the generic __shfl_xor lowers to ds_bpermute_b32 (an LDS-pipe round trip).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, dpp_mov_i32<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = dpp_mov_i32<CTRL>((int)b), hi = dpp_mov_i32<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int W, typename T>
+__device__ __forceinline__ T row_allreduce_add(T x)
+{
+    x += dpp_mov<0xB1>(x);
+    x += dpp_mov<0x4E>(x);
+    if (W >= 8) x += dpp_mov<0x141>(x);
+    if (W >= 16) x += dpp_mov<0x140>(x);
+    return x;
+}
+template <int W>
+__device__ __forceinline__ float row_allreduce_max(float x)
+{
+    x = fmaxf(x, dpp_mov<0xB1>(x));
+    x = fmaxf(x, dpp_mov<0x4E>(x));
+    if (W >= 8) x = fmaxf(x, dpp_mov<0x141>(x));
+    if (W >= 16) x = fmaxf(x, dpp_mov<0x140>(x));
+    return x;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -7,6 +7,9 @@
 // back as the next layer's B-tile; GroupNorm(16) statistics are per neighbourhood (pointnet2.py:642
 // -> per column block of NS), two-pass in LDS; the final max over the NS samples is fused.  The
 // (B,M,C+3,ns) grouped tensor (22.7 MB / frame at N=2048) is never written to HBM.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "common.h"
 
 struct SaLayer {
@@ -23,6 +26,7 @@ struct SaArgs {
     float *out;
     int ldo, out_off;
     int rowsA, rowsB;  // kq rows of the two ping-pong B-tiles
+    unsigned long long *trace;   // debug stamps (NULL in production)
 };
 
 template <int NS, int NCOL>
@@ -144,8 +148,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                 const int co = grp * cpg + e / NS, col = cen * NS + e % NS;
                 s += (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)];
             }
-#pragma unroll
-            for (int off = TPS >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            s = row_allreduce_add<TPS>(s);
             const double mean = s / (double)cnt;
             double v = 0.0;
             for (int e = sub; e < cnt; e += TPS) {
@@ -153,11 +156,10 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                 const double d = (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)] - mean;
                 v += d * d;
             }
-#pragma unroll
-            for (int off = TPS >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            v = row_allreduce_add<TPS>(v);
             if (sub == 0) {
                 s_mean[stat] = mean;
-                s_rstd[stat] = (float)(1.0 / sqrt(v / (double)cnt + 1e-5));
+                s_rstd[stat] = __builtin_amdgcn_rsqf((float)(v / (double)cnt) + 1e-5f);
             }
         }
         __syncthreads();
@@ -207,6 +209,214 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident variant for the narrow levels (all three widths <= 64: SA1 and SA2, 327,680 + 163,840
+// neighbourhoods per 160-frame batch).  The LDS kernel above is barrier-latency bound there (8 MFMA tiles of
+// work between each pair of __syncthreads).  Here ONE WAVE owns 64 columns (4 centres x 16 or 2 centres x 32
+// neighbours) from gather to max, with no LDS and no barrier:
+//   * the gathered operand goes global -> VGPR in MFMA B-fragment shape (lane (g,j) loads the float4
+//     k = 16kc+4g..+3 of its column's neighbour row);
+//   * the D fragment of row tile mt IS the next layer's B fragment of chunk kc = mt (common.h), so the three
+//     layers chain through registers;
+//   * GroupNorm groups are 1, 2 or 4 channels wide = registers of one lane; their statistics reduce over the
+//     16 lanes (x 1 or 2 column tiles) of the neighbourhood with xor-shuffles, in f64 (one pass: sum, sum of squares);
+//   * max over the neighbourhood = the same shuffle pattern; lanes j == 0 store 4 channels (16 bytes) each.
+// ---------------------------------------------------------------------------------------------
+template <int NS, int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
+{
+    constexpr int CT = 4;                 // 64 columns per wave
+    constexpr int TPC = NS / 16;          // column tiles per centre
+    constexpr int NCEN = CT / TPC;        // centres per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y;
+    const int m0 = (blockIdx.x * 4 + wave) * NCEN;
+    if (m0 >= a.M) return;                // wave-uniform; no barriers in this kernel
+#define SA_STAMP(i) if (a.trace && blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = __builtin_amdgcn_s_memtime();
+    SA_STAMP(0)
+
+    // ---- per column tile: neighbour row + centre
+    int nrow[CT];
+    float cx[CT], cy[CT], cz[CT];
+    bool cval[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int cen = ct / TPC;
+        const int m = (m0 + cen) < a.M ? (m0 + cen) : (a.M - 1);
+        cval[ct] = (m0 + cen) < a.M;
+        const int s = (ct % TPC) * 16 + j;
+        nrow[ct] = a.idx[((long)b * a.M + m) * NS + s];
+        const float *c = a.new_xyz + ((long)b * a.M + m) * 3;
+        cx[ct] = c[0]; cy[ct] = c[1]; cz[ct] = c[2];
+    }
+    const int C4 = (a.C + 3) & ~3;
+    SA_STAMP(1)
+
+    // ---- layer 1: K order = [feat (C, padded to C4) | dx dy dz 0 | zeros]
+    f32x4 h1[C1 / 16][CT];
+#pragma unroll
+    for (int rt = 0; rt < C1 / 16; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KC0 = a.L[0].kc;
+    auto gather = [&](f32x4(&bf)[CT], int kc) {     // B fragments of chunk kc straight from global memory
+        const int k = kc * 16 + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k < C4) {
+                v = ld4(a.feat + ((long)b * a.n + nrow[ct]) * a.ldf + k);
+            } else if (k == C4) {
+                const float *p = a.xyz + ((long)b * a.n + nrow[ct]) * 3;
+                v[0] = p[0] - cx[ct];
+                v[1] = p[1] - cy[ct];
+                v[2] = p[2] - cz[ct];
+            }
+            bf[ct] = v;
+        }
+    };
+    auto mask = [&](f32x4(&bf)[CT], int kc) {       // zero the padding lanes of the feature quad that straddles C
+        const int k = kc * 16 + 4 * g;
+        if (k < C4 && k + 3 >= a.C) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k + q >= a.C) bf[ct][q] = 0.f;
+        }
+    };
+    auto mma1 = [&](const f32x4(&bf)[CT], const f32x4(&af)[C1 / 16]) {
+#pragma unroll
+        for (int rt = 0; rt < C1 / 16; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = mfma16(af[rt][q], bf[ct][q], h1[rt][ct]);
+    };
+    auto load_a1 = [&](f32x4(&af)[C1 / 16], int kc) {
+#pragma unroll
+        for (int rt = 0; rt < C1 / 16; ++rt) af[rt] = ld4(a.L[0].wp + (((long)rt * KC0 + kc) * 64 + lane) * 4);
+    };
+    {   // two register sets: chunk kc+1's gather + weights are in flight while chunk kc multiplies (KC0 is even)
+        f32x4 b0[CT], b1[CT], w0[C1 / 16], w1[C1 / 16];
+        gather(b0, 0);
+        load_a1(w0, 0);
+        for (int kc = 0; kc < KC0; kc += 2) {
+            gather(b1, kc + 1);
+            load_a1(w1, kc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mask(b0, kc);
+            mma1(b0, w0);
+            if (kc + 2 < KC0) {
+                gather(b0, kc + 2);
+                load_a1(w0, kc + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mask(b1, kc + 1);
+            mma1(b1, w1);
+        }
+    }
+
+    // bias + GroupNorm(16) per neighbourhood (+ ReLU) on a register-resident layer output
+    auto norm = [&](auto &h, auto RTc, const SaLayer &L, bool relu) {
+        constexpr int RT = decltype(RTc)::value;
+        constexpr int CPG = RT;            // channels per group = (16*RT)/16
+        static_assert(CPG == 1 || CPG == 2 || CPG == 4, "register GroupNorm handles widths 16, 32, 64");
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 bias4 = ld4(L.bias + rt * 16 + 4 * g);
+            const f32x4 ga = ld4(L.gamma + rt * 16 + 4 * g), be = ld4(L.beta + rt * 16 + 4 * g);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) h[rt][ct] += bias4;
+#pragma unroll
+            for (int cen = 0; cen < NCEN; ++cen)
+#pragma unroll
+                for (int sg = 0; sg < 4 / CPG; ++sg) {
+                    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < TPC; ++t)
+#pragma unroll
+                        for (int r = 0; r < CPG; ++r) {
+                            const double x = (double)h[rt][cen * TPC + t][sg * CPG + r];
+                            s1 += x;
+                            s2 += x * x;
+                        }
+                    s1 = row_allreduce_add<16>(s1);
+                    s2 = row_allreduce_add<16>(s2);
+                    constexpr double inv = 1.0 / (double)(CPG * NS);
+                    const double mean = s1 * inv;
+                    double var = s2 * inv - mean * mean;      // f64: exact enough even when var << mean^2
+                    var = var < 0.0 ? 0.0 : var;
+                    const float rstd = __builtin_amdgcn_rsqf((float)var + 1e-5f);
+#pragma unroll
+                    for (int t = 0; t < TPC; ++t)
+#pragma unroll
+                        for (int r = 0; r < CPG; ++r) {
+                            const int e = sg * CPG + r;
+                            const float y = (float)((double)h[rt][cen * TPC + t][e] - mean) * (rstd * ga[e]) + be[e];
+                            h[rt][cen * TPC + t][e] = relu ? (y > 0.f ? y : 0.f) : y;
+                        }
+                }
+        }
+    };
+    // next layer from a register-resident input: chunk kc of the K loop = row tile kc of the input
+    auto layer = [&](auto &hout, auto RTo, const auto &hin, auto RTi, const SaLayer &L) {
+        constexpr int RO = decltype(RTo)::value, RI = decltype(RTi)::value;
+        f32x4 af[RO][RI];   // all weight fragments of the layer first (L1/L2 hits), then the MFMAs back to back
+#pragma unroll
+        for (int rt = 0; rt < RO; ++rt)
+#pragma unroll
+            for (int kc = 0; kc < RI; ++kc) af[rt][kc] = ld4(L.wp + (((long)rt * L.kc + kc) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RO; ++rt) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) hout[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < RI; ++kc)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) hout[rt][ct] = mfma16(af[rt][kc][q], hin[kc][ct][q], hout[rt][ct]);
+        }
+    };
+    using I1 = std::integral_constant<int, C1 / 16>;
+    using I2 = std::integral_constant<int, C2 / 16>;
+    using I3 = std::integral_constant<int, C3 / 16>;
+    SA_STAMP(2)
+    norm(h1, I1{}, a.L[0], true);
+    SA_STAMP(3)
+    f32x4 h2[C2 / 16][CT];
+    layer(h2, I2{}, h1, I1{}, a.L[1]);
+    SA_STAMP(4)
+    norm(h2, I2{}, a.L[1], true);
+    SA_STAMP(5)
+    f32x4 h3[C3 / 16][CT];
+    layer(h3, I3{}, h2, I2{}, a.L[2]);
+    SA_STAMP(6)
+    norm(h3, I3{}, a.L[2], false);
+    SA_STAMP(7)
+
+    // ---- max over the NS samples of each centre (pointnet2.py:690-698)
+#pragma unroll
+    for (int rt = 0; rt < C3 / 16; ++rt)
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen) {
+            f32x4 mx = h3[rt][cen * TPC];
+#pragma unroll
+            for (int t = 1; t < TPC; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], h3[rt][cen * TPC + t][e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx[e] = row_allreduce_max<16>(mx[e]);
+            if (j == 0 && cval[cen * TPC])
+                st4(a.out + ((long)b * a.M + m0 + cen) * a.ldo + a.out_off + rt * 16 + 4 * g, mx);
+        }
+    SA_STAMP(8)
+}
+
 template <int NS, int NCOL>
 static int launch_sa(const SaArgs &a, int B, size_t shmem, hipStream_t st)
 {
@@ -222,6 +432,9 @@ static int launch_sa(const SaArgs &a, int B, size_t shmem, hipStream_t st)
     kern<<<dim3(ceil_div(a.M, NCEN), B), dim3(256), shmem, st>>>(a);
     return CASPR_OK;
 }
+
+static unsigned long long *g_sa_trace = nullptr;
+extern "C" void caspr_debug_set_sa_trace(unsigned long long *dev_buf) { g_sa_trace = dev_buf; }   // debug hook
 
 extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
                                     const int32_t *idx, int B, int n, int M, int C, int ns, const float *w1p,
@@ -245,16 +458,32 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
     a.L[1] = {w2p, b2, g2, be2, C2, 2 * ((C1 + 31) / 32)};
     a.L[2] = {w3p, b3, g3, be3, C3, 2 * ((C2 + 31) / 32)};
     a.out = out; a.ldo = ldo; a.out_off = out_off;
+    a.trace = g_sa_trace;
     const int rA = a.L[0].kc * 4 > a.L[2].kc * 4 ? a.L[0].kc * 4 : a.L[2].kc * 4;
     const int rB0 = a.L[1].kc * 4, rB1 = C3 / 4;
     a.rowsA = rA > C2 / 4 ? rA : C2 / 4;
     a.rowsB = rB0 > rB1 ? rB0 : rB1;
     if (a.rowsB < C1 / 4) a.rowsB = C1 / 4;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool no_small = getenv("CASPR_SA_NO_SMALL") != nullptr;   // experiments: force the LDS kernel
+    if (!no_small && ldo % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)out % 16) == 0) {
+        const int cpb = 4 * (64 / ns);   // centres per 256-thread block (4 waves x 64 columns)
+        dim3 grid(ceil_div(M, cpb), B);
+        bool done = true;
+        if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 16) sa_small_kernel<16, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
+        else if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 32) sa_small_kernel<32, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
+        else if (C1 == 32 && C2 == 32 && C3 == 64 && ns == 16) sa_small_kernel<16, 32, 32, 64><<<grid, dim3(256), 0, st>>>(a);
+        else if (C1 == 32 && C2 == 32 && C3 == 64 && ns == 32) sa_small_kernel<32, 32, 32, 64><<<grid, dim3(256), 0, st>>>(a);
+        else done = false;
+        if (done) {
+            CASPR_CHECK_LAUNCH("sa_mlp_max(small)");
+            return CASPR_OK;
+        }
+    }
     const int bigK = (K0 > 160) || (C3 > 128);
     const int ncol = bigK ? 32 : 64;
     const size_t shmem = (size_t)(a.rowsA + a.rowsB) * ncol * 16 + (3 * 64 + 16 + 64) * 4 + 64;
     CASPR_REQUIRE(shmem <= 160 * 1024, "sa_mlp_max: needs %zu bytes of LDS (> 160 KiB)", shmem);
-    hipStream_t st = (hipStream_t)stream;
     int rc;
     if (ns == 16 && ncol == 64) rc = launch_sa<16, 64>(a, B, shmem, st);
     else if (ns == 32 && ncol == 64) rc = launch_sa<32, 64>(a, B, shmem, st);
