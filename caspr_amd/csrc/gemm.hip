@@ -53,15 +53,19 @@ extern "C" int caspr_pack_weight_f32(const float *w, int ldw, int Cout, int col0
 #define GEMM_MT 128
 #define GEMM_NT 128
 #define GEMM_KT 32
+#define GEMM_MAXC 2048
 
 __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
                                                       const float *__restrict__ bbias, const float *__restrict__ X,
                                                       int ldx, const float *__restrict__ in_scale,
                                                       const float *__restrict__ in_shift, int in_relu,
                                                       int relu_from, float *__restrict__ Y, int ldy, int P, int Cin,
-                                                      int Cout, int act)
+                                                      int Cout, int act, unsigned long long *trace)
 {
     __shared__ __attribute__((aligned(16))) float sB[2][8 * GEMM_NT * 4];  // 2 x 16 KiB (K tile 32 = 2 chunks; K tile 64 measured slower: fewer blocks per CU)
+    // per-batch GroupNorm scale / shift of the input channels, staged once per block: reading them from global
+    // memory inside store_stage exposed an L2 round trip per K tile (tools/gemm_phase_trace.py: 3.6-5.9k of 12.5k cycles)
+    __shared__ __attribute__((aligned(16))) float sSS[2][GEMM_MAXC];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 4 x 1 wave layout: each wave owns 32 output channels x all 128 points.  The weight fragments (streamed from
@@ -79,6 +83,13 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     const float *Xb = X + (long)b * P * ldx;
     const float *sc = in_scale ? in_scale + (long)b * Cin : nullptr;
     const float *sh = in_scale ? in_shift + (long)b * Cin : nullptr;
+    const bool ss_lds = sc && Cin <= GEMM_MAXC;
+    if (ss_lds) {
+        for (int c = tid * 4; c < Cin; c += 1024) {   // Cin % 4 == 0 when the transform is fused
+            st4(&sSS[0][c], ld4(sc + c));
+            st4(&sSS[1][c], ld4(sh + c));
+        }
+    }
 
     // which 16-row tiles of the packed stream this wave owns (wave-uniform validity)
     // Weight fragments: buffer loads (SGPR resource + SGPR tile/chunk offset + one lane-offset VGPR), no VALU
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
             f32x4 v = stage[i];
             if (p < P && k < Cin) {
                 if (sc) {
-                    const f32x4 s4 = ld4(sc + k), t4 = ld4(sh + k);  // scale/shift rows are padded to 4
+                    const f32x4 s4 = ss_lds ? ld4(&sSS[0][k]) : ld4(sc + k), t4 = ss_lds ? ld4(&sSS[1][k]) : ld4(sh + k);
                     v = v * s4 + t4;
                     if (in_relu && k >= relu_from) {  // relu_from % 4 == 0
 #pragma unroll
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         }
     };
 
-    f32x4 a0[2], a1[2], b0[8], b1[8];
+    f32x4 a0[2], a1[2], b0[8];   // one activation-fragment set: a second one costs 32 VGPRs = the third resident block per CU
     auto load_a = [&](f32x4(&a)[2], int kc) {   // kc = chunk index in the packed stream (already rotated)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -177,18 +188,25 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         const int buf = it & 1;
         const bool more = it + 1 < ntiles;
         const int kt = tile_of(it), ktn = tile_of(more ? it + 1 : it);
+#define GEMM_STAMP(i) if (trace && blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == 0 && tid == 0 && it >= 8 && it < 12) trace[(it - 8) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+        GEMM_STAMP(0)
         if (more) load_stage(ktn);             // next tile's global loads stay in flight during this tile's MFMAs
         load_b(b0, buf, 0);
         load_a(a1, kt * 2 + 1);
-        load_b(b1, buf, 1);
         __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP(1)
         mma(a0, b0);
+        GEMM_STAMP(2)
+        load_b(b0, buf, 1);
         load_a(a0, ktn * 2);
         __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
+        mma(a1, b0);
+        GEMM_STAMP(3)
         if (more) {
             store_stage(buf ^ 1, ktn);
+            GEMM_STAMP(4)
             __syncthreads();
+            GEMM_STAMP(5)
         }
     }
 
@@ -415,6 +433,15 @@ __global__ __launch_bounds__(256) void conv1x1_big_kernel(const float *__restric
     }
 }
 
+extern "C" int caspr_debug_gemm_occupancy(void)   // debug hook: resident conv1x1_kernel blocks per CU
+{
+    int n = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)conv1x1_kernel, 256, 0);
+    return n;
+}
+static unsigned long long *g_gemm_trace = nullptr;
+extern "C" void caspr_debug_set_gemm_trace(unsigned long long *dev_buf) { g_gemm_trace = dev_buf; }   // debug hook
+
 extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float *bbias, const float *X, int ldx,
                                  const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
                                  int ldy, int B, int P, int Cin, int Cout, int act, void *stream)
@@ -449,7 +476,7 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, GEMM_NT), B);
     static const size_t lds_pad = getenv("CASPR_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CASPR_GEMM_LDS_PAD")) * 1024 : 0;  // occupancy experiments
     conv1x1_kernel<<<grid, dim3(256), lds_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
-                                                                in_relu_from, Y, ldy, P, Cin, Cout, act);
+                                                                in_relu_from, Y, ldy, P, Cin, Cout, act, g_gemm_trace);
     CASPR_CHECK_LAUNCH("conv1x1");
     return CASPR_OK;
 }
