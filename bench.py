@@ -107,10 +107,18 @@ def main():
         cnf_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
         flop = float((hi - lo) * T * N) * 4 * args.cnf_steps * CNF_FLOP_PER_POINT_EVAL
         achieved = flop / (cnf_ms * 1e-3) / 1e12 if cnf_ms > 0 else 0.0
+        # HBM traffic per launch cannot be counted from inside this process: it is taken from the committed PMC pass
+        # of this same command and workload (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, gfx950 correction).
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_cnf_traffic.json")
+        if os.path.exists(tpath) and (B, T, N, args.cnf_steps) == (16, 10, 2048, 8):
+            tj = json.load(open(tpath))
+            traffic = int(1024 * (tj["fetch_size_kb_per_launch"] * tj["fetch_correction"] + tj["write_size_kb_per_launch"]))
+            traffic_src = tj["source"]
         roofline = {"kernel": "cnf_rk4_kernel<false>", "bound": "mfma", "achieved": round(achieved, 3),
                     "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
-                    "traffic": None, "launch_ms": round(cnf_ms, 3), "launches_timed": len(ev),
-                    "flop_per_launch": flop}
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "launch_ms": round(cnf_ms, 3), "launches_timed": len(ev), "flop_per_launch": flop}
         breakdown = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in ops.TIMERS.items()}
 
         cpu = None

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
             st4(&sSS[0][c], ld4(sc + c));
             st4(&sSS[1][c], ld4(sh + c));
         }
+        __syncthreads();   // the first store_stage below reads sSS
     }
 
     // which 16-row tiles of the packed stream this wave owns (wave-uniform validity)

@@ -220,6 +220,20 @@ def test_conv1x1_fused_input_and_epilogues(ops, dev):
     assert torch.equal(pw2.data, pw.data)
 
 
+def test_conv1x1_repeatable_under_load(ops, dev):
+    """Many co-resident blocks, fused input transform staged through LDS: two launches must agree bit for bit
+    (caught a missing barrier after the per-block scale/shift staging once)."""
+    B, P_, Cin, Cout = 4, 4096, 512, 512
+    x, w = rnd(1, B, P_, Cin).to(dev), rnd(2, Cout, Cin, scale=0.05).to(dev)
+    sc, sh = (rnd(3, B, Cin).abs() + 0.5).to(dev), rnd(4, B, Cin).to(dev)
+    pw = ops.PackedWeight(w)
+    y1 = ops.conv1x1(pw, None, x, in_scale=sc, in_shift=sh, in_relu=True)
+    want = torch.relu(x * sc.unsqueeze(1) + sh.unsqueeze(1)).double() @ w.double().t()
+    record("conv1x1_under_load", y1, want, 2e-5)
+    for _ in range(5):
+        exact("conv1x1_repeat", ops.conv1x1(pw, None, x, in_scale=sc, in_shift=sh, in_relu=True), y1)
+
+
 @pytest.mark.parametrize("B,P_,C", [(2, 2500, 64), (1, 1024, 1600), (3, 64, 512), (2, 1100, 1024), (2, 333, 128)])
 def test_gn_stats(ops, dev, B, P_, C):
     y = rnd(C, B, P_, C) * 2.0 + 0.7
