@@ -1,0 +1,88 @@
+"""Reconstruction / T-NOCS evaluation protocols (reference: caspr/utils/evaluations.py:26-295) on the HIP path.
+
+Metric side of BASELINE.json's headline ("sequences/sec + Chamfer-L2"): the paper's protocol evaluates 10 steps x 2048
+points, either all steps observed or steps [0,5,9] observed / [1,2,3,4,6,7,8] unobserved (evaluations.py:26-34), with
+Chamfer = mean_i min_j |p_i-g_j|^2 + mean_j min_i |.|^2 per frame (evaluations.py:36-44; printed x1000).  EMD
+(evaluations.py:46-47, PyTorchEMD) and the RANSAC pose eval are out of scope.
+Differences from the reference, on purpose: bad protocol sizes raise ValueError instead of exit(); the inference
+timer synchronises the device (evaluations.py:108-115 does not)."""
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+
+PROTOCOL_NUM_STEPS = 10
+PROTOCOL_NUM_PTS = 2048
+ALL_OBSERVED_STEPS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+ALL_UNOBSERVED_STEPS = []
+SPLIT_OBSERVED_STEPS = [0, 5, 9]
+SPLIT_UNOBSERVED_STEPS = [1, 2, 3, 4, 6, 7, 8]
+
+
+def eval_reconstr_frames(pred, gt):
+    """evaluations.py:36-44 (Chamfer part): pred, gt (F,N,3) on the GPU -> per-frame Chamfer-L2 (F,) numpy."""
+    dist1, dist2 = ops.chamfer_distance(pred.contiguous(), gt.contiguous())
+    return (torch.mean(dist1, dim=1) + torch.mean(dist2, dim=1)).cpu().numpy()
+
+
+def _stats(values, scale=1.0):
+    v = np.asarray(values, dtype=np.float64) * scale
+    return {"mean": float(np.mean(v)), "median": float(np.median(v)), "std": float(np.std(v))} if v.size else None
+
+
+def test_shape_recon(model, batches, device, observed_steps=ALL_OBSERVED_STEPS, unobserved_steps=ALL_UNOBSERVED_STEPS,
+                     protocol=True, base_samples=None):
+    """evaluations.py:51-201.  `batches` yields (pcl_in (B,T,N,4), nocs_out (B,T,N,4)); only the observed steps are
+    encoded, all steps are reconstructed at nocs_out's timestamps.  Returns chamfer x1000 statistics for observed /
+    unobserved frames, mean NFE and mean inference time.  base_samples: optional list of (B,T,N,3) tensors (parity tests)."""
+    model.eval()
+    obs, unobs, nfe, times = [], [], [], []
+    for bi, (pcl_in, nocs_out) in enumerate(batches):
+        pcl_in, nocs_out = pcl_in.to(device), nocs_out.to(device)
+        B, T, N, _ = pcl_in.size()
+        if protocol and T != PROTOCOL_NUM_STEPS:
+            raise ValueError('Test protocol requires %d steps, but %d given!' % (PROTOCOL_NUM_STEPS, T))
+        if protocol and N != PROTOCOL_NUM_PTS:
+            raise ValueError('Test protocol requires %d points, but %d given!' % (PROTOCOL_NUM_PTS, N))
+        observed_pcl_in = pcl_in[:, observed_steps, :, :].contiguous()
+        y = None if base_samples is None else base_samples[bi].to(device)
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        _, _, pred_pcl, _ = model.reconstruct(observed_pcl_in, num_points=N, timestamps=nocs_out[0, :, 0, 3],
+                                              constant_in_time=False, y=y)
+        torch.cuda.synchronize(device)
+        times.append(time.time() - t0)
+        nfe.append(model.get_nfe())
+        gt = nocs_out[:, observed_steps, :, :3].reshape(B * len(observed_steps), N, 3)
+        obs.extend(eval_reconstr_frames(pred_pcl[:, observed_steps].reshape(B * len(observed_steps), N, 3), gt).tolist())
+        if len(unobserved_steps) > 0:
+            gt = nocs_out[:, unobserved_steps, :, :3].reshape(B * len(unobserved_steps), N, 3)
+            unobs.extend(eval_reconstr_frames(pred_pcl[:, unobserved_steps].reshape(B * len(unobserved_steps), N, 3), gt).tolist())
+    return {"observed_chamfer_x1000": _stats(obs, 1000.0), "unobserved_chamfer_x1000": _stats(unobs, 1000.0),
+            "observed_chamfer": obs, "unobserved_chamfer": unobs,
+            "nfe_mean": np.mean(nfe, axis=0).tolist() if nfe else None, "infer_time_mean": float(np.mean(times)) if times else None}
+
+
+def test_tnocs_regression(model, batches, device, protocol=True):
+    """evaluations.py:203-295: mean L2 distance in space and mean |dt| per (sequence, step)."""
+    model.eval()
+    space, tdiff = [], []
+    for pcl_in, nocs_out in batches:
+        pcl_in, nocs_out = pcl_in.to(device), nocs_out.to(device)
+        B, T, N, _ = pcl_in.size()
+        if protocol and (T != PROTOCOL_NUM_STEPS or N != PROTOCOL_NUM_PTS):
+            raise ValueError('Test protocol requires %d steps x %d points, but %d x %d given!' % (PROTOCOL_NUM_STEPS, PROTOCOL_NUM_PTS, T, N))
+        with torch.no_grad():
+            _, pred_tnocs = model.encode(pcl_in)
+        diff = pred_tnocs[:, :, :, :3] - nocs_out[:, :, :, :3]
+        space.extend(torch.mean(torch.norm(diff, dim=3), dim=2).cpu().numpy().reshape(-1).tolist())
+        if pred_tnocs.size(3) > 3:
+            tdiff.extend(torch.mean(torch.abs(pred_tnocs[:, :, :, 3] - nocs_out[:, :, :, 3]), dim=2).cpu().numpy().reshape(-1).tolist())
+    return {"space": _stats(space), "time": _stats(tdiff)}
+
+
+# keep pytest from collecting the reference-named entry points of this module
+test_shape_recon.__test__ = False
+test_tnocs_regression.__test__ = False

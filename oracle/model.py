@@ -437,12 +437,13 @@ def reconstruct(sd, x, y, timestamps=None, max_timestamp=5.0, method="rk4", cnf_
     z = aggregate_and_solve_latent(sd, z0, all_times, method=method, steps_per_interval=latent_steps,
                                    counter=lat_counter)
     n = y.shape[2]
-    yy = y.reshape(B * T, n, 3)
-    logp_y = standard_normal_logprob(yy).view(B * T, n, -1).sum(2)             # :258
-    xs = point_cnf(sd, yy, z.reshape(B * T, -1), None, True, method, cnf_steps, counter=cnf_counter)
+    Tz = z.shape[1]                      # decode() takes T from the latent codes (caspr.py:227): may exceed the observed steps
+    yy = y.reshape(B * Tz, n, 3)
+    logp_y = standard_normal_logprob(yy).view(B * Tz, n, -1).sum(2)            # :258
+    xs = point_cnf(sd, yy, z.reshape(B * Tz, -1), None, True, method, cnf_steps, counter=cnf_counter)
     if nfe is not None:
         nfe[:] = [lat_counter[0], cnf_counter[0]]
-    return y, logp_y.view(B, T, n), xs.view(B, T, n, 3), tnocs
+    return y, logp_y.view(B, Tz, n), xs.view(B, Tz, n, 3), tnocs
 
 
 def forward_nll(sd, x, sample_points, e, method="rk4", cnf_steps=8, latent_steps=4, radii=DEFAULT_RADII):

@@ -493,6 +493,30 @@ def test_bad_arguments_raise(dev, model):
         model.point_cnf(torch.zeros(2, 8, 3, device=dev), torch.zeros(2, 1600, device=dev), integration_times=torch.tensor([0.0, 1.0]))
 
 
+def test_eval_protocols_vs_oracle(dev, seeded_sd, model):
+    """evaluations.py protocols (10 steps x 2048 points; 3 observed / 7 unobserved) on the HIP path vs the oracle."""
+    from caspr_amd.utils import evaluations as E
+    x, sp = dense_sequences(1, 10, 2048, seed=11)
+    torch.manual_seed(5)
+    yb = torch.randn(1, 10, 2048, 3)
+    res = E.test_shape_recon(model, [(x, sp)], dev, E.SPLIT_OBSERVED_STEPS, E.SPLIT_UNOBSERVED_STEPS, base_samples=[yb])
+    # oracle: encode only the observed steps, reconstruct at all 10 timestamps (evaluations.py:105-114)
+    _, _, wx, _ = O.reconstruct(seeded_sd, x[:, E.SPLIT_OBSERVED_STEPS].contiguous(), yb, timestamps=sp[0, :, 0, 3])
+    want_obs = O.chamfer_l2(wx[0, E.SPLIT_OBSERVED_STEPS], sp[0, E.SPLIT_OBSERVED_STEPS, :, :3].contiguous())
+    want_un = O.chamfer_l2(wx[0, E.SPLIT_UNOBSERVED_STEPS], sp[0, E.SPLIT_UNOBSERVED_STEPS, :, :3].contiguous())
+    # north_star: Chamfer-L2 to 1e-5.  With random weights the reconstruction is far from the ground truth
+    # (Chamfer ~ 1.6, a trained model gives ~1e-3), so the bound is taken relative to the value.
+    record("eval_chamfer_observed", torch.tensor(res["observed_chamfer"]), want_obs, 1e-5 * max(1.0, float(want_obs.max())))
+    record("eval_chamfer_unobserved", torch.tensor(res["unobserved_chamfer"]), want_un, 1e-5 * max(1.0, float(want_un.max())))
+    assert res["nfe_mean"] == [4 * 4 * 9, 32] and res["infer_time_mean"] > 0
+    tn = E.test_tnocs_regression(model, [(x, sp)], dev)
+    _, wt = O.encode(seeded_sd, x)
+    want_space = torch.mean(torch.norm(wt[..., :3] - sp[..., :3], dim=3), dim=2).mean()
+    record("eval_tnocs_space_mean", torch.tensor(tn["space"]["mean"]), want_space, 1e-5)
+    with pytest.raises(ValueError):
+        E.test_shape_recon(model, [(x[:, :5], sp[:, :5])], dev)
+
+
 def test_full_size_properties(dev, model):
     """cars.cfg recon shape (T=10, N=2048) through size-independent properties (the oracle is too slow here)."""
     from caspr_amd import ops
