@@ -62,8 +62,11 @@ class CNF(nn.Module):
         return self._cache.get("w", srcs, build)
 
     def end_time(self):
+        """T_end = sqrt_end_time^2 (cnf.py:87-90), read back once per parameter version (a D2H sync otherwise
+        sits between the encoder and every CNF launch)."""
         if self.train_T:
-            return float(self.sqrt_end_time.detach() * self.sqrt_end_time.detach())              # cnf.py:87-90
+            p = self.sqrt_end_time
+            return self._cache.get("t_end", [p], lambda: float(p.detach() * p.detach()))
         return float(self.T)
 
     def integrate(self, x, context, logpx, reverse, mbn_in=None, mbn_out=None):

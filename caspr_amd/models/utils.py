@@ -1,37 +1,41 @@
-"""Sampling helpers (reference: caspr/models/utils.py)."""
-from math import log, pi
+"""Base-distribution helpers of the decoder.  Behavioural contract = caspr/models/utils.py:10-29 (the reference
+draws on the CPU generator and then moves the tensor, so `torch.manual_seed` reproduces its samples exactly) and
+caspr/utils/transform_utils.py:80-85 (`sphere_surface_points`, numpy global RNG)."""
+import math
 
 import numpy as np
 import torch
 
+_LOG_SQRT_2PI = 0.5 * math.log(2.0 * math.pi)
+
 
 def standard_normal_logprob(z):
-    log_z = -0.5 * log(2 * pi)
-    return log_z - z.pow(2) / 2
+    """Element-wise log N(z; 0, 1)."""
+    return -_LOG_SQRT_2PI - 0.5 * z * z
 
 
 def truncated_normal(tensor, mean=0, std=1, trunc_std=2):
-    """models/utils.py:15-22: pick the first of 4 normal draws inside (-trunc_std, trunc_std)."""
-    size = tensor.shape
-    tmp = tensor.new_empty(size + (4,)).normal_()
-    valid = (tmp < trunc_std) & (tmp > -trunc_std)
-    ind = valid.max(-1, keepdim=True)[1]
-    tensor.data.copy_(tmp.gather(-1, ind).squeeze(-1))
-    tensor.data.mul_(std).add_(mean)
+    """In-place: each element becomes the first of four fresh N(0,1) candidates that lies inside
+    (-trunc_std, trunc_std) (candidate 0 if none does), then is scaled and shifted."""
+    candidates = tensor.new_empty(tuple(tensor.shape) + (4,)).normal_()
+    inside = candidates.abs() < trunc_std
+    first = inside.to(torch.uint8).argmax(dim=-1, keepdim=True)     # argmax returns the first maximal index
+    picked = torch.gather(candidates, -1, first).squeeze(-1)
+    tensor.data.copy_(picked * std + mean)
     return tensor
 
 
 def sample_gaussian(size, truncate_std=None, device=None):
-    """models/utils.py:24-29: drawn on the CPU generator, then moved (reproducible from torch.manual_seed)."""
-    y = torch.randn(*size).float()
-    y = y if device is None else y.to(device)
+    """N(0,1) samples of shape `size`, drawn with the CPU generator and moved to `device` afterwards."""
+    y = torch.randn(*size, dtype=torch.float32)
+    if device is not None:
+        y = y.to(device)
     if truncate_std is not None:
         truncated_normal(y, mean=0, std=1, trunc_std=truncate_std)
     return y
 
 
 def sphere_surface_points(num_points, radius=0.5):
-    """utils/transform_utils.py:80-85 (numpy global RNG, as the reference)."""
-    uniform_cube = np.random.uniform(low=-1.0, high=1.0, size=(num_points, 3))
-    norm_uniform = uniform_cube / np.linalg.norm(uniform_cube, axis=1).reshape((-1, 1))
-    return norm_uniform * radius
+    """Uniform directions (normalised uniform-cube draws, as the reference) on a sphere of the given radius."""
+    cube = np.random.uniform(low=-1.0, high=1.0, size=(num_points, 3))
+    return radius * cube / np.linalg.norm(cube, axis=1, keepdims=True)
