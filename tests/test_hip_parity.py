@@ -517,6 +517,53 @@ def test_eval_protocols_vs_oracle(dev, seeded_sd, model):
         E.test_shape_recon(model, [(x[:, :5], sp[:, :5])], dev)
 
 
+def test_decode_options_and_variants(dev, seeded_sd, model, tmp_path):
+    """The remaining branches of CaSPR.decode / ctor variants (caspr.py:204-267, 23-70) on the HIP path."""
+    from caspr_amd.models import CaSPR
+    from caspr_amd.utils.torch_utils import load_weights
+    x, sp = dense_sequences(2, 3, 1024, seed=21)
+    xd, ts = x.to(dev), sp[0, :, 0, 3].to(dev)
+    # constant_in_time: one base cloud per sequence, repeated over the steps (caspr.py:254-256)
+    torch.manual_seed(2)
+    y, logp, xr, _ = model.reconstruct(xd, num_points=96, timestamps=ts, constant_in_time=True)
+    assert torch.equal(y[:, 0], y[:, 2]) and not torch.equal(xr[:, 0], xr[:, 2])
+    torch.manual_seed(2)
+    assert torch.equal(y[:, 0].cpu(), torch.randn(2, 96, 3))
+    record("decode_logp_y", logp, (-0.5 * np.log(2 * np.pi) - y.cpu() ** 2 / 2).sum(-1), 1e-6)
+    # truncated base samples (models/utils.py:15-22) and Gaussian contours (caspr.py:232-250)
+    y, _, xr, _ = model.reconstruct(xd, num_points=64, timestamps=ts, truncate_std=1.5)
+    # 4 candidates per element: (1 - 0.866)^4 = 3e-4 of the elements keep an out-of-range first candidate, as in the reference
+    assert float((y.abs() < 1.5).float().mean()) > 0.995 and torch.isfinite(xr).all()
+    y, _, xr, _ = model.reconstruct(xd, num_points=90, timestamps=ts, sample_contours=[0.5, 1.0, 2.0])
+    r = y.norm(dim=-1)[0, 0].cpu()
+    assert torch.allclose(r[:30], torch.full((30,), 0.5), atol=1e-5) and torch.allclose(r[60:], torch.full((30,), 2.0), atol=1e-5)
+    # timestamps=None: times come from the input cloud divided by max_timestamp (caspr.py:299-300)
+    yb = torch.randn(2, 3, 64, 3)
+    _, _, xa, _ = model.reconstruct(xd, num_points=64, y=yb.to(dev))
+    _, _, wa, _ = O.reconstruct(seeded_sd, x, yb)
+    record("recon_times_from_input", xa, wa, 2e-5)
+    # pretrain_tnocs surface: encoder only, forward returns (tnocs_loss,) (caspr.py:55-57,97-99)
+    pm = CaSPR(pretrain_tnocs=True)
+    load_weights(pm, {k: v for k, v in seeded_sd.items() if k.startswith("encoder.")})
+    pm = pm.to(dev).eval()
+    (tl,) = pm(xd, sp.to(dev))
+    _, wt = O.encode(seeded_sd, x)
+    record("pretrain_tnocs_loss", tl, (wt - sp).abs(), 2e-5)
+    # two stacked CNF blocks (flow.py:68-72): chain [MBN, CNF, CNF, MBN]; checkpoint round trip through torch.save
+    m2 = CaSPR(cnf_blocks=2, cnf_rk4_steps=4, latent_rk4_steps=4)
+    from caspr_amd.utils.synthetic import seeded_state_dict
+    sd2 = seeded_state_dict(m2.state_dict(), 3)
+    m2.load_state_dict(sd2)
+    torch.save(m2.state_dict(), tmp_path / "ck.pth")
+    m3 = CaSPR(cnf_blocks=2, cnf_rk4_steps=4, latent_rk4_steps=4)
+    load_weights(m3, torch.load(tmp_path / "ck.pth"))
+    m3 = m3.to(dev).eval()
+    c, yy = rnd(51, 4, 1600), rnd(52, 4, 80, 3)
+    want = O.point_cnf(sd2, yy, c, None, True, "rk4", 4, blocks=2)
+    record("cnf_two_blocks", m3.point_cnf(yy.to(dev), c.to(dev), reverse=True), want, 1e-5)
+    assert m3.get_nfe()[1] == 2 * 16
+
+
 def test_full_size_properties(dev, model):
     """cars.cfg recon shape (T=10, N=2048) through size-independent properties (the oracle is too slow here)."""
     from caspr_amd import ops
