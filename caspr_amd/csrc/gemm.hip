@@ -73,9 +73,21 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     // fragments are re-read by all four waves, but from LDS.  (2 x 2 waves fetched every weight fragment twice.)
     const int wm = wave;
     const int g = lane >> 4, j = lane & 15;
-    const int b = blockIdx.z;
-    const int p0 = blockIdx.y * GEMM_NT;
-    const int co0 = blockIdx.x * GEMM_MT;
+    // XCD-aware work mapping.  The dispatcher places linear block L on XCD L % 8 (MI355X_MICROARCH.md); each XCD has
+    // a private 4 MiB L2.  Work items are renumbered so that XCD k owns a contiguous range of point tiles and walks
+    // all output-channel tiles of one point tile back to back: the activation tile (the big operand: 128 x Cin x 4 B)
+    // is fetched into ONE L2 and re-used by its Mt consumers there, instead of being fetched by up to 8 L2s.
+    // Placement only changes speed, never results.
+    const int Mt = gridDim.x, Pt = gridDim.y;
+    const int nblk = Mt * Pt * gridDim.z;
+    const int lin = blockIdx.x + Mt * (blockIdx.y + Pt * blockIdx.z);
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int wmt = work % Mt, wpt = (work / Mt) % Pt;
+    const int b = work / (Mt * Pt);
+    const int p0 = wpt * GEMM_NT;
+    const int co0 = wmt * GEMM_MT;
     const int KC = 2 * ((Cin + 31) / 32);
     const int MT16 = (Cout + 15) / 16;
     const int ntiles = KC / 2;
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         mvalid[mi] = (mt0 + mi) < MT16;
         wsoff[mi] = (mvalid[mi] ? mt0 + mi : 0) * KC * 1024;
     }
-    const int rot = blockIdx.y % ntiles;
+    const int rot = wpt % ntiles;
 
     f32x4 acc[2][8];
 #pragma unroll
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         const int buf = it & 1;
         const bool more = it + 1 < ntiles;
         const int kt = tile_of(it), ktn = tile_of(more ? it + 1 : it);
-#define GEMM_STAMP(i) if (trace && blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == 0 && tid == 0 && it >= 8 && it < 12) trace[(it - 8) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#define GEMM_STAMP(i) if (trace && wmt == 3 && wpt == 5 && b == 0 && tid == 0 && it >= 8 && it < 12) trace[(it - 8) * 8 + (i)] = __builtin_amdgcn_s_memtime();
         GEMM_STAMP(0)
         if (more) load_stage(ktn);             // next tile's global loads stay in flight during this tile's MFMAs
         load_b(b0, buf, 0);
