@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict
 __global__ void gn_finalize_kernel(const double *__restrict__ psum, const float *__restrict__ pmm, int B, int P, int C,
                                    int G, int S, const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float eps, float *__restrict__ scale, float *__restrict__ shift,
-                                   float *__restrict__ pmax)
+                                   float *__restrict__ pmax, float *__restrict__ mean_out, float *__restrict__ rstd_out)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * C) return;
@@ -590,6 +590,10 @@ __global__ void gn_finalize_kernel(const double *__restrict__ psum, const float 
     const float sf = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
     scale[t] = sc;
     shift[t] = sf;
+    if (mean_out && c % cpg == 0) {   // training tier: the moments themselves, one per (b, group)
+        mean_out[b * G + g] = (float)mean;
+        rstd_out[b * G + g] = (float)rstd;
+    }
     if (pmax) {
         float m1 = -INFINITY, m0 = INFINITY;
         for (int s = 0; s < S; ++s) {
@@ -601,9 +605,9 @@ __global__ void gn_finalize_kernel(const double *__restrict__ psum, const float 
     }
 }
 
-extern "C" int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, int G, const float *gamma,
-                                  const float *beta, float eps, float *scale, float *shift, float *pmax, void *ws,
-                                  long ws_bytes, void *stream)
+static int gn_stats_impl(const float *Y, int ldy, int B, int P, int C, int G, const float *gamma, const float *beta,
+                         float eps, float *scale, float *shift, float *pmax, float *mean, float *rstd, void *ws,
+                         long ws_bytes, void *stream)
 {
     CASPR_REQUIRE(Y && gamma && beta && scale && shift && ws && B > 0 && P > 0 && C > 0 && G > 0, "gn_stats: bad arguments");
     CASPR_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && (C / G) <= 256, "gn_stats: C/G=%d must be a multiple of 4 and <= 256", C / G);
@@ -616,7 +620,23 @@ extern "C" int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, 
     hipStream_t st = (hipStream_t)stream;
     gn_partial_kernel<<<dim3(G, S, B), dim3(256), 0, st>>>(Y, ldy, P, C, G, psum, pmm);
     gn_finalize_kernel<<<dim3(ceil_div(B * C, 256)), dim3(256), 0, st>>>(psum, pmm, B, P, C, G, S, gamma, beta, eps, scale,
-                                                                         shift, pmax);
+                                                                         shift, pmax, mean, rstd);
     CASPR_CHECK_LAUNCH("gn_stats");
     return CASPR_OK;
+}
+
+extern "C" int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, int G, const float *gamma,
+                                  const float *beta, float eps, float *scale, float *shift, float *pmax, void *ws,
+                                  long ws_bytes, void *stream)
+{
+    return gn_stats_impl(Y, ldy, B, P, C, G, gamma, beta, eps, scale, shift, pmax, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+// training tier: same statistics, and the per-(batch, group) mean / rstd the backward pass needs
+extern "C" int caspr_gn_stats_train_f32(const float *Y, int ldy, int B, int P, int C, int G, const float *gamma,
+                                        const float *beta, float eps, float *scale, float *shift, float *pmax,
+                                        float *mean, float *rstd, void *ws, long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(mean && rstd, "gn_stats_train: mean / rstd outputs are required");
+    return gn_stats_impl(Y, ldy, B, P, C, G, gamma, beta, eps, scale, shift, pmax, mean, rstd, ws, ws_bytes, stream);
 }

@@ -1,4 +1,4 @@
-"""ctypes binding of libcaspr_hip.so (include/caspr_hip.h).
+"""ctypes binding of libcaspr_hip.so (include/caspr_hip.h, include/caspr_hip_train.h).
 
 The library is built in-tree by caspr_amd/csrc/build.py (hipcc --offload-arch=gfx950).  There is no
 CPU fallback: if the shared object is missing or a call fails, an exception is raised.
@@ -41,6 +41,15 @@ SIGNATURES = {
     "caspr_cnf_rk4_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_float, c_int, c_int,
                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_stream]),
     "caspr_chamfer_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_stream]),
+    # ---- include/caspr_hip_train.h (training tier) ----
+    "caspr_gn_stats_train_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                         ctypes.c_void_p, c_long, c_stream]),
+    "caspr_wgrad_ws_bytes": (c_long, [c_long, c_int, c_int]),
+    "caspr_conv1x1_wgrad_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_int,
+                                        ctypes.c_void_p, c_long, c_stream]),
+    "caspr_gn_bwd_ws_bytes": (c_long, [c_long, c_int, c_int, c_int]),
+    "caspr_gn_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_long, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int,
+                                 ctypes.c_void_p, c_long, c_stream]),
 }
 
 _lib = None

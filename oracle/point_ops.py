@@ -52,12 +52,18 @@ def furthest_point_sampling(xyz, M, guard=True):
     return idx
 
 
+def _torch_path(*ts):
+    """Differentiable / f64 route: plain torch indexing instead of the C library (same values; the C calls detach).
+    Taken when any operand is float64 (conditioning studies) or takes part in autograd (gradient fixtures)."""
+    return any(t is not None and (t.dtype == torch.float64 or (torch.is_grad_enabled() and t.requires_grad)) for t in ts)
+
+
 def _bidx(idx):
     return torch.arange(idx.shape[0]).view(-1, *([1] * (idx.dim() - 1))).expand_as(idx)
 
 
 def fps_gather_by_index(feat, idx):
-    if feat.dtype == torch.float64:   # f64 "truth" mode (conditioning studies): same indices, exact gather
+    if _torch_path(feat):
         return torch.gather(feat, 2, idx.long().unsqueeze(1).expand(-1, feat.shape[1], -1))
     feat = feat.detach().float().contiguous()
     idx = idx.contiguous()
@@ -80,7 +86,7 @@ def ball_query(radius, ns, xyz, new_xyz):
 
 def group(xyz, new_xyz, feat, idx):
     """-> (B, M, 3+C, ns): centred xyz rows first, then feature rows."""
-    if xyz.dtype == torch.float64:
+    if _torch_path(xyz, feat):
         li = idx.long()
         g = xyz[_bidx(li), li] - new_xyz.unsqueeze(2)                      # (B,M,ns,3)
         g = g.permute(0, 1, 3, 2)
@@ -118,7 +124,7 @@ def three_nn_f64(unknown, known, idx):
 
 
 def three_interpolate(feat, idx, weight):
-    if feat.dtype == torch.float64:
+    if _torch_path(feat, weight):
         li = idx.long()
         f = feat.transpose(1, 2)[_bidx(li), li]                            # (B,n,3,C)
         return (f * weight.unsqueeze(-1)).sum(dim=2).transpose(1, 2).contiguous()

@@ -20,13 +20,13 @@ def test_library_exports_every_declared_symbol():
         sys.path.insert(0, ROOT)
         import __graft_entry__ as g
         g.build()
-    hdr = open(os.path.join(ROOT, "include", "caspr_hip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("caspr_hip.h", "caspr_hip_train.h"))
     declared = sorted(set(re.findall(r"\b(caspr_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 18
     so = ctypes.CDLL(lib.SO_PATH)
     for name in declared:
         assert hasattr(so, name), "libcaspr_hip.so does not export %s" % name
-    assert sorted(lib.SIGNATURES) == declared, "caspr_amd/lib.py and include/caspr_hip.h disagree"
+    assert sorted(lib.SIGNATURES) == declared, "caspr_amd/lib.py and include/*.h disagree"
     L = lib.load()
     assert L.caspr_abi_version() == 1
     assert L.caspr_packed_size(1600, 1600) == 100 * 100 * 256
