@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
                                                              const float *__restrict__ dA, int ldd, int P, int C, int G,
                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                             int relu, double *__restrict__ part)
+                                                             int relu, const float *__restrict__ dMax,
+                                                             const int32_t *__restrict__ aMax, double *__restrict__ part)
 {
     __shared__ double s_g[256 * 4], s_gx[256 * 4];
     const int grp = blockIdx.x, s = blockIdx.y, S = gridDim.y;
@@ -209,12 +210,21 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
     const int c0 = grp * cpg + tq * 4;
     if (tp < TP) {
         const f32x4 ga = ld4(gamma + c0), be = ld4(beta + c0);
+        f32x4 dm = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int am[4] = {-1, -1, -1, -1};
+        if (dMax) {
+            dm = ld4(dMax + b * C + c0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) am[q] = aMax[b * C + c0 + q];
+        }
         for (int p = pbeg + tp; p < pend; p += TP) {
-            const f32x4 y = ld4(Y + (b * P + p) * ldy + c0), d = ld4(dA + (b * P + p) * ldd + c0);
+            const f32x4 y = ld4(Y + (b * P + p) * ldy + c0);
+            const f32x4 d = dA ? ld4(dA + (b * P + p) * ldd + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float xh = (y[q] - mu) * rs;
-                const float gq = (relu && !(ga[q] * xh + be[q] > 0.f)) ? 0.f : d[q];
+                float gq = (relu && !(ga[q] * xh + be[q] > 0.f)) ? 0.f : d[q];
+                if (p == am[q]) gq += dm[q];   // the max over points is taken before the ReLU (tpointnet2.py:100,111)
                 sg[q] += (double)gq;
                 sgx[q] += (double)gq * (double)xh;
             }
@@ -280,9 +290,10 @@ __global__ void gn_bwd_param_kernel(const double *__restrict__ chan, int B, int 
     dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)bx;
 }
 
-__global__ void gn_bwd_apply_kernel(const float *__restrict__ Y, int ldy, float *__restrict__ dA, int ldd, int P, int C,
-                                    int G, const float *__restrict__ mean, const float *__restrict__ rstd,
+__global__ void gn_bwd_apply_kernel(const float *__restrict__ Y, int ldy, const float *dA, int ldd, float *dY, int lddy,
+                                    int P, int C, int G, const float *__restrict__ mean, const float *__restrict__ rstd,
                                     const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                                    const float *__restrict__ dMax, const int32_t *__restrict__ aMax,
                                     const float *__restrict__ s12, long total4)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,18 +304,20 @@ __global__ void gn_bwd_apply_kernel(const float *__restrict__ Y, int ldy, float 
     const long b = row / P;
     const int cpg = C / G;
     const f32x4 y = ld4(Y + row * ldy + c0);
-    f32x4 d = ld4(dA + row * ldd + c0);
+    f32x4 d = dA ? ld4(dA + row * ldd + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 ga = ld4(gamma + c0), be = ld4(beta + c0);
+    const int p = (int)(row - b * P);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int grp = (c0 + q) / cpg;
         const float mu = mean[b * G + grp], rs = rstd[b * G + grp];
         const float xh = (y[q] - mu) * rs;
-        const float gq = (relu && !(ga[q] * xh + be[q] > 0.f)) ? 0.f : d[q];
+        float gq = (relu && !(ga[q] * xh + be[q] > 0.f)) ? 0.f : d[q];
+        if (dMax && p == aMax[b * C + c0 + q]) gq += dMax[b * C + c0 + q];
         const float inv_n = 1.0f / ((float)cpg * (float)P);
         d[q] = rs * (gq * ga[q] - (s12[(b * G + grp) * 2 + 0] + xh * s12[(b * G + grp) * 2 + 1]) * inv_n);
     }
-    st4(dA + row * ldd + c0, d);
+    st4(dY + row * lddy + c0, d);
 }
 
 extern "C" long caspr_gn_bwd_ws_bytes(long B, int P, int C, int G)
@@ -313,12 +326,15 @@ extern "C" long caspr_gn_bwd_ws_bytes(long B, int P, int C, int G)
     return B * C * S * 16 + B * C * 16 + B * G * 8 + 256;
 }
 
-extern "C" int caspr_gn_bwd_f32(const float *Y, int ldy, float *dA, int ldd, long B, int P, int C, int G,
-                                const float *mean, const float *rstd, const float *gamma, const float *beta, int relu,
-                                float *dgamma, float *dbeta, int accumulate, void *ws, long ws_bytes, void *stream)
+extern "C" int caspr_gn_bwd_f32(const float *Y, int ldy, const float *dA, int ldd, const float *dMax, const int32_t *aMax,
+                                float *dY, int lddy, long B, int P, int C, int G, const float *mean, const float *rstd,
+                                const float *gamma, const float *beta, int relu, float *dgamma, float *dbeta, int accumulate,
+                                void *ws, long ws_bytes, void *stream)
 {
-    CASPR_REQUIRE(Y && dA && mean && rstd && gamma && beta && dgamma && dbeta && ws, "gn_bwd: null pointer");
-    CASPR_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && (C / G) <= 256 && ldy % 4 == 0 && ldd % 4 == 0 && ldy >= C && ldd >= C,
+    CASPR_REQUIRE((dA || dMax) && (dMax == nullptr) == (aMax == nullptr), "gn_bwd: give dA and/or dMax + aMax");
+    CASPR_REQUIRE(lddy % 4 == 0 && lddy >= C, "gn_bwd: lddy=%d must be a multiple of 4 and >= C", lddy);
+    CASPR_REQUIRE(Y && dY && mean && rstd && gamma && beta && dgamma && dbeta && ws, "gn_bwd: null pointer");
+    CASPR_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && (C / G) <= 256 && ldy % 4 == 0 && ldd % 4 == 0 && ldy >= C && (!dA || ldd >= C),
                   "gn_bwd: C/G=%d must be a multiple of 4 (<= 256) and strides multiples of 4", C / G);
     CASPR_REQUIRE(ws_bytes >= caspr_gn_bwd_ws_bytes(B, P, C, G), "gn_bwd: workspace too small");
     CASPR_REQUIRE(B <= 65535, "gn_bwd: B=%ld > 65535 (split the call)", B);
@@ -327,11 +343,11 @@ extern "C" int caspr_gn_bwd_f32(const float *Y, int ldy, float *dA, int ldd, lon
     double *chan = part + B * C * S * 2;
     float *s12 = (float *)(chan + B * C * 2);
     hipStream_t st = (hipStream_t)stream;
-    gn_bwd_partial_kernel<<<dim3(G, S, (unsigned)B), dim3(256), 0, st>>>(Y, ldy, dA, ldd, P, C, G, mean, rstd, gamma, beta, relu, part);
+    gn_bwd_partial_kernel<<<dim3(G, S, (unsigned)B), dim3(256), 0, st>>>(Y, ldy, dA, ldd, P, C, G, mean, rstd, gamma, beta, relu, dMax, aMax, part);
     gn_bwd_finalize_kernel<<<dim3((unsigned)((B * G + 255) / 256)), dim3(256), 0, st>>>(part, (int)B, C, G, S, gamma, chan, s12, dgamma, dbeta, accumulate);
     gn_bwd_param_kernel<<<dim3(ceil_div(C, 256)), dim3(256), 0, st>>>(chan, (int)B, C, dgamma, dbeta, accumulate);
     const long total4 = B * P * (C / 4);
-    gn_bwd_apply_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st>>>(Y, ldy, dA, ldd, P, C, G, mean, rstd, gamma, beta, relu, s12, total4);
+    gn_bwd_apply_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st>>>(Y, ldy, dA, ldd, dY, lddy, P, C, G, mean, rstd, gamma, beta, relu, dMax, aMax, s12, total4);
     CASPR_CHECK_LAUNCH("gn_bwd");
     return CASPR_OK;
 }

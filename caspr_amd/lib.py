@@ -48,8 +48,19 @@ SIGNATURES = {
     "caspr_conv1x1_wgrad_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_int,
                                         ctypes.c_void_p, c_long, c_stream]),
     "caspr_gn_bwd_ws_bytes": (c_long, [c_long, c_int, c_int, c_int]),
-    "caspr_gn_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_long, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int,
-                                 ctypes.c_void_p, c_long, c_stream]),
+    "caspr_gn_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_ip, c_fp, c_int, c_long, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp,
+                                 c_int, c_fp, c_fp, c_int, ctypes.c_void_p, c_long, c_stream]),
+    "caspr_argmax_ws_bytes": (c_long, [c_long, c_int, c_int]),
+    "caspr_argmax_points_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_ip, ctypes.c_void_p, c_long, c_stream]),
+    "caspr_colsum_batched_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_stream]),
+    "caspr_three_interp_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
+    "caspr_group_rows_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
+    "caspr_group_rows_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
+    "caspr_gn_rows_f32": (c_int, [c_fp, c_int, c_long, c_int, c_int, c_fp, c_fp, c_float, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_ip,
+                                  c_stream]),
+    "caspr_gn_rows_bwd_ws_bytes": (c_long, [c_int]),
+    "caspr_gn_rows_bwd_f32": (c_int, [c_fp, c_int, c_long, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_ip,
+                                      c_fp, c_int, c_fp, c_fp, c_int, ctypes.c_void_p, c_long, c_stream]),
 }
 
 _lib = None

@@ -5,7 +5,9 @@
  * caspr_losses.py:31-70.  Each entry below names the forward call site whose autograd node it
  * replaces.  Same conventions as caspr_hip.h: device pointers, f32, point-major rows, the
  * caller's stream, int return code (0 = ok, text from caspr_last_error_string()).
- * All reductions combine partial sums in a fixed order: gradients are reproducible run to run.  */
+ * Dense reductions (weight / GroupNorm parameter gradients) combine partial sums in a fixed order and
+ * are reproducible run to run; the two scatter-adds (three_interp / group backward) use float atomics,
+ * as Kaolin's CUDA kernels do.                                                                      */
 #ifndef CASPR_HIP_TRAIN_H
 #define CASPR_HIP_TRAIN_H
 #include "caspr_hip.h"
@@ -33,14 +35,56 @@ int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X, int ldx, 
                             int Cout, float *dW, float *dbias, int accumulate, void *ws, long ws_bytes,
                             void *stream);
 
-/* GroupNorm(+ReLU) backward.  Y = raw conv output (B,P,ldy), dA (B,P,ldd) = gradient w.r.t. the
- * normalised (and, if relu, rectified) activation; on return dA holds the gradient w.r.t. Y.
+/* GroupNorm(+ReLU) backward.  Y = raw conv output (B,P,ldy); dA (B,P,ldd) = gradient w.r.t. the
+ * normalised (and, if relu, rectified) activation, or NULL for zero; dMax (B,C) + aMax (B,C) = gradient
+ * of the max over points of the normalised, NOT rectified feature and its arg-max point (torch.max at
+ * tpointnet2.py:111 / pointnet.py:42), or NULL.  dY (B,P,lddy) = gradient w.r.t. Y (may alias dA).
  * dgamma / dbeta (C) (+)= parameter gradients.  ws >= caspr_gn_bwd_ws_bytes(B,P,C,G).              */
 long caspr_gn_bwd_ws_bytes(long B, int P, int C, int G);
-int caspr_gn_bwd_f32(const float *Y, int ldy, float *dA, int ldd, long B, int P, int C, int G,
+int caspr_gn_bwd_f32(const float *Y, int ldy, const float *dA, int ldd, const float *dMax,
+                     const int32_t *aMax, float *dY, int lddy, long B, int P, int C, int G,
                      const float *mean, const float *rstd, const float *gamma, const float *beta,
                      int relu, float *dgamma, float *dbeta, int accumulate, void *ws, long ws_bytes,
                      void *stream);
+
+/* arg-max over points of y*scale+shift, first index on ties (the index torch.max keeps for backward). */
+long caspr_argmax_ws_bytes(long B, int P, int C);
+int caspr_argmax_points_f32(const float *Y, int ldy, int B, int P, int C, const float *scale,
+                            const float *shift, int32_t *out, void *ws, long ws_bytes, void *stream);
+
+/* out[b,c] = sum_p A[b,p,c]: gradient of the per-sequence bias that carries the tiled global feature
+ * through the head's first conv (tpointnet2.py:96-99, pointnet.py:44-46).                           */
+int caspr_colsum_batched_f32(const float *A, int ld, int B, int P, int C, float *out, void *stream);
+
+/* three_interpolate backward (Kaolin three_interpolate grad, call site pointnet2.py:519):
+ * dFeat[b, idx[b,i,k], c] += weight[b,i,k] * dOut[b,i,c], c < C.  dFeat must be initialised by the
+ * caller (float atomics: the summation order, hence the last bit, can vary run to run).             */
+int caspr_three_interp_bwd_f32(const float *dOut, int ldo, const int32_t *idx, const float *weight,
+                               int B, int m, int n, int C, float *dFeat, int ldf, void *stream);
+
+/* Training layout of the grouper (Kaolin PointNet2GroupingLayer, call site pointnet2.py:391): one row
+ * per (b, centre j, sample s): G[(b*M+j)*ns+s] = [xyz[b,i]-new_xyz[b,j] | feat[b,i,0:C] | 0 pad],
+ * i = idx[b,j,s]; channel order = the reference's (xyz first).  Backward scatters the feature columns
+ * back: dFeat[b,i,c] += dG[row,3+c] (float atomics).                                                */
+int caspr_group_rows_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                         const int32_t *idx, int B, int n, int M, int C, int ns, float *G, int ldg,
+                         void *stream);
+int caspr_group_rows_bwd_f32(const float *dG, int ldg, const int32_t *idx, int B, int n, int M, int C,
+                             int ns, float *dFeat, int ldf, void *stream);
+
+/* GroupNorm(16) over one neighbourhood (ns rows) at a time (PointNetFeatureExtractor, pointnet2.py:
+ * 649-703).  Y (NB*ns, ldy).  Forward writes mean/rstd (NB,16) and either the dense activation
+ * A = relu?(gn(Y)) or, for the last layer, maxout (NB, ldm) = max over the ns rows and arg (NB,C) =
+ * first row attaining it (torch.max at pointnet2.py:701).  Backward takes dA (dense) or dMax + arg.  */
+int caspr_gn_rows_f32(const float *Y, int ldy, long NB, int ns, int C, const float *gamma,
+                      const float *beta, float eps, int relu, float *A, int lda, float *mean,
+                      float *rstd, float *maxout, int ldm, int32_t *arg, void *stream);
+long caspr_gn_rows_bwd_ws_bytes(int C);
+int caspr_gn_rows_bwd_f32(const float *Y, int ldy, long NB, int ns, int C, const float *gamma,
+                          const float *beta, int relu, const float *mean, const float *rstd,
+                          const float *dA, int lda, const float *dMax, int ldm, const int32_t *arg,
+                          float *dY, int lddy, float *dgamma, float *dbeta, int accumulate, void *ws,
+                          long ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -21,11 +21,13 @@ def rnd(seed, *shape, scale=1.0):
     return torch.from_numpy((np.random.default_rng(seed).normal(0, 1, shape) * scale).astype(np.float32))
 
 
-def rel(name, got, want, rtol):
+def rel(name, got, want, rtol, ref=None):
+    """max |got - want| <= rtol * ref, ref = largest reference entry (or a given scale, for gradients that are
+    mathematically zero such as a conv bias in front of a one-channel-per-group GroupNorm)."""
     got = got.detach().cpu().double().numpy()
     want = want.detach().cpu().double().numpy()
     assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
-    ref = float(np.abs(want).max()) or 1.0
+    ref = float(ref) if ref is not None else (float(np.abs(want).max()) or 1.0)
     err = float(np.abs(got - want).max()) / ref
     REPORT[name] = {"max_rel_err": err, "rtol": rtol, "ref_absmax": ref}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -88,3 +90,138 @@ def test_conv_gn_relu_block_backward(B, P, Cin, C1, C2):
     dW2c = torch.empty_like(W2d)
     T.conv1x1_wgrad(dy2, y1d, C1, C2, dW2c, None, in_scale=sc, in_shift=sh, in_relu=True)
     assert torch.equal(dW2c, dW2)
+
+
+@pytest.mark.parametrize("B,n,M,ns,C,dims", [(2, 256, 64, 16, 6, (16, 16, 32)), (2, 128, 32, 32, 96, (64, 96, 128)), (1, 64, 16, 32, 512, (256, 256, 512))])
+def test_set_abstraction_scale_backward(B, n, M, ns, C, dims):
+    """group -> 3 x (conv -> per-neighbourhood GroupNorm(16) [-> ReLU]) -> max over samples  (pointnet2.py:391-409,649-703):
+    forward output, all parameter gradients and the gradient w.r.t. the input features."""
+    from caspr_amd import ops, train_ops as T
+    dev = "cuda:0"
+    g = np.random.default_rng(5)
+    xyz = torch.from_numpy(g.uniform(0, 1, (B, n, 3)).astype(np.float32))
+    feat = rnd(11, B, n, C)
+    idx = torch.from_numpy(g.integers(0, n, (B, M, ns)).astype(np.int32))
+    ctr = xyz[:, :M].contiguous()
+    R = rnd(12, B, M, dims[2])
+    cin = [3 + C, dims[0], dims[1]]
+    Ws = [rnd(20 + l, dims[l], cin[l], scale=0.4 / np.sqrt(cin[l]) * 3) for l in range(3)]
+    bs = [rnd(30 + l, dims[l], scale=0.1) for l in range(3)]
+    gs = [1 + rnd(40 + l, dims[l], scale=0.2) for l in range(3)]
+    bes = [rnd(50 + l, dims[l], scale=0.2) for l in range(3)]
+    # reference (f64 autograd)
+    f6 = feat.double().requires_grad_(True)
+    P6 = [[t.double().requires_grad_(True) for t in grp] for grp in (Ws, bs, gs, bes)]
+    li = idx.long()
+    bi = torch.arange(B).view(B, 1, 1)
+    grouped = torch.cat([xyz.double()[bi, li] - ctr.double().unsqueeze(2), f6[bi, li]], dim=3)      # (B,M,ns,3+C)
+    h = grouped.reshape(B * M, ns, 3 + C)
+    for l in range(3):
+        h = h @ P6[0][l].t() + P6[1][l]
+        h = F.group_norm(h.transpose(1, 2), 16, P6[2][l], P6[3][l], 1e-5).transpose(1, 2)
+        if l < 2:
+            h = F.relu(h)
+    out6 = h.max(dim=1)[0].view(B, M, dims[2])
+    (out6 * R.double()).sum().backward()
+    # HIP
+    ldf = (C + 3) // 4 * 4
+    featd = F.pad(feat, (0, ldf - C)).to(dev)
+    xyzd, ctrd, idxd = xyz.to(dev), ctr.to(dev), idx.to(dev)
+    Wd, bd, gd, bed = ([t.to(dev) for t in grp] for grp in (Ws, bs, gs, bes))
+    G = T.group_rows(xyzd, ctrd, featd, C, idxd)
+    tape, cur = [], G
+    out = torch.empty(B, M, dims[2], device=dev)
+    for l in range(3):
+        y = ops.conv1x1(ops.PackedWeight(Wd[l]), bd[l], cur)
+        A, mean, rstd, arg = T.gn_rows(y, ns, dims[l], gd[l], bed[l], relu=l < 2, maxout=out if l == 2 else None)
+        tape.append((cur, y, mean, rstd, arg))
+        cur = A
+    tag = "[%d,%d,%s]" % (C, ns, "-".join(map(str, dims)))
+    rel("sa_fwd" + tag, out, out6, 2e-5)
+    dout = R.to(dev).contiguous()
+    d = None
+    for l in (2, 1, 0):
+        xin, y, mean, rstd, arg = tape[l]
+        dg, dbe = torch.empty_like(gd[l]), torch.empty_like(bed[l])
+        if l == 2:
+            dy = T.gn_rows_bwd(y, ns, dims[l], gd[l], bed[l], False, mean, rstd, dg, dbe, dmax=dout, arg=arg)
+        else:
+            dy = T.gn_rows_bwd(y, ns, dims[l], gd[l], bed[l], True, mean, rstd, dg, dbe, da=d)
+        dW, db = torch.empty_like(Wd[l]), torch.empty_like(bd[l])
+        T.conv1x1_wgrad(dy, xin, cin[l], dims[l], dW, db)
+        d = ops.conv1x1(ops.PackedWeight(Wd[l].t().contiguous()), None, dy)
+        rel("sa_dW%d" % l + tag, dW, P6[0][l].grad, 1e-4)
+        rel("sa_db%d" % l + tag, db, P6[1][l].grad, 1e-4, ref=float(P6[0][l].grad.abs().max()))
+        rel("sa_dgamma%d" % l + tag, dg, P6[2][l].grad, 1e-4)
+        rel("sa_dbeta%d" % l + tag, dbe, P6[3][l].grad, 1e-4)
+    dfeat = torch.zeros(B, n, ldf, device=dev)
+    T.group_rows_bwd(d, idxd, C, dfeat)
+    rel("sa_dfeat" + tag, dfeat[:, :, :C], f6.grad, 1e-4)
+
+
+def test_three_interp_backward():
+    from caspr_amd import ops, train_ops as T
+    dev = "cuda:0"
+    B, m, n, C = 3, 64, 256, 96
+    g = np.random.default_rng(6)
+    known, unknown = rnd(1, B, m, 3), rnd(2, B, n, 3)
+    feat, R = rnd(3, B, m, C), rnd(4, B, n, C)
+    _, idx, w = ops.three_nn(unknown.to(dev), known.to(dev), with_weights=True)
+    f6 = feat.double().requires_grad_(True)
+    bi = torch.arange(B).view(B, 1, 1)
+    interp = (f6[bi, idx.cpu().long()] * w.cpu().double().unsqueeze(3)).sum(2)
+    (interp * R.double()).sum().backward()
+    dfeat = torch.zeros(B, m, C, device=dev)
+    T.three_interp_bwd(R.to(dev), idx, w, C, dfeat)
+    rel("three_interp_bwd", dfeat, f6.grad, 1e-5)
+
+
+def test_head_max_backward():
+    """z = max_p GN(conv(x)) (no ReLU, tpointnet2.py:100,111) and t = conv2(relu(GN(conv(x)))): both consumers of one GroupNorm."""
+    from caspr_amd import ops, train_ops as T
+    dev = "cuda:0"
+    B, P, Cin, C1, C2 = 3, 2500, 32, 64, 4
+    x, Rz, Rt = rnd(1, B, P, Cin), rnd(2, B, C1), rnd(3, B, P, C2)
+    W1, b1, g1, be1 = rnd(4, C1, Cin, scale=0.3), rnd(5, C1, scale=0.1), 1 + rnd(6, C1, scale=0.3), rnd(7, C1, scale=0.2)
+    g1[::5] *= -1   # negative gamma: the max of the normalised feature is the min of the raw one
+    W2, b2 = rnd(8, C2, C1, scale=0.2), rnd(9, C2, scale=0.1)
+    p6 = [t.double().requires_grad_(True) for t in (x, W1, b1, g1, be1, W2, b2)]
+    x6, W16, b16, g16, be16, W26, b26 = p6
+    nrm = F.group_norm((x6 @ W16.t() + b16).transpose(1, 2), 16, g16, be16, 1e-5)      # (B,C1,P)
+    z6 = nrm.max(dim=2)[0]
+    t6 = torch.sigmoid(F.relu(nrm).transpose(1, 2) @ W26.t() + b26)
+    ((z6 * Rz.double()).sum() + (t6 * Rt.double()).sum()).backward()
+    xd = x.to(dev)
+    W1d, b1d, g1d, be1d, W2d, b2d = (t.to(dev) for t in (W1, b1, g1, be1, W2, b2))
+    y1 = ops.conv1x1(ops.PackedWeight(W1d), b1d, xd)
+    sc, sh, mean, rstd, z = T.gn_stats_train(y1, C1, g1d, be1d, want_max=True)
+    t = ops.conv1x1(ops.PackedWeight(W2d), b2d, y1, in_scale=sc, in_shift=sh, in_relu=True, act=1)
+    rel("head_z", z, z6, 2e-5)
+    rel("head_t", t[:, :, :C2], t6, 2e-5)
+    amax = T.argmax_points(y1, C1, sc, sh)
+    assert torch.equal(amax.cpu().long(), nrm.max(dim=2)[1])
+    dt = Rt.to(dev) * t[:, :, :C2] * (1 - t[:, :, :C2])
+    dt = dt.contiguous()
+    dW2, db2 = torch.empty_like(W2d), torch.empty_like(b2d)
+    T.conv1x1_wgrad(dt, y1, C1, C2, dW2, db2, in_scale=sc, in_shift=sh, in_relu=True)
+    da = ops.conv1x1(ops.PackedWeight(W2d.t().contiguous()), None, dt)
+    dg, dbe = torch.empty_like(g1d), torch.empty_like(be1d)
+    T.gn_bwd(y1, da, C1, mean, rstd, g1d, be1d, dg, dbe, relu=True, dmax=Rz.to(dev), amax=amax)
+    dW1, db1 = torch.empty_like(W1d), torch.empty_like(b1d)
+    T.conv1x1_wgrad(da, xd, Cin, C1, dW1, db1)
+    rel("head_dW2", dW2, W26.grad, 2e-5)
+    rel("head_dgamma", dg, g16.grad, 5e-5)
+    rel("head_dbeta", dbe, be16.grad, 5e-5)
+    rel("head_dW1", dW1, W16.grad, 5e-5)
+    rel("head_db1", db1, b16.grad, 5e-4)
+    cs = T.colsum_batched(da, C1)
+    rel("colsum_batched", cs, da.sum(1), 1e-5)
+    # max-only consumer (global PointNet, pointnet.py:41-42): dA = None
+    p6b = [t.double().requires_grad_(True) for t in (x, W1, b1, g1, be1)]
+    nrm_b = F.group_norm((p6b[0] @ p6b[1].t() + p6b[2]).transpose(1, 2), 16, p6b[3], p6b[4], 1e-5)
+    (nrm_b.max(dim=2)[0] * Rz.double()).sum().backward()
+    dy = torch.empty(B, P, C1, device=dev)
+    T.gn_bwd(y1, None, C1, mean, rstd, g1d, be1d, dg, dbe, relu=False, dmax=Rz.to(dev), amax=amax, out=dy)
+    T.conv1x1_wgrad(dy, xd, Cin, C1, dW1, db1)
+    rel("maxonly_dW1", dW1, p6b[1].grad, 5e-5)
+    rel("maxonly_dgamma", dg, p6b[3].grad, 5e-5)
