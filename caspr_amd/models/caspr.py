@@ -5,8 +5,10 @@ state_dict keys, so train.py / test.py / viz.py-style cal
 checkpoints work unchanged.  Extra keyword-only knobs of this build: `cnf_rk4_steps`,
 `latent_rk4_steps` (fixed-step RK4 replaces torchdiffeq's adaptive dopri5).
 
-This round implements inference (`encode`, `reconstruct`, `decode`, and `forward` for NLL / T-NOCS loss
-VALUES); there is no backward pass yet, so `forward` runs under no_grad.
+Inference: `encode`, `reconstruct`, `decode`, and `forward` for NLL / T-NOCS loss values.
+Training: in train() mode with grad enabled the encoder is differentiable (caspr_amd/train/encoder_grad.py: a taped
+forward and a backward on the HIP gradient kernels), which covers `pretrain_tnocs=True` end to end; the latent-ODE /
+CNF backward is not built yet, so the NLL term of `forward` is returned as a value without grad_fn.
 """
 import numpy as np
 import torch
@@ -46,7 +48,11 @@ class CaSPR(nn.Module):
     # ------------------------------------------------------------------------------------------
     def forward(self, x, sample_points, aggregate_points=None, e=None):
         """caspr.py:76-122.  x, sample_points (B,T,N,4) -> (recon_loss (B,T,N), tnocs_loss (B,T,N,4)).
-        `e` (B*T,N,3) optionally fixes the Hutchinson noise (odefunc.py:115-117); loss VALUES only."""
+        `e` (B*T,N,3) optionally fixes the Hutchinson noise (odefunc.py:115-117)."""
+        if self.pretrain_tnocs and self.training and torch.is_grad_enabled():
+            _, tnocs_pred = self.encode(x)                                                      # differentiable (HIP backward)
+            return tuple([self.encoder.loss(tnocs_pred[:, :, :, :self.tnocs_point_size],
+                                            sample_points[:, :, :, :self.tnocs_point_size])])
         with torch.no_grad():
             z0, tnocs_pred = self.encode(x)
             B, H = z0.size()

@@ -92,6 +92,10 @@ class TPointNet2(nn.Module):
         """x (B,T,N,4) -> z0 (B, out_feat_size), tnocs (B,T,N,4) | None   (tpointnet2.py:70-115)."""
         if not x.is_cuda:
             raise ValueError("caspr_amd.TPointNet2 runs on the GPU only (HIP kernels); got a %s tensor" % x.device)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: one autograd node with a taped forward and a HIP backward (train/encoder_grad.py)
+            from ..train.encoder_grad import encode_with_grad
+            return encode_with_grad(self, x)
         B, T, N, _ = x.size()
         x = x.contiguous().float()
         L, S = self.local_feat_size, self.space_time_pt_feat

@@ -225,3 +225,87 @@ def test_head_max_backward():
     T.conv1x1_wgrad(dy, xd, Cin, C1, dW1, db1)
     rel("maxonly_dW1", dW1, p6b[1].grad, 5e-5)
     rel("maxonly_dgamma", dg, p6b[3].grad, 5e-5)
+
+
+def _f64_state(sd):
+    out = {}
+    for k, v in sd.items():
+        out[k] = v.double().requires_grad_(True) if v.is_floating_point() else v
+    return out
+
+
+@pytest.mark.parametrize("B,T,N", [(1, 2, 1024), (2, 2, 1024)])
+def test_encoder_backward_matches_oracle_autograd(B, T, N):
+    """Whole TPointNet++ encoder: loss = 100*mean|tnocs - gt| + <z0, R>  (the first term is the reference's T-NOCS
+    training loss, train_utils.py:160-165; the second exercises the z0 / max-pool branch).  Gradients of all 188
+    encoder parameters from the HIP backward vs f64 autograd through the CPU oracle on the same weights and input."""
+    from oracle import model as O
+    from caspr_amd.models import CaSPR
+    from caspr_amd.utils.synthetic import seeded_state_dict, dense_sequences
+    dev = "cuda:0"
+    m = CaSPR(pretrain_tnocs=True)
+    sd = {k: v for k, v in seeded_state_dict(CaSPR().state_dict(), seed=7).items() if k.startswith("encoder.")}
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    x, sp = dense_sequences(B, T, N)
+    R = rnd(3, B, 1600, scale=0.05)
+    # oracle, f64 and f32 autograd
+    def oracle_grads(dt):
+        s_ = {k: (v.detach().clone().to(dt).requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        z_, t_ = O.encode(s_, x.to(dt))
+        l_ = 100.0 * (t_ - sp.to(dt)).abs().mean() + (z_ * R.to(dt)).sum()
+        l_.backward()
+        return s_, l_.detach()
+    sd6, loss6 = oracle_grads(torch.float64)
+    sd3, _ = oracle_grads(torch.float32)
+    # HIP
+    z0, tn = m.encoder(x.to(dev))
+    assert z0.requires_grad and tn.requires_grad
+    loss = 100.0 * (tn - sp.to(dev)).abs().mean() + (z0 * R.to(dev)).sum()
+    loss.backward()
+    tag = "[%d,%d,%d]" % (B, T, N)
+    rel("enc_loss" + tag, loss.detach().reshape(1), loss6.reshape(1), 1e-5)
+    # The f32 gradient of this network is not a continuous function of rounding: every ReLU mask and max-pool selection
+    # within rounding of a tie flips (a 1e-7 fraction of a few million elements per layer = O(1) flips per layer, each
+    # worth ~1/sqrt(#elements) = 5e-4 of that layer's gradient in the L2 norm, then carried through the ~20 layers below
+    # it), and GroupNorm over 16-sample neighbourhoods puts 1/sigma into the backward pass twice.  f32 autograd on the CPU
+    # is itself 2e-4 (head) to 2e-2 (set abstraction) away from f64 autograd in the relative L2 norm, with the same
+    # layer-by-layer growth.  Criteria:
+    #   * exact where no selection is upstream: the loss value and conv3's gradient (first in the backward chain);
+    #   * wiring: per parameter the MEDIAN elementwise error stays below 1.5e-2 of the largest entry and the L2 error below
+    #     0.05 + 2x the f32 oracle's -- a mis-wired block (wrong operand, missing term, transposed index) is O(1) in both;
+    #   * accuracy class: the whole-gradient L2 error is within 5x of the f32 oracle's own error against f64.
+    e_gpu, e_ref, n, num_g, num_r, den, bad = [], [], 0, 0.0, 0.0, 0.0, []
+    for name, p in m.named_parameters():
+        want = sd6[name].grad
+        assert p.grad is not None, "no gradient for %s" % name
+        nrm = float(want.norm())
+        mx = float(want.abs().max())
+        if name.endswith(".bias"):   # a conv bias in front of a one-channel-per-group GroupNorm has a zero gradient
+            gw = sd6[name[:-4] + "weight"].grad
+            nrm = max(nrm, float(gw.norm()) / (np.sqrt(gw.shape[1]) if gw.dim() > 1 else 1.0))
+            mx = max(mx, float(gw.abs().max()))
+        nrm, mx = max(nrm, 1e-9), max(mx, 1e-9)
+        diff = p.grad.detach().cpu().double() - want
+        dg = float(diff.norm())
+        dr = float((sd3[name].grad.double() - want).norm())
+        med = float(diff.abs().median()) / mx
+        REPORT["enc_grad" + tag + ":" + name] = {"hip_vs_f64_l2": dg / nrm, "oracle32_vs_f64_l2": dr / nrm, "median_elem_err": med, "ref_l2": nrm}
+        e_gpu.append(dg / nrm)
+        e_ref.append(dr / nrm)
+        num_g += dg * dg
+        num_r += dr * dr
+        den += float(want.norm()) ** 2
+        n += 1
+        assert np.isfinite(dg)
+        if not (med <= 1.5e-2 and dg / nrm <= 0.05 + 2 * dr / nrm):
+            bad.append("%s: median elementwise err %.3e (of max), L2 err %.3e" % (name, med, dg / nrm))
+    rel("enc_flush" + tag, torch.zeros(1), torch.zeros(1), 1.0)   # writes the report file
+    assert not bad, "\n".join(bad)
+    assert n == 188
+    tot_g, tot_r = np.sqrt(num_g / den), np.sqrt(num_r / den)
+    REPORT["enc_grad_summary" + tag] = {"total_l2_hip": tot_g, "total_l2_oracle32": tot_r, "median_hip": float(np.median(e_gpu)),
+                                        "median_oracle32": float(np.median(e_ref)), "max_hip": float(np.max(e_gpu)),
+                                        "max_oracle32": float(np.max(e_ref))}
+    rel("enc_grad_conv3" + tag, m.encoder.conv3.weight.grad, sd6["encoder.conv3.weight"].grad, 1e-4)
+    assert tot_g <= 5 * tot_r + 1e-5, "whole-gradient L2 error %.3e vs the f32 oracle's %.3e" % (tot_g, tot_r)
