@@ -68,9 +68,10 @@ def install_shims():
         """Fixed-step RK4 standing in for torchdiffeq.odeint: returns the solution at every t."""
         is_tuple = isinstance(y0, tuple)
         ys = y0 if is_tuple else (y0,)
-        f = (lambda tt, s: func(torch.tensor(tt, dtype=torch.float32), s)) if is_tuple else \
-            (lambda tt, s: (func(torch.tensor(tt, dtype=torch.float32), s[0]),))
-        times = [float(v) for v in t]
+        as_t = lambda tt: tt.float() if torch.is_tensor(tt) else torch.tensor(tt, dtype=torch.float32)
+        f = (lambda tt, s: func(as_t(tt), s)) if is_tuple else (lambda tt, s: (func(as_t(tt), s[0]),))
+        # training (cnf.py:80-81,102-110): the end time is a learnable tensor -> keep it in the autograd graph
+        times = [t[k] for k in range(len(t))] if (torch.is_tensor(t) and t.requires_grad) else [float(v) for v in t]
         steps = CNF_STEPS if is_tuple else LATENT_STEPS
         sols = [ys]
         for k in range(1, len(times)):
@@ -233,6 +234,58 @@ def main():
         for key, val in fr.items():
             g["loader_in_%d_%s" % (k, key)] = val
     g["loader_nocs"], g["loader_depth"], g["loader_pose"] = ln, ld, lp
+
+    # ---- 5. one training step of the reference (run_one_epoch, train_utils.py:120-176) ------
+    # The reference model in train() mode on the shimmed (differentiable) ops; loss = 0.01*mean_{b,t}(sum_n nll) +
+    # 100*mean(tnocs L1) (train_utils.py:151-165 with the config defaults), Adam(lr 1e-4, betas 0.9/0.999, eps 1e-8).
+    # Captured: the loss, gradients and one-step parameter deltas of encoder.conv3.weight / point_cnf.chain.1.sqrt_end_time
+    # and a few more tensors along the backward chain.  A second capture trains the T-NOCS head alone (pretrain_tnocs).
+    import copy
+    from caspr_amd.utils.synthetic import dense_sequences
+    x, sp = dense_sequences(1, 2, 1024)
+    e_tr = rnd(29, 2, 1024, 3)
+    state0 = copy.deepcopy(ref.state_dict())
+    watch = ["encoder.conv3.weight", "encoder.conv3.bias", "encoder.conv2.bias", "encoder.bn2.weight", "encoder.global_extract.conv1.weight",
+             "encoder.local_extract.final_layers.3.weight", "point_cnf.chain.1.sqrt_end_time", "point_cnf.chain.0.weight",
+             "point_cnf.chain.1.odefunc.diffeq.layers.3._layer.weight", "latent_ode.ode_func.dynamics_net.net.0.weight"]
+
+    def train_step(model, full):
+        model.train()
+        params = dict(model.named_parameters())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        opt.zero_grad()
+        losses = model(x, sp)
+        loss = torch.zeros(1)
+        if full:
+            loss = loss + 0.01 * losses[0].sum(2).mean()
+        loss = loss + 100.0 * losses[-1][:, :, :, :4].mean()
+        loss.backward()
+        missing = [k for k in watch if k in params and params[k].grad is None]
+        assert not missing, "no gradient reached %s" % missing
+        before = {k: params[k].detach().clone() for k in watch if k in params}
+        grads = {k: params[k].grad.detach().clone() for k in before}
+        opt.step()
+        return float(loss), grads, {k: (params[k].detach() - before[k]) for k in before}, losses
+
+    odef.before_odeint = lambda e_=None: orig(e=e_tr)
+    loss_full, gr, dl, losses = train_step(ref, True)
+    g["train_x"], g["train_sp"], g["train_e"] = x.numpy(), sp.numpy(), e_tr.numpy()
+    g["train_full_loss"] = np.float64(loss_full)
+    g["train_full_nll"], g["train_full_tnocs_l1"] = losses[0].detach().numpy(), losses[1].detach().numpy()
+    for k in gr:
+        g["train_full_grad:" + k], g["train_full_delta:" + k] = gr[k].numpy(), dl[k].numpy()
+    g["train_full_mbn_running_mean"] = ref.state_dict()["point_cnf.chain.0.running_mean"].numpy()
+    g["train_full_mbn_running_var"] = ref.state_dict()["point_cnf.chain.0.running_var"].numpy()
+    odef.before_odeint = orig
+    ref.load_state_dict(state0)
+    ref.eval()
+    from models.caspr import CaSPR as RefCaSPR
+    pre = RefCaSPR(pretrain_tnocs=True)
+    pre.load_state_dict({k: v for k, v in state0.items() if k.startswith("encoder.")})
+    loss_pre, gr, dl, _ = train_step(pre, False)
+    g["train_pre_loss"] = np.float64(loss_pre)
+    for k in gr:
+        g["train_pre_grad:" + k], g["train_pre_delta:" + k] = gr[k].numpy(), dl[k].numpy()
 
     out_path = os.path.join(HERE, "reference_golden.npz")
     np.savez_compressed(out_path, **g)
