@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
             }
 }
 
-// out[i] (+)= sum_s part[s][i]  in slab order
+// out[i] (+)= sum_s part[s][i]  in a fixed order.  Few slabs: one thread per element walks them (coalesced over i).
+// Many slabs (small weights of the set-abstraction MLPs, up to 4096 slabs): 32 lanes per element each take every 32nd
+// slab, then a fixed xor-shuffle tree -- a single thread walking thousands of slabs was a 0.6 ms latency chain.
 __global__ void slab_reduce_kernel(const float *__restrict__ part, long n, int S, int accumulate, float *__restrict__ out)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,6 +123,27 @@ __global__ void slab_reduce_kernel(const float *__restrict__ part, long n, int S
     float s = accumulate ? out[i] : 0.f;
     for (int k = 0; k < S; ++k) s += part[(long)k * n + i];
     out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float *__restrict__ part, long n, int S, int accumulate,
+                                                               float *__restrict__ out)
+{
+    const int l32 = threadIdx.x & 31;
+    const long i = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    float s = 0.f;
+    if (i < n)
+        for (int k = l32; k < S; k += 32) s += part[(long)k * n + i];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 32);
+    if (i < n && l32 == 0) out[i] = (accumulate ? out[i] : 0.f) + s;
+}
+
+static void launch_slab_reduce(const float *part, long n, int S, int accumulate, float *out, hipStream_t st)
+{
+    if (S > 64)
+        slab_reduce_wide_kernel<<<dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st>>>(part, n, S, accumulate, out);
+    else
+        slab_reduce_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(part, n, S, accumulate, out);
 }
 
 // column sums of a (R, ld) matrix restricted to C columns, per slab
@@ -140,17 +163,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     if (sub == 0 && c < C) part[(long)slab * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-static int pick_slabs(long R, int want_blocks)
+// number of row slabs: enough workgroups (tiles x slabs ~ 2048) to fill 256 CUs even when the weight is one tile,
+// at least 512 rows per slab, at most 4096 slabs
+static int pick_slabs(long R, int Cin, int Cout)
 {
-    long s = (R + 4095) / 4096;
-    if (s > want_blocks) s = want_blocks;
+    const long tiles = (long)ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T);
+    long s = (2048 + tiles - 1) / tiles;
+    const long by_rows = (R + 511) / 512;
+    if (s > by_rows) s = by_rows;
+    if (s > 4096) s = 4096;
     if (s < 1) s = 1;
     return (int)s;
 }
 
 extern "C" long caspr_wgrad_ws_bytes(long R, int Cin, int Cout)
 {
-    return (long)pick_slabs(R, 32) * ((long)Cout * Cin + Cout) * 4 + 256;
+    return (long)pick_slabs(R, Cin, Cout) * ((long)Cout * Cin + Cout) * 4 + 256;
 }
 
 extern "C" int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X, int ldx, const float *in_scale,
@@ -165,18 +193,18 @@ extern "C" int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X
                   "conv1x1_wgrad: in_scale/in_shift must be given together and need Cin %% 4 == 0");
     const long R = (long)B * P;
     CASPR_REQUIRE(ws_bytes >= caspr_wgrad_ws_bytes(R, Cin, Cout), "conv1x1_wgrad: workspace too small");
-    const int S = pick_slabs(R, 32);
+    const int S = pick_slabs(R, Cin, Cout);
     const long rps = ((R + S - 1) / S + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)ws;
     conv1x1_wgrad_kernel<<<dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T), S), dim3(256), 0, st>>>(
         dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin, Cout, rps, part);
     const long n = (long)Cout * Cin;
-    slab_reduce_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(part, n, S, accumulate, dW);
+    launch_slab_reduce(part, n, S, accumulate, dW, st);
     if (dbias) {
         float *bpart = part + (long)S * n;
         colsum_partial_kernel<<<dim3(ceil_div(Cout, 64), S), dim3(256), 0, st>>>(dY, lddy, R, Cout, rps, bpart);
-        slab_reduce_kernel<<<dim3(ceil_div(Cout, 256)), dim3(256), 0, st>>>(bpart, Cout, S, accumulate, dbias);
+        launch_slab_reduce(bpart, Cout, S, accumulate, dbias, st);
     }
     CASPR_CHECK_LAUNCH("conv1x1_wgrad");
     return CASPR_OK;

@@ -258,18 +258,28 @@ __global__ __launch_bounds__(256) void gn_rows_bwd_kernel(const float *__restric
         part[(long)blockIdx.x * (16 * CPG * 2) + t] = (s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t]);
 }
 
-__global__ void gn_rows_param_kernel(const float *__restrict__ part, int nblocks, int C, float *__restrict__ dgamma,
-                                     float *__restrict__ dbeta, int accumulate)
+// one workgroup per channel: 256 threads take every 256th block partial (f64), LDS tree in a fixed order
+__global__ __launch_bounds__(256) void gn_rows_param_kernel(const float *__restrict__ part, int nblocks, int C,
+                                                            float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sa[256], sb[256];
+    const int c = blockIdx.x, t = threadIdx.x;
     double a = 0.0, bx = 0.0;
-    for (int k = 0; k < nblocks; ++k) {
+    for (int k = t; k < nblocks; k += 256) {
         a += (double)part[(long)k * C * 2 + c * 2 + 0];
         bx += (double)part[(long)k * C * 2 + c * 2 + 1];
     }
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a;
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)bx;
+    sa[t] = a;
+    sb[t] = bx;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w) { sa[t] += sa[t + w]; sb[t] += sb[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sa[0];
+        dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sb[0];
+    }
 }
 
 #define GN_ROWS_BLOCKS 2048
@@ -330,7 +340,7 @@ extern "C" int caspr_gn_rows_bwd_f32(const float *Y, int ldy, long NB, int ns, i
         return CASPR_EINVAL;
     }
 #undef CASE
-    gn_rows_param_kernel<<<dim3(ceil_div(C, 256)), dim3(256), 0, st>>>(part, blocks, C, dgamma, dbeta, accumulate);
+    gn_rows_param_kernel<<<dim3(C), dim3(256), 0, st>>>(part, blocks, C, dgamma, dbeta, accumulate);
     CASPR_CHECK_LAUNCH("gn_rows_bwd");
     return CASPR_OK;
 }
@@ -340,24 +350,47 @@ extern "C" int caspr_gn_rows_bwd_f32(const float *Y, int ldy, long NB, int ns, i
 // global feature through the head's first conv, tpointnet2.py:96-99)   -- fixed-order: one thread per column
 // quad walks a 256-row stripe, stripes combined in order.
 // ---------------------------------------------------------------------------------------------
+#define CSB_SPLIT 512
 __global__ __launch_bounds__(256) void colsum_batched_kernel(const float *__restrict__ A, int ld, int P, int C,
-                                                             float *__restrict__ out)
+                                                             float *__restrict__ part)
 {
     __shared__ double red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-    const long b = blockIdx.y;
-    double s = 0.0;
+    const int s = blockIdx.y, S = gridDim.y;
+    const long b = blockIdx.z;
+    const int pbeg = s * CSB_SPLIT, pend = (pbeg + CSB_SPLIT) < P ? (pbeg + CSB_SPLIT) : P;
+    double acc = 0.0;
     if (c < C)
-        for (int p = sub; p < P; p += 4) s += (double)A[(b * P + p) * ld + c];
-    red[sub][threadIdx.x & 63] = s;
+        for (int p = pbeg + sub; p < pend; p += 4) acc += (double)A[(b * P + p) * ld + c];
+    red[sub][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (sub == 0 && c < C) out[b * C + c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (sub == 0 && c < C)
+        part[(b * S + s) * C + c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
-extern "C" int caspr_colsum_batched_f32(const float *A, int ld, int B, int P, int C, float *out, void *stream)
+__global__ void colsum_batched_final_kernel(const float *__restrict__ part, long BC, int C, int S, float *__restrict__ out)
 {
-    CASPR_REQUIRE(A && out && B > 0 && B <= 65535 && P > 0 && C > 0 && ld >= C, "colsum_batched: bad arguments");
-    colsum_batched_kernel<<<dim3(ceil_div(C, 64), B), dim3(256), 0, (hipStream_t)stream>>>(A, ld, P, C, out);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= BC) return;
+    const long b = t / C;
+    const int c = (int)(t % C);
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += (double)part[(b * S + s) * C + c];
+    out[t] = (float)acc;
+}
+
+extern "C" long caspr_colsum_ws_bytes(long B, int P, int C) { return B * ((P + CSB_SPLIT - 1) / CSB_SPLIT) * C * 4 + 256; }
+
+extern "C" int caspr_colsum_batched_f32(const float *A, int ld, int B, int P, int C, float *out, void *ws, long ws_bytes,
+                                        void *stream)
+{
+    CASPR_REQUIRE(A && out && ws && B > 0 && B <= 65535 && P > 0 && C > 0 && ld >= C, "colsum_batched: bad arguments");
+    CASPR_REQUIRE(ws_bytes >= caspr_colsum_ws_bytes(B, P, C), "colsum_batched: workspace too small");
+    const int S = ceil_div(P, CSB_SPLIT);
+    hipStream_t st = (hipStream_t)stream;
+    colsum_batched_kernel<<<dim3(ceil_div(C, 64), S, B), dim3(256), 0, st>>>(A, ld, P, C, (float *)ws);
+    const long BC = (long)B * C;
+    colsum_batched_final_kernel<<<dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, st>>>((const float *)ws, BC, C, S, out);
     CASPR_CHECK_LAUNCH("colsum_batched");
     return CASPR_OK;
 }

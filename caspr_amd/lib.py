@@ -52,7 +52,8 @@ SIGNATURES = {
                                  c_int, c_fp, c_fp, c_int, ctypes.c_void_p, c_long, c_stream]),
     "caspr_argmax_ws_bytes": (c_long, [c_long, c_int, c_int]),
     "caspr_argmax_points_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_ip, ctypes.c_void_p, c_long, c_stream]),
-    "caspr_colsum_batched_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_stream]),
+    "caspr_colsum_ws_bytes": (c_long, [c_long, c_int, c_int]),
+    "caspr_colsum_batched_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_three_interp_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_group_rows_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_group_rows_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),

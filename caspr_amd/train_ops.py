@@ -80,7 +80,9 @@ def colsum_batched(a, C):
     ld = _chk_rows(a)
     B, P, _ = a.shape
     out = torch.empty(B, C, device=a.device, dtype=torch.float32)
-    _lib.check(_lib.load().caspr_colsum_batched_f32(_p(a), ld, B, P, C, _p(out), _stream()), "caspr_colsum_batched_f32")
+    L = _lib.load()
+    ws = _workspace(L.caspr_colsum_ws_bytes(B, P, C), a.device)
+    _lib.check(L.caspr_colsum_batched_f32(_p(a), ld, B, P, C, _p(out), _p(ws), ws.numel(), _stream()), "caspr_colsum_batched_f32")
     return out
 
 

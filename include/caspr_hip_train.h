@@ -54,7 +54,9 @@ int caspr_argmax_points_f32(const float *Y, int ldy, int B, int P, int C, const 
 
 /* out[b,c] = sum_p A[b,p,c]: gradient of the per-sequence bias that carries the tiled global feature
  * through the head's first conv (tpointnet2.py:96-99, pointnet.py:44-46).                           */
-int caspr_colsum_batched_f32(const float *A, int ld, int B, int P, int C, float *out, void *stream);
+long caspr_colsum_ws_bytes(long B, int P, int C);
+int caspr_colsum_batched_f32(const float *A, int ld, int B, int P, int C, float *out, void *ws,
+                             long ws_bytes, void *stream);
 
 /* three_interpolate backward (Kaolin three_interpolate grad, call site pointnet2.py:519):
  * dFeat[b, idx[b,i,k], c] += weight[b,i,k] * dOut[b,i,c], c < C.  dFeat must be initialised by the

@@ -1,0 +1,47 @@
+"""Time one T-NOCS pre-training step (taped forward + HIP backward + Adam) on synthetic sequences.
+usage: PYTHONPATH=. python tools/train_bench.py [B T N steps]      (cfg-3 per GPU: 8 10 1024)"""
+import json
+import sys
+import time
+
+import torch
+
+from caspr_amd.models import CaSPR
+from caspr_amd.utils.synthetic import car_sequences, seeded_state_dict
+
+B, T, N, steps = (int(a) for a in (sys.argv[1:5] + ["8", "10", "1024", "5"][len(sys.argv) - 1:]))
+dev = torch.device("cuda:0")
+m = CaSPR(pretrain_tnocs=True)
+m.load_state_dict({k: v for k, v in seeded_state_dict(CaSPR().state_dict(), 0).items() if k.startswith("encoder.")})
+m = m.to(dev).train()
+opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+x, sp = car_sequences(B, T, N, seed=1234)
+x, sp = x.to(dev), sp.to(dev)
+
+
+def step():
+    opt.zero_grad()
+    loss = 100.0 * m(x, sp)[0][:, :, :, :4].mean()
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    l0 = step()
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(steps):
+    l = step()
+torch.cuda.synchronize()
+dt = (time.time() - t0) / steps
+# forward only (taped) for the split
+torch.cuda.synchronize()
+t1 = time.time()
+for _ in range(steps):
+    with torch.enable_grad():
+        out = m(x, sp)
+torch.cuda.synchronize()
+df = (time.time() - t1) / steps
+print(json.dumps({"B": B, "T": T, "N": N, "ms_per_step": dt * 1e3, "ms_taped_forward": df * 1e3, "sequences_per_s": B / dt,
+                  "loss_first": float(l0), "loss_last": float(l), "max_mem_GB": torch.cuda.max_memory_allocated() / 2**30}))
