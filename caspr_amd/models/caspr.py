@@ -6,9 +6,9 @@ checkpoints work unchanged.  Extra keyword-only knobs of this build: `cnf_rk4_st
 `latent_rk4_steps` (fixed-step RK4 replaces torchdiffeq's adaptive dopri5).
 
 Inference: `encode`, `reconstruct`, `decode`, and `forward` for NLL / T-NOCS loss values.
-Training: in train() mode with grad enabled the encoder is differentiable (caspr_amd/train/encoder_grad.py: a taped
-forward and a backward on the HIP gradient kernels), which covers `pretrain_tnocs=True` end to end; the latent-ODE /
-CNF backward is not built yet, so the NLL term of `forward` is returned as a value without grad_fn.
+Training: in train() mode with grad enabled `forward` is differentiable end to end -- the encoder as one autograd node
+with a HIP backward (caspr_amd/train/encoder_grad.py), the latent ODE and the CNF through the discrete RK4 map with
+every matrix product on the HIP kernels (caspr_amd/train/flow_grad.py).
 """
 import numpy as np
 import torch
@@ -49,10 +49,8 @@ class CaSPR(nn.Module):
     def forward(self, x, sample_points, aggregate_points=None, e=None):
         """caspr.py:76-122.  x, sample_points (B,T,N,4) -> (recon_loss (B,T,N), tnocs_loss (B,T,N,4)).
         `e` (B*T,N,3) optionally fixes the Hutchinson noise (odefunc.py:115-117)."""
-        if self.pretrain_tnocs and self.training and torch.is_grad_enabled():
-            _, tnocs_pred = self.encode(x)                                                      # differentiable (HIP backward)
-            return tuple([self.encoder.loss(tnocs_pred[:, :, :, :self.tnocs_point_size],
-                                            sample_points[:, :, :, :self.tnocs_point_size])])
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x, sample_points, e)
         with torch.no_grad():
             z0, tnocs_pred = self.encode(x)
             B, H = z0.size()
@@ -72,6 +70,26 @@ class CaSPR(nn.Module):
             cnf_result = self.point_cnf(pts, z, init_logprob, e=e)
             recon_loss = self.get_nll_loss(cnf_result, B, T)
             return tuple([recon_loss, tnocs_loss])
+
+    def _forward_train(self, x, sample_points, e=None):
+        """Differentiable forward (train_utils.py:125 calls it under model.train()): the encoder is one autograd node with
+        a HIP backward (train/encoder_grad.py); the latent ODE and the CNF differentiate the RK4 map (train/flow_grad.py)."""
+        from ..train.flow_grad import point_cnf_train
+        z0, tnocs_pred = self.encode(x)
+        B, _ = z0.size()
+        _, T, N, _ = sample_points.size()
+        tnocs_loss = None
+        if self.regress_tnocs:
+            tnocs_loss = self.encoder.loss(tnocs_pred[:, :, :, :self.tnocs_point_size], sample_points[:, :, :, :self.tnocs_point_size])
+        if self.pretrain_tnocs:
+            return tuple([tnocs_loss])
+        all_times = sample_points[:, :, 0, 3]
+        sample_feats = self.aggregate_and_solve_latent(z0, all_times)
+        z = sample_feats.reshape(B * T, self.cnf_args.zdim)
+        pts = sample_points.reshape(B * T, N, 4)[:, :, :3].contiguous()
+        init_logprob = torch.zeros(B * T, N, 1, device=pts.device, dtype=pts.dtype)
+        cnf_result = point_cnf_train(self.point_cnf, pts, z, init_logprob, e=e)
+        return tuple([self.get_nll_loss(cnf_result, B, T), tnocs_loss])
 
     def get_nll_loss(self, cnf_result_list, B, T):
         """caspr.py:124-146."""

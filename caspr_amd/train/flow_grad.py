@@ -1,0 +1,182 @@
+"""Training path of the latent ODE and the point CNF.
+
+The reference back-propagates through torchdiffeq's adjoint (cnf.py:102-110, latent_ode_model.py:98).  This build
+integrates with fixed-step RK4, so the training path differentiates the discrete RK4 map itself
+(discretise-then-optimise): the gradient is exact for the map the forward pass computes, including d/d(sqrt_end_time)
+through the step size and the stage times.
+
+Status (round 1): every matrix product of the path -- the 512x512 layers of the ODE function on value AND tangent
+columns (the Hutchinson divergence e^T (df/dy) e is carried as a forward-mode tangent, odefunc.py:13-31), the hyper
+networks, the latent dynamics -- runs on the HIP kernels through `LinearRows` (forward: caspr_conv1x1_f32, data
+gradient: the same kernel with the transposed packed weight, weight/bias gradient: caspr_conv1x1_wgrad_f32).  The
+element-wise glue (gates, softplus and its derivatives, RK4 combinations) is recorded by torch.autograd; fusing it
+into the GEMM epilogues is the next step.  No CPU path: everything below requires GPU tensors.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .. import train_ops as T
+
+_pack_cache = {}
+
+
+def _packed(w, transposed):
+    """PackedWeight of a 2-D weight; cached for nn.Parameters (keyed on storage + version), fresh for temporaries."""
+    def build():
+        src = w.detach()
+        return ops.PackedWeight((src.t() if transposed else src).contiguous())
+    if not isinstance(w, nn.Parameter):
+        return build()
+    key = (id(w), transposed)
+    sig = (w.data_ptr(), w._version)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    pw = build()
+    _pack_cache[key] = (sig, pw)
+    return pw
+
+
+def _pad4(x):
+    c = x.shape[-1]
+    return x.contiguous() if c % 4 == 0 else F.pad(x, (0, (-c) % 4)).contiguous()
+
+
+class LinearRows(torch.autograd.Function):
+    """y = x W^T (+ b) over rows.  x (R, >=Cin) f32 GPU, W (Cout, Cin), b (Cout) | None  ->  (R, Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        if not x.is_cuda:
+            raise ValueError("LinearRows runs on the GPU only (HIP kernels)")
+        cout, cin = w.shape
+        xp = _pad4(x[:, :cin]) if x.shape[1] != (cin + 3) // 4 * 4 else x.contiguous()
+        y = ops.conv1x1(_packed(w, False), None if b is None else b.detach().contiguous(), xp.view(1, xp.shape[0], xp.shape[1]))
+        ctx.save_for_backward(xp, w)
+        ctx.has_bias = b is not None
+        ctx.x_cols = x.shape[1]
+        return y.view(xp.shape[0], -1)[:, :cout]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w = ctx.saved_tensors
+        cout, cin = w.shape
+        R = xp.shape[0]
+        dyp = _pad4(dy)
+        dyv = dyp.view(1, R, dyp.shape[1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv1x1(_packed(w, True), None, dyv).view(R, -1)
+            if dx.shape[1] != cin:
+                dx[:, cin:] = 0.0
+            if dx.shape[1] != ctx.x_cols:
+                dx = dx[:, :ctx.x_cols] if dx.shape[1] > ctx.x_cols else F.pad(dx, (0, ctx.x_cols - dx.shape[1]))
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty(cout, cin, device=xp.device, dtype=torch.float32)
+            db = torch.empty(cout, device=xp.device, dtype=torch.float32) if ctx.has_bias else None
+            T.conv1x1_wgrad(dyv, xp.view(1, R, xp.shape[1]), cin, cout, dw, db)
+        return dx, dw, db
+
+
+def linear_rows(x, w, b=None):
+    return LinearRows.apply(x, w, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# latent ODE (latent_ode_model.py:45-70,139-147): z' = MLP_tanh(z), classic RK4, `steps` per requested interval
+# ---------------------------------------------------------------------------------------------
+def latent_solve_train(lat, z0, times):
+    """z0 (B,D) differentiable, times (Tu,) ascending -> (B,Tu,D); first output is z0 itself."""
+    lin = [lat.ode_func.dynamics_net[i] for i in (0, 2, 4, 6)]
+
+    def f(z):
+        h = z
+        for i, l in enumerate(lin):
+            h = linear_rows(h, l.weight, l.bias)
+            if i < 3:
+                h = torch.tanh(h)
+        return h
+    outs = [z0]
+    z = z0
+    tt = times.detach().float()
+    for k in range(1, tt.shape[0]):
+        h = (tt[k] - tt[k - 1]) / lat.rk4_steps
+        for _ in range(lat.rk4_steps):
+            k1 = f(z)
+            k2 = f(z + 0.5 * h * k1)
+            k3 = f(z + 0.5 * h * k2)
+            k4 = f(z + h * k3)
+            z = z + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        outs.append(z)
+    lat.ode_func._num_evals.fill_(4 * lat.rk4_steps * max(tt.shape[0] - 1, 0))
+    return torch.stack(outs, dim=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# point CNF block (cnf.py:70-128, odefunc.py:119-142, diffeq_layers.py:83-90)
+# ---------------------------------------------------------------------------------------------
+def cnf_block_train(block, x, context, logpx, e):
+    """x (BT,n,3), context (BT,zdim), logpx (BT,n,1), e (BT,n,3) fixed Hutchinson noise.  Forward direction
+    t: 0 -> sqrt_end_time^2 with `block.rk4_steps` RK4 steps.  -> (x_T, logp_T), differentiable in every parameter."""
+    layers = block.odefunc.diffeq.layers
+    BT, n, _ = x.shape
+    c = context.contiguous()
+    # hyper networks: the context columns once per step (constant over the solve), the time column per evaluation
+    G, Bb, tg, tb = [], [], [], []
+    for l in layers:
+        wg, wb = l._hyper_gate.weight, l._hyper_bias.weight
+        G.append(linear_rows(c, wg[:, 1:].contiguous(), l._hyper_gate.bias))
+        Bb.append(linear_rows(c, wb[:, 1:].contiguous(), None))
+        tg.append(wg[:, 0])
+        tb.append(wb[:, 0])
+    e_rows = e.reshape(BT * n, 3)
+
+    def func(t, y, _lp):
+        h = torch.cat([y.reshape(BT * n, 3), e_rows], dim=0)              # value rows | tangent rows
+        R = BT * n
+        a = ad = None
+        for i, l in enumerate(layers):
+            z = linear_rows(h, l._layer.weight, None)
+            cout = l._layer.weight.shape[0]
+            gate = torch.sigmoid(G[i] + t * tg[i]).unsqueeze(1)           # (BT,1,C)
+            bias = (Bb[i] + t * tb[i]).unsqueeze(1)
+            zv = z[:R].reshape(BT, n, cout) + l._layer.bias
+            zt = z[R:].reshape(BT, n, cout)
+            a = zv * gate + bias
+            ad = zt * gate
+            if i < 3:
+                s = torch.sigmoid(a)
+                h = torch.cat([F.softplus(a).reshape(R, cout), (s * ad).reshape(R, cout)], dim=0)
+        div = (ad * e).sum(dim=-1, keepdim=True)
+        return a, -div
+
+    t_end = block.sqrt_end_time * block.sqrt_end_time if block.train_T else torch.tensor(float(block.T), device=x.device)
+    steps = block.rk4_steps
+    hstep = t_end / steps
+    y, lp = x, logpx
+    for s in range(steps):
+        t = hstep * s
+        k1 = func(t, y, lp)
+        k2 = func(t + 0.5 * hstep, y + 0.5 * hstep * k1[0], lp)
+        k3 = func(t + 0.5 * hstep, y + 0.5 * hstep * k2[0], lp)
+        k4 = func(t + hstep, y + hstep * k3[0], lp)
+        y = y + (hstep / 6.0) * (k1[0] + 2.0 * k2[0] + 2.0 * k3[0] + k4[0])
+        lp = lp + (hstep / 6.0) * (k1[1] + 2.0 * k2[1] + 2.0 * k3[1] + k4[1])
+    block.odefunc._num_evals.fill_(4 * steps)
+    return y, lp
+
+
+def point_cnf_train(flow, x, context, logpx, e=None):
+    """SequentialFlow in the forward (training / NLL) direction (cnf.py:33-48): [MBN, CNF x k, MBN]."""
+    from ..models.cnf import CNF
+    if e is None:
+        e = torch.randn_like(x)                                           # odefunc.py:127-128
+    for layer in flow.chain:
+        if isinstance(layer, CNF):
+            layer.odefunc._e = e
+            x, logpx = cnf_block_train(layer, x, context, logpx, e)
+        else:
+            x, logpx = layer(x, context, logpx, None, False)
+    return x, logpx

@@ -247,7 +247,11 @@ def main():
     state0 = copy.deepcopy(ref.state_dict())
     watch = ["encoder.conv3.weight", "encoder.conv3.bias", "encoder.conv2.bias", "encoder.bn2.weight", "encoder.global_extract.conv1.weight",
              "encoder.local_extract.final_layers.3.weight", "point_cnf.chain.1.sqrt_end_time", "point_cnf.chain.0.weight",
-             "point_cnf.chain.1.odefunc.diffeq.layers.3._layer.weight", "latent_ode.ode_func.dynamics_net.net.0.weight"]
+             "point_cnf.chain.2.bias", "point_cnf.chain.1.odefunc.diffeq.layers.0._layer.weight",
+             "point_cnf.chain.1.odefunc.diffeq.layers.1._layer.weight", "point_cnf.chain.1.odefunc.diffeq.layers.2._layer.bias",
+             "point_cnf.chain.1.odefunc.diffeq.layers.3._layer.weight", "point_cnf.chain.1.odefunc.diffeq.layers.3._hyper_gate.weight",
+             "point_cnf.chain.1.odefunc.diffeq.layers.3._hyper_bias.weight", "point_cnf.chain.1.odefunc.diffeq.layers.1._hyper_gate.bias",
+             "latent_ode.ode_func.dynamics_net.0.weight", "latent_ode.ode_func.dynamics_net.6.weight"]
 
     def train_step(model, full):
         model.train()
@@ -274,8 +278,8 @@ def main():
     g["train_full_nll"], g["train_full_tnocs_l1"] = losses[0].detach().numpy(), losses[1].detach().numpy()
     for k in gr:
         g["train_full_grad:" + k], g["train_full_delta:" + k] = gr[k].numpy(), dl[k].numpy()
-    g["train_full_mbn_running_mean"] = ref.state_dict()["point_cnf.chain.0.running_mean"].numpy()
-    g["train_full_mbn_running_var"] = ref.state_dict()["point_cnf.chain.0.running_var"].numpy()
+    g["train_full_mbn_running_mean"] = ref.state_dict()["point_cnf.chain.0.running_mean"].clone().numpy()
+    g["train_full_mbn_running_var"] = ref.state_dict()["point_cnf.chain.0.running_var"].clone().numpy()
     odef.before_odeint = orig
     ref.load_state_dict(state0)
     ref.eval()
