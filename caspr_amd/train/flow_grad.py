@@ -9,8 +9,11 @@ Status (round 1): every matrix product of the path -- the 512x512 layers of the 
 columns (the Hutchinson divergence e^T (df/dy) e is carried as a forward-mode tangent, odefunc.py:13-31), the hyper
 networks, the latent dynamics -- runs on the HIP kernels through `LinearRows` (forward: caspr_conv1x1_f32, data
 gradient: the same kernel with the transposed packed weight, weight/bias gradient: caspr_conv1x1_wgrad_f32).  The
-element-wise glue (gates, softplus and its derivatives, RK4 combinations) is recorded by torch.autograd; fusing it
-into the GEMM epilogues is the next step.  No CPU path: everything below requires GPU tensors.
+gated softplus layers (value and tangent rows, forward and backward with the per-frame gate / bias reductions) are the
+fused kernels caspr_cnf_act_f32 / caspr_cnf_act_bwd_f32 (`CnfAct`).  torch.autograd records only the small tensors
+around them: the (frames, C) gates, the (BT,n,3) RK4 combinations and the 3-channel output layer.  Fusing the
+activation into the GEMM epilogue and recomputing instead of storing the layer products is the next step
+(DESIGN.md section 7).  No CPU path: everything below requires GPU tensors.
 """
 import torch
 import torch.nn as nn
@@ -84,6 +87,42 @@ def linear_rows(x, w, b=None):
     return LinearRows.apply(x, w, b)
 
 
+class CnfAct(torch.autograd.Function):
+    """Gated softplus layer on value + tangent rows (caspr_cnf_act_f32 / caspr_cnf_act_bwd_f32).
+    z (2R,C) = layer product, b (C), gate / beta (frames, C), n points per frame -> h (2R,C)."""
+
+    @staticmethod
+    def forward(ctx, z, b, gate, beta, n):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        R2, C = z.shape
+        R = R2 // 2
+        if not (z.is_cuda and z.stride(1) == 1 and z.stride(0) % 4 == 0):
+            raise ValueError("CnfAct: z must be a GPU (2R,C) tensor with unit column stride")
+        b, gate, beta = b.detach().contiguous(), gate.detach().contiguous(), beta.detach().contiguous()
+        h = torch.empty(R2, C, device=z.device, dtype=torch.float32)
+        _lib.check(_lib.load().caspr_cnf_act_f32(_p(z), z.stride(0), _p(b), _p(gate), _p(beta), R, n, C, _p(h), C, _stream()), "caspr_cnf_act_f32")
+        ctx.save_for_backward(z, b, gate, beta)
+        ctx.n = n
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        z, b, gate, beta = ctx.saved_tensors
+        R2, C = z.shape
+        R = R2 // 2
+        dh = dh.contiguous()
+        dz = torch.empty(R2, C, device=z.device, dtype=torch.float32)
+        dgate = torch.empty_like(gate)
+        dbeta = torch.empty_like(beta)
+        _lib.check(_lib.load().caspr_cnf_act_bwd_f32(_p(z), z.stride(0), _p(b), _p(gate), _p(beta), _p(dh), C, R, ctx.n, C, _p(dz), C,
+                                                     _p(dgate), _p(dbeta), _stream()), "caspr_cnf_act_bwd_f32")
+        db = (gate * dbeta).sum(dim=0)                                    # d/db = sum_r da*g = sum_f g[f]*dbeta[f]
+        return dz, db, dgate, dbeta, None
+
+
 # ---------------------------------------------------------------------------------------------
 # latent ODE (latent_ode_model.py:45-70,139-147): z' = MLP_tanh(z), classic RK4, `steps` per requested interval
 # ---------------------------------------------------------------------------------------------
@@ -134,21 +173,18 @@ def cnf_block_train(block, x, context, logpx, e):
     e_rows = e.reshape(BT * n, 3)
 
     def func(t, y, _lp):
-        h = torch.cat([y.reshape(BT * n, 3), e_rows], dim=0)              # value rows | tangent rows
         R = BT * n
-        a = ad = None
+        h = torch.cat([y.reshape(R, 3), e_rows], dim=0)                   # value rows | tangent rows
         for i, l in enumerate(layers):
             z = linear_rows(h, l._layer.weight, None)
-            cout = l._layer.weight.shape[0]
-            gate = torch.sigmoid(G[i] + t * tg[i]).unsqueeze(1)           # (BT,1,C)
-            bias = (Bb[i] + t * tb[i]).unsqueeze(1)
-            zv = z[:R].reshape(BT, n, cout) + l._layer.bias
-            zt = z[R:].reshape(BT, n, cout)
-            a = zv * gate + bias
-            ad = zt * gate
+            gate = torch.sigmoid(G[i] + t * tg[i])                        # (BT,C): context part + time column
+            bias = Bb[i] + t * tb[i]
             if i < 3:
-                s = torch.sigmoid(a)
-                h = torch.cat([F.softplus(a).reshape(R, cout), (s * ad).reshape(R, cout)], dim=0)
+                h = CnfAct.apply(z, l._layer.bias, gate, bias, n)         # fused gate + softplus on value / tangent rows
+            else:                                                         # 512 -> 3 output layer: (BT,n,3) tensors
+                cout = l._layer.weight.shape[0]
+                a = (z[:R].reshape(BT, n, cout) + l._layer.bias) * gate.unsqueeze(1) + bias.unsqueeze(1)
+                ad = z[R:].reshape(BT, n, cout) * gate.unsqueeze(1)
         div = (ad * e).sum(dim=-1, keepdim=True)
         return a, -div
 

@@ -88,6 +88,17 @@ int caspr_gn_rows_bwd_f32(const float *Y, int ldy, long NB, int ns, int C, const
                           float *dY, int lddy, float *dgamma, float *dbeta, int accumulate, void *ws,
                           long ws_bytes, void *stream);
 
+/* Gated softplus layer of the CNF's ODE function (ConcatSquashLinear + Softplus, diffeq_layers.py:83-90,
+ * odefunc.py:98-105) on value rows [0,R) and tangent rows [R,2R) of Z (2R, ldz) = the layer's matrix
+ * product; frame f = r / n has its own gate / beta rows (hyper networks of the context).
+ *   H[r] = softplus((Z[r]+b)*gate[f]+beta[f])     H[R+r] = sigmoid(same) * Z[R+r]*gate[f]
+ * Backward: dZ (2R, lddz), dgate / dbeta (R/n, C) summed over each frame's points in a fixed order.   */
+int caspr_cnf_act_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
+                      long R, int n, int C, float *H, int ldh, void *stream);
+int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
+                          const float *dH, int ldd, long R, int n, int C, float *dZ, int lddz,
+                          float *dgate, float *dbeta, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
