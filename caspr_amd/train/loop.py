@@ -1,0 +1,160 @@
+"""Training loop (reference: caspr/utils/train_utils.py:82-232 `run_one_epoch`, caspr/train.py:135-190).
+
+Same loss and bookkeeping as the reference: loss = cnf_loss_weight * mean_{b,t}(sum_n nll) + tnocs_loss_weight *
+mean(L1 tnocs) (train_utils.py:151-165), Adam, periodic checkpoints `time_model_<epoch>.pth` and
+`BEST_time_model.pth` on the best validation loss (train.py:160-188).
+
+Multi-GPU: instead of nn.DataParallel (one process, scatter/gather, train.py:131-132) each rank owns a
+contiguous block of the batch's sequences; the only collective is ONE all-reduce (RCCL over xGMI on the GPU box) of a
+flat bucket holding every gradient, after which each rank applies the same Adam step.  With equal shard sizes the
+averaged per-rank means equal the reference's mean over the global batch.  MovingBatchNorm running statistics are
+rank-local (the reference's DataParallel keeps replica 0's); rank 0's are the ones checkpointed.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..utils.sharding import shard_range
+
+
+def training_loss(losses, cnf_loss_weight, tnocs_loss_weight):
+    """(loss, cnf_loss, tnocs_loss) from CaSPR.forward's tuple (train_utils.py:131-165)."""
+    if len(losses) == 1:
+        per_point_nll, per_point_tnocs = None, losses[0]
+    elif len(losses) == 2:
+        per_point_nll, per_point_tnocs = losses
+    else:
+        raise ValueError("unexpected number of losses returned: %d" % len(losses))
+    ref = per_point_tnocs if per_point_tnocs is not None else per_point_nll
+    loss = torch.zeros(1, device=ref.device)
+    cnf_loss = tnocs_loss = torch.zeros(1, device=ref.device)
+    if per_point_nll is not None:
+        cnf_loss = cnf_loss_weight * per_point_nll.sum(2).mean()
+        loss = loss + cnf_loss
+    if per_point_tnocs is not None:
+        tnocs_loss = tnocs_loss_weight * per_point_tnocs[:, :, :, :4].mean()
+        loss = loss + tnocs_loss
+    return loss, cnf_loss, tnocs_loss
+
+
+class GradBucket:
+    """All gradients of a model in one flat f32 buffer (16,262,189 elements = 65 MB for the full model):
+    a single all-reduce per step instead of one per tensor."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.sizes = [p.numel() for p in self.params]
+        self.flat = None
+
+    def pack(self):
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(sum(self.sizes), device=dev, dtype=torch.float32)
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        return self.flat
+
+    def unpack(self):
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            g = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+    def all_reduce_mean(self):
+        """Average the gradients over the ranks (no-op without an initialised process group)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        flat = self.pack()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+        self.unpack()
+
+
+def train_step(model, optimizer, pcl_in, nocs_out, cnf_loss_weight=0.01, tnocs_loss_weight=100.0, bucket=None, e=None):
+    """One optimisation step on this rank's sequences (train_utils.py:120-176).  Returns the python floats
+    (loss, cnf_loss, tnocs_loss) of the local shard."""
+    model.train()
+    optimizer.zero_grad()
+    losses = model(pcl_in, nocs_out, e=e) if e is not None else model(pcl_in, nocs_out)
+    loss, cnf_loss, tnocs_loss = training_loss(losses, cnf_loss_weight, tnocs_loss_weight)
+    loss.backward()
+    if bucket is not None:
+        bucket.all_reduce_mean()
+    optimizer.step()
+    return float(loss.detach()), float(cnf_loss.detach()), float(tnocs_loss.detach())
+
+
+def shard_batch(pcl_in, nocs_out, rank=None, world=None):
+    """This rank's contiguous block of the global batch (frames of one sequence stay together)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = shard_range(pcl_in.shape[0], rank, world)
+    return pcl_in[lo:hi], nocs_out[lo:hi]
+
+
+def run_one_epoch(model, data_loader, device, optimizer, cnf_loss_weight, tnocs_loss_weight, epoch, log=print, mode='train',
+                  print_stats_every=10, bucket=None):
+    """train_utils.py:82-232 without the plotting: iterates `data_loader` (items: ((pcl_in, nocs_out), ...)), returns the
+    list of per-batch losses (train) or the mean loss (val / test)."""
+    if mode not in ['train', 'val', 'test']:
+        raise ValueError('mode must be train, val or test')
+    out = []
+    for i, data in enumerate(data_loader):
+        pcl_in, nocs_out = data[0]
+        pcl_in, nocs_out = shard_batch(pcl_in.to(device), nocs_out.to(device))
+        if pcl_in.shape[0] == 0:
+            continue
+        if mode == 'train':
+            loss, cnf_l, tnocs_l = train_step(model, optimizer, pcl_in, nocs_out, cnf_loss_weight, tnocs_loss_weight, bucket)
+        else:
+            model.eval()
+            with torch.no_grad():
+                loss, cnf_l, tnocs_l = (float(v) for v in training_loss(model(pcl_in, nocs_out), cnf_loss_weight, tnocs_loss_weight))
+        out.append(loss)
+        if i % print_stats_every == 0:
+            log('%s epoch %d batch %d/%d: loss %.6f (cnf %.6f, tnocs %.6f)' % (mode, epoch, i, len(data_loader), loss, cnf_l, tnocs_l))
+    return out if mode == 'train' else (float(np.mean(out)) if out else float('nan'))
+
+
+def train(model, train_loader, val_loader, device, out_dir, num_epochs, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+          cnf_loss_weight=0.01, tnocs_loss_weight=100.0, val_every=1, save_every=1, log=print, resume=None):
+    """train.py:135-190: Adam, validation every `val_every` epochs with BEST checkpointing, periodic checkpoints.
+    `resume` = path of a checkpoint written by this function (model + optimizer + epoch)."""
+    optimizer = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+    bucket = GradBucket(model.parameters())
+    start, val_losses = 0, []
+    if resume:
+        ck = torch.load(resume, map_location=device)
+        model.load_state_dict(ck["model"])
+        optimizer.load_state_dict(ck["optimizer"])
+        start, val_losses = ck["epoch"] + 1, ck.get("val_losses", [])
+    is_rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    for epoch in range(start, num_epochs):
+        run_one_epoch(model, train_loader, device, optimizer, cnf_loss_weight, tnocs_loss_weight, epoch, log, 'train', bucket=bucket)
+        if val_loader is not None and epoch % val_every == 0:
+            val = run_one_epoch(model, val_loader, device, None, cnf_loss_weight, tnocs_loss_weight, epoch, log, 'val')
+            if not math.isnan(val):
+                best = len(val_losses) == 0 or val < min(val_losses)
+                val_losses.append(val)
+                if best and is_rank0:
+                    log('BEST Val loss so far! Saving checkpoint...')
+                    torch.save(model.state_dict(), os.path.join(out_dir, 'BEST_time_model.pth'))
+        if epoch % save_every == 0 and is_rank0:
+            torch.save(model.state_dict(), os.path.join(out_dir, 'time_model_%d.pth' % epoch))          # reference-format weights
+            torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch, "val_losses": val_losses},
+                       os.path.join(out_dir, 'resume_%d.pth' % epoch))
+    return val_losses

@@ -398,3 +398,38 @@ def test_full_training_step_matches_reference_golden(golden, seeded_sd):
         assert bad == 0.0, "%s: Adam update differs" % k
     rel("train_full_mbn_running_mean", m.point_cnf.chain[0].running_mean, torch.from_numpy(golden["train_full_mbn_running_mean"]), 1e-5)
     rel("train_full_mbn_running_var", m.point_cnf.chain[0].running_var, torch.from_numpy(golden["train_full_mbn_running_var"]), 1e-5)
+
+
+def test_train_loop_checkpoint_resume(tmp_path, seeded_sd):
+    """train.py:135-190 cadence on the HIP path: two epochs of T-NOCS pre-training over a two-batch loader, periodic and
+    BEST checkpoints in the reference's state_dict format, and a resumed run that continues bit-identically."""
+    from caspr_amd.models import CaSPR
+    from caspr_amd.train.loop import train
+    from caspr_amd.utils.synthetic import dense_sequences
+    dev = torch.device("cuda:0")
+    enc_sd = {k: v for k, v in seeded_sd.items() if k.startswith("encoder.")}
+    batches = [[dense_sequences(1, 2, 1024, seed=s)] for s in (1, 2)]
+    logs = []
+
+    def fresh():
+        m = CaSPR(pretrain_tnocs=True)
+        m.load_state_dict(enc_sd)
+        return m.to(dev)
+    m = fresh()
+    val = train(m, batches, batches[:1], dev, str(tmp_path), num_epochs=2, log=logs.append)
+    assert len(val) == 2 and val[1] < val[0], "validation loss did not go down: %s" % val
+    for f in ("time_model_0.pth", "time_model_1.pth", "BEST_time_model.pth", "resume_0.pth"):
+        assert os.path.exists(os.path.join(str(tmp_path), f)), f
+    saved = torch.load(os.path.join(str(tmp_path), "time_model_1.pth"), map_location="cpu")
+    assert list(saved.keys()) == list(CaSPR(pretrain_tnocs=True).state_dict().keys())
+    # resume from the end of epoch 0 and redo epoch 1: same weights as the uninterrupted run (deterministic reductions;
+    # the float-atomic scatter-adds may move the last bit)
+    m2 = fresh()
+    out2 = tmp_path / "resumed"
+    out2.mkdir()
+    train(m2, batches, batches[:1], dev, str(out2), num_epochs=2, log=logs.append, resume=os.path.join(str(tmp_path), "resume_0.pth"))
+    a, b = m.state_dict()["encoder.conv3.weight"], m2.state_dict()["encoder.conv3.weight"]
+    rel("resume_conv3_weight", b, a, 1e-5)
+    a, b = m.state_dict()["encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight"], \
+        m2.state_dict()["encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight"]
+    rel("resume_sa1_weight", b, a, 1e-4)

@@ -118,3 +118,64 @@ def test_two_rank_sharding_gloo(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29533", str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+TRAIN_WORKER = r'''
+import os, sys, torch, torch.nn as nn, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from caspr_amd.train.loop import GradBucket, shard_batch, training_loss
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+
+class Tiny(nn.Module):          # stand-in with CaSPR.forward's return convention: (per-point nll (B,T,N), per-point tnocs L1 (B,T,N,4))
+    def __init__(self):
+        super().__init__()
+        self.a, self.b = nn.Linear(4, 4), nn.Linear(4, 1)
+        self.unused = nn.Parameter(torch.zeros(3))
+    def forward(self, x, y):
+        return (self.b(torch.tanh(self.a(x))).squeeze(-1) ** 2, (torch.sigmoid(self.a(x)) - y).abs())
+
+B, T, N = 4, 3, 8
+x, y = torch.randn(B, T, N, 4), torch.rand(B, T, N, 4)
+ref = Tiny()
+full, _, _ = training_loss(ref(x, y), 0.01, 100.0)
+full.backward()
+m = Tiny()
+m.load_state_dict(ref.state_dict())
+xs, ys = shard_batch(x, y)
+assert xs.shape[0] == B // world
+loss, _, _ = training_loss(m(xs, ys), 0.01, 100.0)
+loss.backward()
+bucket = GradBucket(m.parameters())
+bucket.all_reduce_mean()
+for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+    want = q.grad if q.grad is not None else torch.zeros_like(q)
+    assert p.grad is not None and torch.allclose(p.grad, want, atol=1e-6, rtol=1e-5), "gradient of %s differs after the all-reduce" % n
+dist.barrier()
+if rank == 0:
+    print("GRAD_OK")
+'''
+
+
+def test_two_rank_gradient_bucket_gloo(tmp_path):
+    """Sharded training step: per-rank mean losses + ONE flat all-reduce (mean) give the gradient of the reference's
+    global-batch mean (train_utils.py:154,163), including parameters that received no gradient."""
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29534", str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "GRAD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_training_loss_weights():
+    """train_utils.py:151-165: 0.01 * mean_{b,t}(sum_n nll) + 100 * mean(tnocs[..., :4]); pretrain tuple has one entry."""
+    from caspr_amd.train.loop import training_loss
+    nll, tn = torch.rand(2, 3, 5), torch.rand(2, 3, 5, 4)
+    loss, c, t = training_loss((nll, tn), 0.01, 100.0)
+    assert torch.allclose(loss, 0.01 * nll.sum(2).mean() + 100.0 * tn.mean())
+    loss1, c1, _ = training_loss((tn,), 0.01, 100.0)
+    assert torch.allclose(loss1, 100.0 * tn.mean()) and float(c1) == 0.0
+    with pytest.raises(ValueError):
+        training_loss((nll, tn, tn), 0.01, 100.0)
