@@ -433,3 +433,26 @@ def test_train_loop_checkpoint_resume(tmp_path, seeded_sd):
     a, b = m.state_dict()["encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight"], \
         m2.state_dict()["encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight"]
     rel("resume_sa1_weight", b, a, 1e-4)
+
+
+@pytest.mark.parametrize("kw", [dict(regress_tnocs=False), dict(cnf_blocks=2), dict(augment_quad=False, augment_pairs=False)])
+def test_training_variants_step(kw, seeded_sd):
+    """Constructor variants the reference configs use (cfg-4: regress_tnocs=False; cnf_blocks; no input augmentation):
+    three optimisation steps run and every trainable parameter the loss depends on receives a finite gradient.  (The
+    loss itself need not fall monotonically over three steps: the MovingBatchNorm running statistics that normalise the
+    CNF's input and output move by 10% towards the batch statistics at every training-mode call.)"""
+    from caspr_amd.models import CaSPR
+    from caspr_amd.train.loop import train_step
+    from caspr_amd.utils.synthetic import dense_sequences, seeded_state_dict
+    dev = torch.device("cuda:0")
+    m = CaSPR(cnf_rk4_steps=4, latent_rk4_steps=2, **kw)
+    m.load_state_dict(seeded_state_dict(m.state_dict(), 3))
+    m = m.to(dev)
+    x, sp = (t.to(dev) for t in dense_sequences(1, 2, 1024, seed=11))
+    e = rnd(5, 2, 1024, 3).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    losses = [train_step(m, opt, x, sp, e=e)[0] for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+    missing = [n for n, p in m.named_parameters() if p.grad is None and not (kw.get("regress_tnocs") is False and n.startswith("encoder.conv3"))]
+    assert not missing, "no gradient for %s" % missing[:5]
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
