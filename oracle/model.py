@@ -335,12 +335,20 @@ def odenet(sd, pre, tc, y):
     return dx
 
 
+GRAD_MODE = False   # True: keep the autograd graph through the divergence (training-step oracle, train_utils.py:173)
+
+
 def odefunc(sd, pre, t, y, c, e=None):
     """models/odefunc.py:119-142.  Returns (dy, -divergence) ; divergence None when e is None."""
     tt = torch.ones(y.shape[0], 1, dtype=y.dtype) * t                         # :121
     tc = torch.cat([tt, c.view(y.shape[0], -1)], dim=1)                       # :133
     if e is None:
         return odenet(sd, pre + ".diffeq", tc, y), None
+    if GRAD_MODE:   # training: the reference differentiates through divergence_approx (create_graph=True, odefunc.py:14)
+        yy = y if y.requires_grad else y.detach().requires_grad_(True)
+        dy = odenet(sd, pre + ".diffeq", tc, yy)
+        e_dzdx = torch.autograd.grad(dy, yy, e, create_graph=True)[0]
+        return dy, -(e_dzdx * e).sum(dim=-1, keepdim=True)
     with torch.enable_grad():
         yy = y.detach().requires_grad_(True)
         dy = odenet(sd, pre + ".diffeq", tc, yy)
@@ -375,7 +383,7 @@ def mbn_reverse(sd, pre, y, logpy=None):
 
 def cnf_block(sd, pre, x, c, logpx, reverse, method, steps, e, counter=None):
     """models/cnf.py:70-128.  Integrates (x, logp) over [0,T] (or [T,0] when reverse)."""
-    T_end = float(sd[pre + ".sqrt_end_time"]) ** 2                            # cnf.py:87-90
+    T_end = sd[pre + ".sqrt_end_time"] ** 2 if GRAD_MODE else float(sd[pre + ".sqrt_end_time"]) ** 2   # cnf.py:87-90
     t0, t1 = (T_end, 0.0) if reverse else (0.0, T_end)                        # :95-96
     with_div = logpx is not None and e is not None
     lp = logpx if logpx is not None else torch.zeros(*x.shape[:-1], 1, dtype=x.dtype)
@@ -454,10 +462,23 @@ def forward_nll(sd, x, sample_points, e, method="rk4", cnf_steps=8, latent_steps
     all_times = sample_points[:, :, 0, 3]                                      # :106
     z = aggregate_and_solve_latent(sd, z0, all_times, method=method, steps_per_interval=latent_steps)
     pts = sample_points.reshape(B * T, N, 4)[:, :, :3].clone()
-    yy, dlogp = point_cnf(sd, pts, z.reshape(B * T, -1), torch.zeros(B * T, N, 1), False, method, cnf_steps, e)
+    yy, dlogp = point_cnf(sd, pts, z.reshape(B * T, -1), torch.zeros(B * T, N, 1, dtype=pts.dtype), False, method, cnf_steps, e)
     log_py = standard_normal_logprob(yy).sum(2)                                # :133-134
     log_px = log_py - dlogp.view(B * T, N)                                     # :136-138
     return (-log_px).view(B, T, -1), tnocs_loss
+
+
+def training_loss(sd, x, sample_points, e, cnf_steps=8, latent_steps=4, cnf_loss_weight=0.01, tnocs_loss_weight=100.0,
+                  radii=DEFAULT_RADII):
+    """The scalar `run_one_epoch` back-propagates (train_utils.py:151-173), differentiable in every entry of `sd` that
+    requires grad (the gradient of the discrete RK4 map, including sqrt_end_time).  -> (loss, recon_loss, tnocs_loss)."""
+    global GRAD_MODE
+    prev, GRAD_MODE = GRAD_MODE, True
+    try:
+        recon, tl = forward_nll(sd, x, sample_points, e, "rk4", cnf_steps, latent_steps, radii)
+    finally:
+        GRAD_MODE = prev
+    return cnf_loss_weight * recon.sum(2).mean() + tnocs_loss_weight * tl[:, :, :, :4].mean(), recon, tl
 
 
 def chamfer_l2(pred, gt):

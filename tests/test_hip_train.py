@@ -456,3 +456,40 @@ def test_training_variants_step(kw, seeded_sd):
     missing = [n for n, p in m.named_parameters() if p.grad is None and not (kw.get("regress_tnocs") is False and n.startswith("encoder.conv3"))]
     assert not missing, "no gradient for %s" % missing[:5]
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+
+
+def test_full_step_all_flow_parameters_vs_f64_oracle(golden, seeded_sd):
+    """Every latent-ODE / CNF / MovingBatchNorm parameter (51 tensors: all four gated layers with their hyper networks,
+    the dynamics MLP, sqrt_end_time): HIP training-step gradients against f64 autograd through the oracle's
+    differentiable mode (itself pinned to the real reference's gradients in tests/test_oracle_golden.py)."""
+    from oracle import model as O
+    from caspr_amd.models import CaSPR
+    dev = "cuda:0"
+    skip = ("running_mean", "running_var", "step", "_num_evals")
+    sd6 = {k: (v.detach().clone().double().requires_grad_(True) if v.is_floating_point() and not k.endswith(skip) else
+               (v.double() if v.is_floating_point() else v)) for k, v in seeded_sd.items()}
+    x, sp, e = (torch.from_numpy(golden[k]) for k in ("train_x", "train_sp", "train_e"))
+    loss6, _, _ = O.training_loss(sd6, x.double(), sp.double(), e.double(), cnf_steps=8, latent_steps=4)
+    loss6.backward()
+    m = CaSPR(cnf_rk4_steps=8, latent_rk4_steps=4)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).train()
+    nll, tl = m(x.to(dev), sp.to(dev), e=e.to(dev))
+    loss = 0.01 * nll.sum(2).mean() + 100.0 * tl[:, :, :, :4].mean()
+    loss.backward()
+    rel("full64_loss", loss.detach().reshape(1), loss6.detach().reshape(1), 1e-5)
+    n, bad = 0, []
+    for name, p in m.named_parameters():
+        if name.startswith("encoder."):
+            continue        # encoder gradients: test_encoder_backward_matches_oracle_autograd (selection noise discussed there)
+        key = name.replace("latent_ode.solver.ode_func", "latent_ode.ode_func")
+        want = sd6[key].grad
+        assert want is not None and p.grad is not None, name
+        err = float((p.grad.detach().cpu().double() - want).norm() / want.norm().clamp_min(1e-12))
+        REPORT["full64_grad_l2:" + name] = {"rel_l2": err, "ref_l2": float(want.norm())}
+        n += 1
+        if not err <= 2e-4:
+            bad.append("%s: rel L2 %.3e" % (name, err))
+    rel("full64_flush", torch.zeros(1), torch.zeros(1), 1.0)
+    assert n >= 30, n
+    assert not bad, "\n".join(bad)

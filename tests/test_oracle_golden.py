@@ -180,3 +180,28 @@ def test_npz_loader_matches_reference(golden, tmp_path):
     xin, xout = select_item(nocs, depth, seq_len=2, num_pts=64)
     assert xin.shape == (2, 64, 4) and xin.dtype == torch.float32
     assert torch.equal(xout, torch.from_numpy(golden["loader_nocs"][:2, :64].astype(np.float32)))
+
+
+def test_oracle_training_step_matches_reference_gradients(golden, seeded_sd):
+    """Row 19 pin of the oracle's differentiable mode (`oracle.model.training_loss`): loss and gradients of the REAL
+    reference's training step (tests/golden/gen_golden.py section 5) on the same weights, input and Hutchinson noise."""
+    import torch
+    from oracle import model as O
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "step", "_num_evals")) else v)
+          for k, v in seeded_sd.items()}
+    x, sp, e = (torch.from_numpy(golden[k]) for k in ("train_x", "train_sp", "train_e"))
+    loss, recon, tl = O.training_loss(sd, x, sp, e, cnf_steps=8, latent_steps=4)
+    loss.backward()
+    assert abs(float(loss) - float(golden["train_full_loss"])) <= 1e-5 * abs(float(golden["train_full_loss"]))
+    assert float((recon.detach() - torch.from_numpy(golden["train_full_nll"])).abs().max()) <= 1e-5
+    n = 0
+    for k in golden.files:
+        if not k.startswith("train_full_grad:"):
+            continue
+        name = k.split(":", 1)[1]
+        want, got = torch.from_numpy(golden[k]), sd[name].grad
+        err = float((got - want).norm() / want.norm())
+        # same torch arithmetic as the reference -> equal to rounding; the end-time gradient sums 2048 x 32 signed terms
+        assert err <= (2e-3 if name.endswith("sqrt_end_time") else 1e-5), "%s: rel L2 %.3e" % (name, err)
+        n += 1
+    assert n >= 18
