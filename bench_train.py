@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""bench_train.py -- sequences/sec of one TRAINING step (BASELINE.json configs[2] = cfg-3).
+
+    python bench_train.py --gpus N --steps K --warmup W [--mode full|pretrain]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench_train.py --gpus N --steps K --warmup W
+
+Companion of bench.py (which measures the headline `reconstruct` metric and is the one the driver runs); same JSON
+contract.  One "step" = `run_one_epoch`'s body (train_utils.py:120-176) on one batch resident in HBM: forward in
+train() mode, loss = 0.01*mean(sum_n nll) + 100*mean(L1 tnocs), backward (HIP gradient kernels), gradient all-reduce
+when N > 1 (ONE flat 65 MB bucket over RCCL -- the only collective), Adam.  Workload: cfg-3's per-GPU shard, 8 sequences
+of T=10 x N=1024 per GPU (weak scaling), f32, 8 CNF RK4 steps with the Hutchinson divergence, 2 latent RK4 steps.
+
+  roofline     : all matrix products of the step (forward + data gradient + weight gradient = 3x the forward
+                 contraction FLOPs of SURVEY.md 8d: 176.6 GFLOP/sequence encoder, 21.70 GFLOP/sequence/evaluation CNF
+                 with divergence) divided by the step time, vs the dense f32 MFMA peak;
+  cpu_baseline : the CPU oracle's differentiable mode (oracle.model.training_loss + backward: torch-CPU autograd, a
+                 port -- the reference's own training needs CUDA-only Kaolin ops) on ONE sequence of the same shape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3
+ENC_GFLOP_PER_SEQ = {(10, 1024): 176.6, (10, 2048): 306.0, (20, 4096): 1129.6, (5, 512): 56.0}
+CNF_FLOP_PER_POINT_EVAL_DIV = 2 * 2 * (3 * 512 + 512 * 512 + 512 * 512 + 512 * 3)               # value + tangent
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
+    ap.add_argument("--seq-len", type=int, default=10)
+    ap.add_argument("--num-pts", type=int, default=1024)
+    ap.add_argument("--cnf-steps", type=int, default=8)
+    ap.add_argument("--latent-steps", type=int, default=2)
+    ap.add_argument("--mode", choices=["full", "pretrain"], default="full")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")   # RCCL on ROCm
+    assert torch.cuda.is_available(), "bench_train.py needs a ROCm GPU (there is no CPU execution path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from caspr_amd.models import CaSPR
+    from caspr_amd.train.loop import GradBucket, train_step
+    from caspr_amd.utils.sharding import max_over_ranks
+    from caspr_amd.utils.synthetic import car_sequences, seeded_state_dict
+
+    B, T, N = args.batch, args.seq_len, args.num_pts
+    full = args.mode == "full"
+    sd = seeded_state_dict(CaSPR().state_dict(), 0)
+    model = CaSPR(pretrain_tnocs=not full, cnf_rk4_steps=args.cnf_steps, latent_rk4_steps=args.latent_steps)
+    model.load_state_dict(sd if full else {k: v for k, v in sd.items() if k.startswith("encoder.")})
+    model = model.to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    bucket = GradBucket(model.parameters()) if world > 1 else None
+    x_all, sp_all = car_sequences(world * B, T, N, seed=1234)
+    x, sp = x_all[rank * B:(rank + 1) * B].to(dev), sp_all[rank * B:(rank + 1) * B].to(dev)
+    e = torch.randn(B * T, N, 3, device=dev) if full else None
+
+    losses = []
+    for _ in range(args.warmup):
+        train_step(model, opt, x, sp, bucket=bucket, e=e)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(train_step(model, opt, x, sp, bucket=bucket, e=e)[0])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        enc = ENC_GFLOP_PER_SEQ.get((T, N))
+        flop = None
+        if enc is not None:
+            flop = 3.0 * B * enc * 1e9
+            if full:
+                flop += 3.0 * B * T * N * 4 * args.cnf_steps * CNF_FLOP_PER_POINT_EVAL_DIV
+        achieved = flop / (ms * 1e-3) / 1e12 if flop else None
+        roofline = {"kernel": "all MFMA kernels of the step (conv1x1 forward / data gradient, conv1x1_wgrad)", "bound": "mfma",
+                    "achieved": None if achieved is None else round(achieved, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": None if achieved is None else round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "flop_per_step": flop}
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import model as O
+            ncores = min(os.cpu_count() or 1, 32)
+            torch.set_num_threads(ncores)
+            s_ = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "step", "_num_evals")) else v)
+                  for k, v in sd.items()}
+            xs, sps = x_all[:1], sp_all[:1]
+            t1 = time.perf_counter()
+            if full:
+                l_, _, _ = O.training_loss(s_, xs, sps, e[:T].cpu(), cnf_steps=args.cnf_steps, latent_steps=args.latent_steps)
+            else:
+                _, tn = O.encode(s_, xs)
+                l_ = 100.0 * (tn - sps).abs().mean()
+            l_.backward()
+            cpu_s = time.perf_counter() - t1
+            cpu = {"value": round(1.0 / cpu_s, 5), "unit": "sequences/sec", "cores": ncores, "kind": "port",
+                   "sample": "1 sequence (T=%d, N=%d) forward + backward through the oracle's differentiable mode (torch-CPU autograd "
+                             "+ C point ops, same RK4 steps), no optimizer step, %.1f s" % (T, N, cpu_s)}
+        print(json.dumps({
+            "metric": "training sequences/sec (%s step: forward + backward + Adam)" % ("full CaSPR" if full else "T-NOCS pre-training"),
+            "value": round(world * B * args.steps / elapsed, 3), "unit": "sequences/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg-3 shard (BASELINE.json configs[2]): run_one_epoch body, B=%d sequences/GPU, T=%d, N=%d, %s; seeded "
+                                   "random-init weights" % (B, T, N, "NLL (CNF with Hutchinson divergence) + T-NOCS L1" if full else "T-NOCS L1 only"),
+                       "global_batch": world * B, "seq_len": T, "num_pts": N, "cnf_rk4_steps": args.cnf_steps,
+                       "latent_rk4_steps": args.latent_steps, "parallelism": "seq-shard x%d + 1 gradient all-reduce" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "loss_first": losses[0], "loss_last": losses[-1],
+            "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+        }))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
