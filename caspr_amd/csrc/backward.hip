@@ -42,9 +42,11 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging: 32 rows x 128 channels = 1024 float4 per operand, 4 per thread: row = f >> 5, c4 = f & 31
-    for (long r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
-        f32x4 va[4], vb[4];
+    // staging: 32 rows x 128 channels = 1024 float4 per operand, 4 per thread: row = f >> 5, c4 = f & 31.
+    // Software pipeline: the global loads of stage s+1 are issued before the MFMAs of stage s and stay in flight
+    // under them (sched_barrier pins the issue point -- hipcc otherwise sinks the loads to their first use).
+    f32x4 va[4], vb[4];
+    auto load_stage = [&](long r0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i;
@@ -52,15 +54,26 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
             const long r = r0 + row;
             f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (r < r_end) {
-                if (co0 + c < Cout) {
-                    a = ld4(dY + r * lddy + co0 + c);   // lddy >= roundup4(Cout)
+                if (co0 + c < Cout) a = ld4(dY + r * lddy + co0 + c);   // lddy >= roundup4(Cout)
+                if (k0 + c < Cin) b = ld4(X + r * ldx + k0 + c);
+            }
+            va[i] = a;
+            vb[i] = b;
+        }
+    };
+    auto store_stage = [&](long r0) {   // masking and the fused input transform run here, when the data has arrived
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (co0 + c + q >= Cout) a[q] = 0.f;
-                }
-                const int k = k0 + c;
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f >> 5, c = (f & 31) * 4;
+            const long r = r0 + row;
+            f32x4 a = va[i], b = vb[i];
+            const int k = k0 + c;
+            if (r < r_end) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (co0 + c + q >= Cout) a[q] = 0.f;
                 if (k < Cin) {
-                    b = ld4(X + r * ldx + k);
                     if (in_scale) {
                         const long bi = r / P;
                         const f32x4 s4 = ld4(in_scale + bi * Cin + k), t4 = ld4(in_shift + bi * Cin + k);
@@ -75,18 +88,17 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
                         if (k + q >= Cin) b[q] = 0.f;
                 }
             }
-            va[i] = a;
-            vb[i] = b;
+            st4(&sA[row * WG_LD + c], a);
+            st4(&sB[row * WG_LD + c], b);
         }
+    };
+    load_stage(r_beg);
+    for (long r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
         __syncthreads();   // previous stage fully consumed
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f >> 5, c = (f & 31) * 4;
-            st4(&sA[row * WG_LD + c], va[i]);
-            st4(&sB[row * WG_LD + c], vb[i]);
-        }
+        store_stage(r0);
         __syncthreads();
+        if (r0 + WG_ROWS < r_end) load_stage(r0 + WG_ROWS);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < WG_ROWS / 4; ++ks) {
             float af[4], bf[4];
@@ -278,8 +290,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
 }
 
 __global__ void gn_bwd_finalize_kernel(const double *__restrict__ part, int B, int C, int G, int S,
-                                       const float *__restrict__ gamma, double *__restrict__ chan, float *__restrict__ s12,
-                                       float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate)
+                                       const float *__restrict__ gamma, double *__restrict__ chan, float *__restrict__ s12)
 {
     // one thread per (b, group): s1, s2 ; also per-(b,c) totals into `chan` for the dgamma/dbeta pass below
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,7 +312,6 @@ __global__ void gn_bwd_finalize_kernel(const double *__restrict__ part, int B, i
         s12[t * 2 + 0] = (float)s1;
         s12[t * 2 + 1] = (float)s2;
     }
-    (void)dgamma; (void)dbeta; (void)accumulate;
 }
 
 __global__ void gn_bwd_param_kernel(const double *__restrict__ chan, int B, int C, float *__restrict__ dgamma,
@@ -372,7 +382,7 @@ extern "C" int caspr_gn_bwd_f32(const float *Y, int ldy, const float *dA, int ld
     float *s12 = (float *)(chan + B * C * 2);
     hipStream_t st = (hipStream_t)stream;
     gn_bwd_partial_kernel<<<dim3(G, S, (unsigned)B), dim3(256), 0, st>>>(Y, ldy, dA, ldd, P, C, G, mean, rstd, gamma, beta, relu, dMax, aMax, part);
-    gn_bwd_finalize_kernel<<<dim3((unsigned)((B * G + 255) / 256)), dim3(256), 0, st>>>(part, (int)B, C, G, S, gamma, chan, s12, dgamma, dbeta, accumulate);
+    gn_bwd_finalize_kernel<<<dim3((unsigned)((B * G + 255) / 256)), dim3(256), 0, st>>>(part, (int)B, C, G, S, gamma, chan, s12);
     gn_bwd_param_kernel<<<dim3(ceil_div(C, 256)), dim3(256), 0, st>>>(chan, (int)B, C, dgamma, dbeta, accumulate);
     const long total4 = B * P * (C / 4);
     gn_bwd_apply_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st>>>(Y, ldy, dA, ldd, dY, lddy, P, C, G, mean, rstd, gamma, beta, relu, dMax, aMax, s12, total4);

@@ -1,0 +1,23 @@
+"""Time caspr_conv1x1_wgrad_f32 on the training step's shapes.  usage: PYTHONPATH=. python tools/wgrad_bench.py"""
+import torch
+from caspr_amd import train_ops as T
+
+dev = "cuda:0"
+for (R, cin, cout) in [(81920, 1600, 1600), (163840, 512, 512), (81920, 576, 1600), (2621440, 12, 32), (655360, 64, 128), (163840, 3, 512)]:
+    cinp = (cin + 3) // 4 * 4
+    x = torch.randn(1, R, cinp, device=dev)
+    dy = torch.randn(1, R, (cout + 3) // 4 * 4, device=dev)
+    dw = torch.empty(cout, cin, device=dev)
+    db = torch.empty(cout, device=dev)
+    for _ in range(2):
+        T.conv1x1_wgrad(dy, x, cin, cout, dw, db)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    n = 5
+    for _ in range(n):
+        T.conv1x1_wgrad(dy, x, cin, cout, dw, db)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
+    print("R=%8d Cin=%5d Cout=%5d  %8.3f ms  %7.1f TFLOP/s" % (R, cin, cout, ms, 2.0 * R * cin * cout / ms / 1e9))
