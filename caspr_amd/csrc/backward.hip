@@ -4,7 +4,7 @@
 //   data gradient   dX = dY . W            : the forward conv1x1 kernel with the transposed packed weight (no new code)
 //   weight gradient dW = dY^T . in(X)      : conv1x1_wgrad_kernel  (f32 MFMA, contraction over points, split into
 //                                            point slabs, fixed-order slab reduction -> deterministic)
-//   bias gradient   db = colsum(dY)        : colsum kernels (same slab scheme)
+//   bias gradient   db = colsum(dY)        : rides along in the weight-gradient kernel's k-tile-0 blocks
 //   GroupNorm(+ReLU) backward              : gn_bwd_partial / finalize / apply
 #include <stdlib.h>
 
@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
                                                             const float *__restrict__ in_scale,
                                                             const float *__restrict__ in_shift, int in_relu,
                                                             int relu_from, long R, int P, int Cin, int Cout,
-                                                            long rows_per_slab, float *__restrict__ part)
+                                                            long rows_per_slab, float *__restrict__ part,
+                                                            float *__restrict__ bpart)
 {
     __shared__ __attribute__((aligned(16))) float sA[WG_ROWS * WG_LD], sB[WG_ROWS * WG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
     // Software pipeline: the global loads of stage s+1 are issued before the MFMAs of stage s and stay in flight
     // under them (sched_barrier pins the issue point -- hipcc otherwise sinks the loads to their first use).
     f32x4 va[4], vb[4];
+    f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto load_stage = [&](long r0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -88,6 +90,8 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
                         if (k + q >= Cin) b[q] = 0.f;
                 }
             }
+            if (r >= r_end) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bsum = bsum + a;   // bias gradient: column sums of dY ride along (used by the k-tile-0 blocks only)
             st4(&sA[row * WG_LD + c], a);
             st4(&sB[row * WG_LD + c], b);
         }
@@ -110,6 +114,19 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(af[mi], bf[ni], acc[mi][ni]);
+        }
+    }
+    // bias-gradient partial of this slab: thread (row phase tid >> 5, column quad tid & 31) summed rows phase, phase+8, ..
+    // of its quad; combine the 8 phases in a fixed order through LDS (sA is free after the last MFMA)
+    if (bpart && blockIdx.y == 0) {
+        __syncthreads();
+        st4(&sA[(tid >> 5) * WG_LD + (tid & 31) * 4], bsum);
+        __syncthreads();
+        if (tid < WG_T && co0 + tid < Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < 8; ++ph) t += sA[ph * WG_LD + tid];
+            bpart[(long)slab * Cout + co0 + tid] = t;
         }
     }
     // partial slab: part[slab][co][k]  (D fragment: row = co = 4g + r, col = k = j)
@@ -158,23 +175,6 @@ static void launch_slab_reduce(const float *part, long n, int S, int accumulate,
         slab_reduce_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(part, n, S, accumulate, out);
 }
 
-// column sums of a (R, ld) matrix restricted to C columns, per slab
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ A, int ld, long R, int C,
-                                                             long rows_per_slab, float *__restrict__ part)
-{
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-    const int slab = blockIdx.y;
-    const long r_beg = (long)slab * rows_per_slab;
-    const long r_end = (r_beg + rows_per_slab) < R ? (r_beg + rows_per_slab) : R;
-    double s = 0.0;
-    if (c < C)
-        for (long r = r_beg + sub; r < r_end; r += 4) s += (double)A[r * ld + c];
-    red[sub][threadIdx.x & 63] = (float)s;
-    __syncthreads();
-    if (sub == 0 && c < C) part[(long)slab * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
 // number of row slabs: enough workgroups (tiles x slabs ~ 2048) to fill 256 CUs even when the weight is one tile,
 // at least 512 rows per slab, at most 4096 slabs
 static int pick_slabs(long R, int Cin, int Cout)
@@ -210,12 +210,11 @@ extern "C" int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)ws;
     conv1x1_wgrad_kernel<<<dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T), S), dim3(256), 0, st>>>(
-        dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin, Cout, rps, part);
+        dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin, Cout, rps, part, dbias ? part + (long)S * ((long)Cout * Cin) : nullptr);
     const long n = (long)Cout * Cin;
     launch_slab_reduce(part, n, S, accumulate, dW, st);
     if (dbias) {
         float *bpart = part + (long)S * n;
-        colsum_partial_kernel<<<dim3(ceil_div(Cout, 64), S), dim3(256), 0, st>>>(dY, lddy, R, Cout, rps, bpart);
         launch_slab_reduce(bpart, Cout, S, accumulate, dbias, st);
     }
     CASPR_CHECK_LAUNCH("conv1x1_wgrad");
