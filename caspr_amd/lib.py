@@ -41,6 +41,8 @@ SIGNATURES = {
     "caspr_cnf_rk4_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_float, c_int, c_int,
                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_stream]),
     "caspr_chamfer_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_stream]),
+    "caspr_emd_ws_bytes": (c_long, [c_int, c_int, c_int]),
+    "caspr_emd_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, ctypes.c_void_p, c_long, c_stream]),
     # ---- include/caspr_hip_train.h (training tier) ----
     "caspr_gn_stats_train_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, c_fp, c_fp,
                                          ctypes.c_void_p, c_long, c_stream]),

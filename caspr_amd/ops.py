@@ -287,3 +287,23 @@ def chamfer_distance(p, q):
     d2 = torch.empty(B, m, device=p.device, dtype=torch.float32)
     _lib.check(_lib.load().caspr_chamfer_f32(_p(p), _p(q), B, n, m, _p(d1), _p(d2), _stream()), "caspr_chamfer_f32")
     return d1, d2
+
+
+def earth_mover_distance(xyz1, xyz2, transpose=True):
+    """`utils.emd.earth_mover_distance` (emd.py:24-45): approximate EMD cost per cloud pair, (b,3,n) inputs when
+    `transpose` (as the reference), else (b,n,3).  -> (b,) ; evaluations.py:46 divides by the point count."""
+    if xyz1.dim() == 2:
+        xyz1 = xyz1.unsqueeze(0)
+    if xyz2.dim() == 2:
+        xyz2 = xyz2.unsqueeze(0)
+    if transpose:
+        xyz1, xyz2 = xyz1.transpose(1, 2), xyz2.transpose(1, 2)
+    xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+    _chk_f32(xyz1, xyz2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    cost = torch.empty(B, device=xyz1.device, dtype=torch.float32)
+    L = _lib.load()
+    ws = _workspace(L.caspr_emd_ws_bytes(B, n, m), xyz1.device)
+    _lib.check(L.caspr_emd_f32(_p(xyz1), _p(xyz2), B, n, m, _p(cost), _p(ws), ws.numel(), _stream()), "caspr_emd_f32")
+    return cost

@@ -2,8 +2,8 @@
 
 Metric side of BASELINE.json's headline ("sequences/sec + Chamfer-L2"): the paper's protocol evaluates 10 steps x 2048
 points, either all steps observed or steps [0,5,9] observed / [1,2,3,4,6,7,8] unobserved (evaluations.py:26-34), with
-Chamfer = mean_i min_j |p_i-g_j|^2 + mean_j min_i |.|^2 per frame (evaluations.py:36-44; printed x1000).  EMD
-(evaluations.py:46-47, PyTorchEMD) and the RANSAC pose eval are out of scope.
+Chamfer = mean_i min_j |p_i-g_j|^2 + mean_j min_i |.|^2 per frame (evaluations.py:36-44; printed x1000) and the
+approximate EMD / N (evaluations.py:45-46, caspr_emd_f32).  The RANSAC pose eval is out of scope.
 Differences from the reference, on purpose: bad protocol sizes raise ValueError instead of exit(); the inference
 timer synchronises the device (evaluations.py:108-115 does not)."""
 import time
@@ -21,10 +21,14 @@ SPLIT_OBSERVED_STEPS = [0, 5, 9]
 SPLIT_UNOBSERVED_STEPS = [1, 2, 3, 4, 6, 7, 8]
 
 
-def eval_reconstr_frames(pred, gt):
-    """evaluations.py:36-44 (Chamfer part): pred, gt (F,N,3) on the GPU -> per-frame Chamfer-L2 (F,) numpy."""
+def eval_reconstr_frames(pred, gt, with_emd=True):
+    """evaluations.py:36-49: pred, gt (F,N,3) on the GPU -> [per-frame Chamfer-L2 (F,), per-frame EMD / N (F,)] numpy."""
     dist1, dist2 = ops.chamfer_distance(pred.contiguous(), gt.contiguous())
-    return (torch.mean(dist1, dim=1) + torch.mean(dist2, dim=1)).cpu().numpy()
+    mean_dist = (torch.mean(dist1, dim=1) + torch.mean(dist2, dim=1)).cpu().numpy()
+    cur_emd = None
+    if with_emd:
+        cur_emd = (ops.earth_mover_distance(pred, gt, transpose=False) / pred.size(1)).cpu().numpy()
+    return [mean_dist, cur_emd]
 
 
 def _stats(values, scale=1.0):
@@ -38,7 +42,7 @@ def test_shape_recon(model, batches, device, observed_steps=ALL_OBSERVED_STEPS, 
     encoded, all steps are reconstructed at nocs_out's timestamps.  Returns chamfer x1000 statistics for observed /
     unobserved frames, mean NFE and mean inference time.  base_samples: optional list of (B,T,N,3) tensors (parity tests)."""
     model.eval()
-    obs, unobs, nfe, times = [], [], [], []
+    obs, unobs, nfe, times, obs_emd, unobs_emd = [], [], [], [], [], []
     for bi, (pcl_in, nocs_out) in enumerate(batches):
         pcl_in, nocs_out = pcl_in.to(device), nocs_out.to(device)
         B, T, N, _ = pcl_in.size()
@@ -56,12 +60,18 @@ def test_shape_recon(model, batches, device, observed_steps=ALL_OBSERVED_STEPS, 
         times.append(time.time() - t0)
         nfe.append(model.get_nfe())
         gt = nocs_out[:, observed_steps, :, :3].reshape(B * len(observed_steps), N, 3)
-        obs.extend(eval_reconstr_frames(pred_pcl[:, observed_steps].reshape(B * len(observed_steps), N, 3), gt).tolist())
+        cd, em = eval_reconstr_frames(pred_pcl[:, observed_steps].reshape(B * len(observed_steps), N, 3), gt)
+        obs.extend(cd.tolist())
+        obs_emd.extend(em.tolist())
         if len(unobserved_steps) > 0:
             gt = nocs_out[:, unobserved_steps, :, :3].reshape(B * len(unobserved_steps), N, 3)
-            unobs.extend(eval_reconstr_frames(pred_pcl[:, unobserved_steps].reshape(B * len(unobserved_steps), N, 3), gt).tolist())
+            cd, em = eval_reconstr_frames(pred_pcl[:, unobserved_steps].reshape(B * len(unobserved_steps), N, 3), gt)
+            unobs.extend(cd.tolist())
+            unobs_emd.extend(em.tolist())
     return {"observed_chamfer_x1000": _stats(obs, 1000.0), "unobserved_chamfer_x1000": _stats(unobs, 1000.0),
             "observed_chamfer": obs, "unobserved_chamfer": unobs,
+            "observed_emd_x1000": _stats(obs_emd, 1000.0), "unobserved_emd_x1000": _stats(unobs_emd, 1000.0),
+            "observed_emd": obs_emd, "unobserved_emd": unobs_emd,
             "nfe_mean": np.mean(nfe, axis=0).tolist() if nfe else None, "infer_time_mean": float(np.mean(times)) if times else None}
 
 

@@ -146,6 +146,14 @@ int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const floa
 int caspr_chamfer_f32(const float *p, const float *q, int B, int n, int m, float *dist1, float *dist2,
                       void *stream);
 
+/* ---------------- approximate EMD (utils/emd.py: emd_cuda approxmatch + matchcost; call site
+ * utils/evaluations.py:45) -- p (B,n,3), q (B,m,3) -> cost (B) = sum_{k,l} match[k,l] |p_k - q_l| with the
+ * 10-level annealed soft assignment of approxmatch (the caller divides by n, evaluations.py:46).
+ * ws >= caspr_emd_ws_bytes(B,n,m).                                                                   */
+long caspr_emd_ws_bytes(int B, int n, int m);
+int caspr_emd_f32(const float *xyz1, const float *xyz2, int B, int n, int m, float *cost, void *ws,
+                  long ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -485,3 +485,29 @@ def chamfer_l2(pred, gt):
     """utils/evaluations.py:40-43: mean_i min_j + mean_j min_i of squared distances, per frame."""
     d1, d2 = P.chamfer(pred, gt)
     return d1.mean(dim=1) + d2.mean(dim=1)
+
+
+def approx_emd(xyz1, xyz2):
+    """utils/emd.py:5-45 -> emd_cuda.approxmatch_forward + matchcost_forward.  emd_cuda (PyTorchEMD, no pin,
+    README.md:33-38) is NOT under /root/reference: this restates its published algorithm (approxmatch of Fan et al.,
+    "A Point Set Generation Network") -- parity unpinned, the restatement defines the contract.
+    xyz1 (B,n,3), xyz2 (B,m,3) -> cost (B) = sum_{k,l} match[k,l] * |p_k - q_l|."""
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d2 = ((xyz1[:, :, None, :] - xyz2[:, None, :, :]) ** 2).sum(-1)              # (B,n,m)
+    dist = d2.sqrt()
+    multiL, multiR = (1.0, float(n // m)) if n >= m else (float(m // n), 1.0)
+    remainL = torch.full((B, n), multiL, dtype=xyz1.dtype)
+    remainR = torch.full((B, m), multiR, dtype=xyz1.dtype)
+    cost = torch.zeros(B, dtype=xyz1.dtype)
+    for j in range(7, -3, -1):
+        level = 0.0 if j == -2 else -(4.0 ** j)
+        K = torch.exp(level * d2)
+        ratioL = remainL / (1e-9 + (K * remainR[:, None, :]).sum(2))
+        sumr = (K * ratioL[:, :, None]).sum(1) * remainR
+        ratioR = torch.clamp(remainR / (sumr + 1e-9), max=1.0) * remainR
+        remainR = torch.clamp(remainR - sumr, min=0.0)
+        inc = K * ratioL[:, :, None] * ratioR[:, None, :]                        # this level's addition to the match matrix
+        cost = cost + (inc * dist).sum((1, 2))
+        remainL = torch.clamp(remainL - inc.sum(2), min=0.0)
+    return cost

@@ -509,6 +509,8 @@ def test_eval_protocols_vs_oracle(dev, seeded_sd, model):
     record("eval_chamfer_observed", torch.tensor(res["observed_chamfer"]), want_obs, 1e-5 * max(1.0, float(want_obs.max())))
     record("eval_chamfer_unobserved", torch.tensor(res["unobserved_chamfer"]), want_un, 1e-5 * max(1.0, float(want_un.max())))
     assert res["nfe_mean"] == [4 * 4 * 9, 32] and res["infer_time_mean"] > 0
+    want_emd = O.approx_emd(wx[0, E.SPLIT_UNOBSERVED_STEPS].double(), sp[0, E.SPLIT_UNOBSERVED_STEPS, :, :3].double()) / 2048   # evaluations.py:45-46
+    record("eval_emd_unobserved", torch.tensor(res["unobserved_emd"]), want_emd, 1e-4 * float(want_emd.max()))
     tn = E.test_tnocs_regression(model, [(x, sp)], dev)
     _, wt = O.encode(seeded_sd, x)
     want_space = torch.mean(torch.norm(wt[..., :3] - sp[..., :3], dim=3), dim=2).mean()
@@ -592,3 +594,22 @@ def test_full_size_properties(dev, model):
     exact("shard_invariance_tnocs", ta[2:], tb)
     assert torch.isfinite(xa).all() and float(ta.min()) > 0.0 and float(ta.max()) < 1.0
     assert [int(v) for v in model.get_nfe()] == [4 * 4 * 9, 32]
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 512, 512), (2, 300, 512), (2, 1024, 256), (1, 2048, 2048)])
+def test_emd_matches_oracle(ops, dev, B, n, m):
+    """Approximate EMD (utils/emd.py, evaluations.py:45-46) vs the oracle's restatement of approxmatch + matchcost, f64.
+    Also the metric's basic properties: zero-ish for identical clouds, symmetric under swapping equal-size clouds."""
+    g = np.random.default_rng(n + m)
+    p = torch.from_numpy(g.uniform(0, 1, (B, n, 3)).astype(np.float32))
+    q = torch.from_numpy(g.uniform(0, 1, (B, m, 3)).astype(np.float32))
+    want = O.approx_emd(p.double(), q.double())
+    got = ops.earth_mover_distance(p.to(dev), q.to(dev), transpose=False)
+    err = float(((got.cpu().double() - want) / want).abs().max())
+    REPORT["emd[%d,%d]" % (n, m)] = {"max_rel_err": err, "tol": 1e-4, "cost_per_point": float((want / n).mean())}
+    assert err <= 1e-4, "EMD rel err %.3e" % err
+    # reference call shape: (b,3,n) with transpose=True (emd.py:24)
+    got_t = ops.earth_mover_distance(p.transpose(1, 2).to(dev), q.transpose(1, 2).to(dev))
+    assert torch.equal(got_t, got)
+    same = ops.earth_mover_distance(p.to(dev), p.to(dev), transpose=False) / n
+    assert float(same.max()) < 0.05 * float((want / n).min()) + 1e-3
