@@ -291,6 +291,51 @@ def main():
     for k in gr:
         g["train_pre_grad:" + k], g["train_pre_delta:" + k] = gr[k].numpy(), dl[k].numpy()
 
+    # ---- 6. the reference's Dataset class on a tiny synthetic tree (caspr_dataset.py:211-349): split logic, item
+    # tuples, numpy-RNG call order.  The tree itself is stored (frame arrays), tests rebuild it anywhere. -----------
+    from data.caspr_dataset import DynamicPCLDataset as RefDataset
+    rng = np.random.default_rng(91)
+    n_models, n_seqs, n_frames, exp_pts = 5, 2, 3, 64
+    with tempfile.TemporaryDirectory() as td:
+        root = os.path.join(td, "toy")
+        for mi in range(n_models):
+            for si in range(n_seqs):
+                d = os.path.join(root, "model%02d" % mi, "seq_%08d" % si)
+                os.makedirs(d)
+                for fi in range(n_frames):
+                    npts = int(rng.integers(40, exp_pts + 1))
+                    fr = {"nocs_data": rng.uniform(0.1, 0.9, (npts, 3)), "depth_data": rng.normal(0, 1, (npts, 3)), "obj_T": rng.normal(0, 1, (4, 4))}
+                    np.savez(os.path.join(d, "frame_%08d.npz" % fi), **fr)
+                    for key, val in fr.items():
+                        g["ds_in_%d_%d_%d_%s" % (mi, si, fi, key)] = val
+        cfg = os.path.join(td, "toy.cfg")
+        with open(cfg, "w") as f:
+            f.write("--data %s\n--max-timestamp 2.0\n--expected-num-pts %d\n--expected-seq-len %d" % (root, exp_pts, n_frames))
+        sdir = os.path.join(td, "splits")
+        os.makedirs(sdir)
+        with open(os.path.join(sdir, "val_split.txt"), "w") as f:
+            f.write("model03\nmodel01\nmissing_model\n")
+        cfg2 = os.path.join(td, "toy_splits.cfg")
+        with open(cfg2, "w") as f:
+            f.write("--data %s\n--splits %s\n--max-timestamp 2.0\n--expected-num-pts %d\n--expected-seq-len %d" % (root, sdir, exp_pts, n_frames))
+        for split in ("train", "val", "test"):
+            ds = RefDataset(cfg, split=split, train_frac=0.6, val_frac=0.2, num_pts=32, seq_len=2, random_point_sample=False)
+            g["ds_ids_" + split] = np.array(["/".join(p[0].split("/")[-3:-1]) for p in ds.seq_data_paths])
+        ds = RefDataset(cfg2, split="val", num_pts=32, seq_len=2, random_point_sample=False)
+        g["ds_ids_splitfile_val"] = np.array(["/".join(p[0].split("/")[-3:-1]) for p in ds.seq_data_paths])
+        ds.set_return_first_steps(True)
+        ds.set_return_pose_data(True)
+        (a, b), pose, mid, sid = ds[1]
+        g["ds_first_in"], g["ds_first_out"], g["ds_first_pose"], g["ds_first_ids"] = a.numpy(), b.numpy(), pose, np.array([mid, sid])
+        ds = RefDataset(cfg, split="train", train_frac=0.6, val_frac=0.2, num_pts=24, seq_len=2, shift_time_to_zero=True, random_point_sample=True)
+        np.random.seed(5)
+        (a, b), mid, sid = ds[3]
+        g["ds_rand_in"], g["ds_rand_out"], g["ds_rand_ids"] = a.numpy(), b.numpy(), np.array([mid, sid])
+        ds = RefDataset(cfg, split="test", train_frac=0.6, val_frac=0.2, num_pts=16, seq_len=3, random_point_sample=False, random_point_sample_per_step=True)
+        np.random.seed(6)
+        (a, b), mid, sid = ds[0]
+        g["ds_perstep_in"], g["ds_perstep_out"] = a.numpy(), b.numpy()
+
     out_path = os.path.join(HERE, "reference_golden.npz")
     np.savez_compressed(out_path, **g)
     print("wrote", out_path, os.path.getsize(out_path) // 1024, "KiB;", len(g), "arrays")

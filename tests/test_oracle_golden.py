@@ -1,6 +1,7 @@
 """The CPU oracle (oracle/model.py + oracle/point_ops.c) against fixtures produced by the REAL
 reference modules (tests/golden/gen_golden.py, run where /root/reference exists).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import model as O
@@ -205,3 +206,59 @@ def test_oracle_training_step_matches_reference_gradients(golden, seeded_sd):
         assert err <= (2e-3 if name.endswith("sqrt_end_time") else 1e-5), "%s: rel L2 %.3e" % (name, err)
         n += 1
     assert n >= 18
+
+
+def _rebuild_toy_dataset(golden, td):
+    import os
+    root = os.path.join(td, "toy")
+    keys = [k for k in golden.files if k.startswith("ds_in_") and k.endswith("_nocs_data")]
+    for k in keys:
+        mi, si, fi = (int(v) for v in k.split("_")[2:5])
+        d = os.path.join(root, "model%02d" % mi, "seq_%08d" % si)
+        os.makedirs(d, exist_ok=True)
+        pre = "ds_in_%d_%d_%d_" % (mi, si, fi)
+        np.savez(os.path.join(d, "frame_%08d.npz" % fi), nocs_data=golden[pre + "nocs_data"], depth_data=golden[pre + "depth_data"], obj_T=golden[pre + "obj_T"])
+    cfg = os.path.join(td, "toy.cfg")
+    with open(cfg, "w") as f:
+        f.write("--data %s\n--max-timestamp 2.0\n--expected-num-pts 64\n--expected-seq-len 3" % root)
+    sdir = os.path.join(td, "splits")
+    os.makedirs(sdir)
+    with open(os.path.join(sdir, "val_split.txt"), "w") as f:
+        f.write("model03\nmodel01\nmissing_model\n")
+    cfg2 = os.path.join(td, "toy_splits.cfg")
+    with open(cfg2, "w") as f:
+        f.write("--data %s\n--splits %s\n--max-timestamp 2.0\n--expected-num-pts 64\n--expected-seq-len 3" % (root, sdir))
+    return cfg, cfg2
+
+
+def test_dataset_class_matches_reference(golden, tmp_path):
+    """caspr_amd.data.DynamicPCLDataset against the REAL reference class run on the same toy tree (gen_golden.py section 6):
+    fraction and split-file splits, first-steps / first-points items with pose data, seeded random step + point
+    sampling with shift_time_to_zero (same numpy RNG call order), per-step point sampling."""
+    from caspr_amd.data.caspr_dataset import DynamicPCLDataset
+    cfg, cfg2 = _rebuild_toy_dataset(golden, str(tmp_path))
+    ids = lambda ds: ["/".join(p[0].split("/")[-3:-1]) for p in ds.seq_data_paths]
+    for split in ("train", "val", "test"):
+        ds = DynamicPCLDataset(cfg, split=split, train_frac=0.6, val_frac=0.2, num_pts=32, seq_len=2, random_point_sample=False)
+        assert ids(ds) == [str(v) for v in golden["ds_ids_" + split]], split
+        assert len(ds) == len(golden["ds_ids_" + split])
+    ds = DynamicPCLDataset(cfg2, split="val", num_pts=32, seq_len=2, random_point_sample=False)
+    assert ids(ds) == [str(v) for v in golden["ds_ids_splitfile_val"]]
+    ds.set_return_first_steps(True)
+    ds.set_return_pose_data(True)
+    (a, b), pose, mid, sid = ds[1]
+    assert np.array_equal(a.numpy(), golden["ds_first_in"]) and np.array_equal(b.numpy(), golden["ds_first_out"])
+    assert np.array_equal(pose, golden["ds_first_pose"]) and [mid, sid] == [str(v) for v in golden["ds_first_ids"]]
+    ds = DynamicPCLDataset(cfg, split="train", train_frac=0.6, val_frac=0.2, num_pts=24, seq_len=2, shift_time_to_zero=True, random_point_sample=True)
+    np.random.seed(5)
+    (a, b), mid, sid = ds[3]
+    assert np.array_equal(a.numpy(), golden["ds_rand_in"]) and np.array_equal(b.numpy(), golden["ds_rand_out"])
+    assert [mid, sid] == [str(v) for v in golden["ds_rand_ids"]]
+    ds = DynamicPCLDataset(cfg, split="test", train_frac=0.6, val_frac=0.2, num_pts=16, seq_len=3, random_point_sample=False, random_point_sample_per_step=True)
+    np.random.seed(6)
+    (a, b), _, _ = ds[0]
+    assert np.array_equal(a.numpy(), golden["ds_perstep_in"]) and np.array_equal(b.numpy(), golden["ds_perstep_out"])
+    with pytest.raises(ValueError):
+        DynamicPCLDataset(cfg, split="nope")
+    with pytest.raises(FileNotFoundError):
+        DynamicPCLDataset(cfg2, split="train")      # no train_split.txt in the split directory
