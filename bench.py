@@ -105,7 +105,8 @@ def main():
         # ---- roofline of the dominant kernel (cnf_rk4_kernel), HIP events recorded on the launch stream
         ev = ops.TIMERS.get("cnf_rk4", [])
         cnf_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-        flop = float((hi - lo) * T * N) * 4 * args.cnf_steps * CNF_FLOP_PER_POINT_EVAL
+        launches_per_step = max(len(ev) // max(args.steps, 1), 1)      # reconstruct() runs the batch as two halves (one CNF launch each)
+        flop = float((hi - lo) * T * N) * 4 * args.cnf_steps * CNF_FLOP_PER_POINT_EVAL / launches_per_step
         achieved = flop / (cnf_ms * 1e-3) / 1e12 if cnf_ms > 0 else 0.0
         # HBM traffic per launch cannot be counted from inside this process: it is taken from the committed PMC pass
         # of this same command and workload (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, gfx950 correction).

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(512) void latent_rk4_kernel(const float *__restrict
         const float r0 = times[ti - 1] - t_first, r1 = times[ti] - t_first;  // latent_ode_model.py:58
         const double h = ((double)r1 - (double)r0) / (double)steps;
         const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
-        for (int s = 0; s < steps; ++s) {
+        // a repeated time stamp (the host may pass the sorted, NOT de-duplicated times of a whole batch so that it never
+        // has to synchronise on torch.unique's data-dependent size) is a zero-length interval: the state is unchanged
+        for (int s = 0; s < (r1 != r0 ? steps : 0); ++s) {
             write_in(0.f, nullptr);
             dyn();
             for (int i = tid; i < 64 * LAT_NCOL; i += 512) s_acc[i] = s_k[i];

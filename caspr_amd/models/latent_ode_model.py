@@ -57,6 +57,23 @@ class LatentODE(nn.Module):
         self.ode_func._num_evals += 4 * self.rk4_steps * max(Tu - 1, 0)
         return out
 
+    def solve_at(self, z0, time_tensor):
+        """z(t) for every entry of time_tensor (B,T) [any order, repeats allowed] -> (B,T,H), without a host
+        synchronisation: the reference takes torch.unique of the times (caspr.py:166), whose output size is
+        data-dependent; here ALL B*T stamps are sorted on the device and handed to the kernel, which skips the
+        zero-length intervals between repeated stamps -- the same integration steps, the same values."""
+        B, T = time_tensor.shape
+        flat = time_tensor.reshape(-1).float()
+        sorted_t, perm = torch.sort(flat, stable=True)
+        pos = torch.empty_like(perm)
+        pos[perm] = torch.arange(perm.numel(), device=perm.device)
+        self.ode_func._num_evals.fill_(0)
+        out = ops.latent_rk4(z0, sorted_t.contiguous(), self.rk4_steps, self._weights())       # (B, B*T, H)
+        distinct = (sorted_t[1:] != sorted_t[:-1]).sum()
+        self.ode_func._num_evals.copy_(4.0 * self.rk4_steps * distinct)                         # evaluations actually run
+        rows = torch.arange(B, device=z0.device).view(-1, 1).expand(B, T)
+        return out[rows, pos.view(B, T), :]
+
     def num_evals(self):
         return self.ode_func._num_evals.item()
 

@@ -613,3 +613,31 @@ def test_emd_matches_oracle(ops, dev, B, n, m):
     assert torch.equal(got_t, got)
     same = ops.earth_mover_distance(p.to(dev), p.to(dev), transpose=False) / n
     assert float(same.max()) < 0.05 * float((want / n).min()) + 1e-3
+
+
+def test_two_half_schedule_is_bit_identical(dev, seeded_sd):
+    """CaSPR.reconstruct's opt-in two-half schedule (latent ODE of one half on a side stream under the other half's
+    kernels, index chain launched once for all frames) and the synchronisation-free latent path return exactly the
+    tensors of the plain schedule -- repeated / unsorted time stamps included."""
+    from caspr_amd.models import CaSPR
+    m = CaSPR(cnf_rk4_steps=2, latent_rk4_steps=2)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    x, sp = dense_sequences(4, 3, 1024, seed=31)
+    yb = torch.randn(4, 3, 128, 3)
+    ts = torch.tensor([0.0, 0.4, 1.0])
+    ref = m.reconstruct(x.to(dev), num_points=128, timestamps=ts.to(dev), y=yb.to(dev))
+    m.pipeline_min_chunk = 2
+    got = m.reconstruct(x.to(dev), num_points=128, timestamps=ts.to(dev), y=yb.to(dev))
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert m.get_nfe().tolist() == [4 * 2 * 2, 8]
+    # latent path alone: unsorted stamps with repeats across the batch vs torch.unique + the sorted solve
+    z0 = torch.randn(3, 1600, device=dev)
+    tt = torch.tensor([[0.5, 0.0, 0.5, 1.0], [1.0, 0.25, 0.0, 0.25], [0.0, 0.0, 1.0, 0.5]], device=dev)
+    a = m.aggregate_and_solve_latent(z0, tt)
+    solve_t, tmap = torch.unique(tt, sorted=True, return_inverse=True)
+    pred = m.gen_latent(z0[:, :64], solve_t)
+    b = torch.cat([pred[torch.arange(3, device=dev).view(-1, 1), tmap], z0[:, 64:].unsqueeze(1).expand(3, 4, 1536)], dim=2)
+    assert torch.equal(a, b)
+    assert m.get_nfe()[0] == 4 * 2 * (solve_t.numel() - 1)
