@@ -10,6 +10,8 @@ Training: in train() mode with grad enabled `forward` is differentiable end to e
 with a HIP backward (caspr_amd/train/encoder_grad.py), the latent ODE and the CNF through the discrete RK4 map with
 every matrix product on the HIP kernels (caspr_amd/train/flow_grad.py).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -222,11 +224,10 @@ class CaSPR(nn.Module):
             tnocs_pred = None if enc[0] is None else torch.cat(enc, dim=0)
             return y_out, logp_y, x_out, tnocs_pred
 
-    import os as _os
     # Two-half schedule: off by default.  Measured at cfg-2 (B=16): 130.1 ms/step with it (min chunk 4) vs 131.1 without --
     # the ~3.9 ms latent ODE disappears under the other half, but the half-size encoder / CNF launches lose 2.6 ms to
     # their tails and the dominant kernel drops from 0.863 to 0.856 of the MFMA peak.  CASPR_PIPELINE_MIN_CHUNK=4 turns it on.
-    pipeline_min_chunk = int(_os.environ.get("CASPR_PIPELINE_MIN_CHUNK", str(1 << 30)))
+    pipeline_min_chunk = int(os.environ.get("CASPR_PIPELINE_MIN_CHUNK", str(1 << 30)))
 
     def _latent_stream(self, device):
         key = (device.type, device.index)
