@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--cnf-steps", type=int, default=8)
     ap.add_argument("--latent-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calibrate-cnf-steps", type=float, default=0.0, metavar="TOL",
+                    help="choose the CNF step count by step doubling at this tolerance (CaSPR.calibrate_rk4_steps) instead of --cnf-steps; "
+                         "off by default: the headline number is quoted at the fixed, conservative 8 steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,6 +79,9 @@ def main():
     ts = sp_all[0, :, 0, 3].to(dev)
     torch.manual_seed(rank)
     ybase = torch.randn(hi - lo, T, N, 3).to(dev)        # base samples (models/utils.py:25), resident before timing
+
+    if args.calibrate_cnf_steps > 0:
+        args.cnf_steps, _diffs = model.calibrate_rk4_steps(x, tol=args.calibrate_cnf_steps, timestamps=ts)
 
     def step():
         return model.reconstruct(x, num_points=N, timestamps=ts, y=ybase)

@@ -227,6 +227,33 @@ class CaSPR(nn.Module):
     # Two-half schedule: off by default.  Measured at cfg-2 (B=16): 130.1 ms/step with it (min chunk 4) vs 131.1 without --
     # the ~3.9 ms latent ODE disappears under the other half, but the half-size encoder / CNF launches lose 2.6 ms to
     # their tails and the dominant kernel drops from 0.863 to 0.856 of the MFMA peak.  CASPR_PIPELINE_MIN_CHUNK=4 turns it on.
+    def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16), num_points=512, timestamps=None, max_timestamp=5.0):
+        """Pick the CNF's fixed RK4 step count the way an adaptive solver picks its step: by an error estimate on the
+        actual weights and input.  Decodes the first sequence of `x` with S and 2S steps (same base samples) for each
+        candidate S and keeps the smallest S whose step-doubling difference max|x_S - x_2S| (= 15/16 of the S-step
+        error for a 4th-order method) is <= tol.  Sets `rk4_steps` on every CNF block; returns (S, {S: difference}).
+        The reference's dopri5 runs at atol = rtol = 1e-5 (flow.py:96-99); the default of this build (8 steps) is kept
+        unless this is called."""
+        from .cnf import CNF
+        blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
+        with torch.no_grad():
+            xs = x[:1]
+            z0, _ = self.encode(xs)
+            times = xs[:, :, 0, 3] / max_timestamp if timestamps is None else timestamps.view(1, -1).to(xs)
+            z = self.aggregate_and_solve_latent(z0, times)
+            y = torch.randn(1, z.shape[1], num_points, self.cnf_args.input_dim, device=x.device)
+            sols = {}
+            for S in sorted(set(candidates) | {2 * c for c in candidates}):
+                for b in blocks:
+                    b.rk4_steps = S
+                sols[S] = self.decode(z, num_points, y=y)[2]
+            diffs = {S: float((sols[S] - sols[2 * S]).abs().max()) for S in candidates}
+        chosen = next((S for S in sorted(candidates) if diffs[S] <= tol), max(candidates))
+        for b in blocks:
+            b.rk4_steps = chosen
+        self.cnf_args.rk4_steps = chosen
+        return chosen, diffs
+
     pipeline_min_chunk = int(os.environ.get("CASPR_PIPELINE_MIN_CHUNK", str(1 << 30)))
 
     def _latent_stream(self, device):

@@ -641,3 +641,23 @@ def test_two_half_schedule_is_bit_identical(dev, seeded_sd):
     b = torch.cat([pred[torch.arange(3, device=dev).view(-1, 1), tmap], z0[:, 64:].unsqueeze(1).expand(3, 4, 1536)], dim=2)
     assert torch.equal(a, b)
     assert m.get_nfe()[0] == 4 * 2 * (solve_t.numel() - 1)
+
+
+def test_calibrate_rk4_steps(dev, seeded_sd):
+    """Step-doubling calibration of the CNF step count: the differences fall ~16x per doubling (4th order), the chosen
+    count meets the tolerance, and the result at the chosen count is within the tolerance of a 32-step solve."""
+    from caspr_amd.models import CaSPR
+    m = CaSPR()
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    x, sp = dense_sequences(1, 3, 1024, seed=41)
+    chosen, diffs = m.calibrate_rk4_steps(x.to(dev), tol=1e-6)
+    REPORT["calibrate_rk4"] = {"chosen": chosen, "diffs": {str(k): v for k, v in diffs.items()}}
+    assert diffs[chosen] <= 1e-6 and all(diffs[s] > 1e-6 for s in diffs if s < chosen)
+    assert diffs[1] > 4 * diffs[2] or diffs[1] < 1e-6
+    assert m.point_cnf.chain[1].rk4_steps == chosen
+    yb = torch.randn(1, 3, 256, 3)
+    a = m.reconstruct(x.to(dev), num_points=256, y=yb.to(dev))[2]
+    m.point_cnf.chain[1].rk4_steps = 32
+    b = m.reconstruct(x.to(dev), num_points=256, y=yb.to(dev))[2]
+    record("calibrated_vs_32_steps", a, b, 2e-6)
