@@ -661,3 +661,24 @@ def test_calibrate_rk4_steps(dev, seeded_sd):
     m.point_cnf.chain[1].rk4_steps = 32
     b = m.reconstruct(x.to(dev), num_points=256, y=yb.to(dev))[2]
     record("calibrated_vs_32_steps", a, b, 2e-6)
+
+
+def test_hip_graph_replay_is_bit_identical(dev, seeded_sd):
+    """The whole reconstruct() -- encoder side stream included -- captures into one hipGraph (no host synchronisation,
+    no data-dependent shape on the path) and replays bit-identically, also on new inputs written to the static buffers."""
+    from caspr_amd.models import CaSPR
+    from caspr_amd.utils.graphs import GraphedReconstruct
+    m = CaSPR(cnf_rk4_steps=2)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    x, sp = dense_sequences(2, 3, 1024, seed=51)
+    x2, _ = dense_sequences(2, 3, 1024, seed=52)
+    ts = sp[0, :, 0, 3].to(dev)
+    g = GraphedReconstruct(m, x.to(dev), 256, ts)
+    for xi, seed in ((x, 1), (x2, 2), (x, 3)):
+        torch.manual_seed(seed)
+        y = torch.randn(2, 3, 256, 3, device=dev)
+        want = m.reconstruct(xi.to(dev), num_points=256, timestamps=ts, y=y)
+        got = g(xi.to(dev), y)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(want, got))
