@@ -97,3 +97,123 @@ extern "C" int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, co
     CASPR_CHECK_LAUNCH("cnf_act_bwd");
     return CASPR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// First layer of the ODE function (3 -> C, diffeq_layers.py:83-90) fused with its gate + softplus, on value and
+// tangent rows:  zv = W0 y + b0,  zt = W0 e;  H as in cnf_act.  K = 3, so the matrix product is three FMAs per output
+// and the layer is a pure streaming write of H (2R x C): no GEMM pass, no stored pre-activation.
+// Backward recomputes zv, zt from (y, e) and emits, per (frame, 64-channel chunk) workgroup in a fixed order:
+//   dgate, dbeta (frame, C);  dW0 partials (frame, C, 3) = sum_p dzv*y + dzt*e;  dy partials (chunk, R, 3) = sum_c dzv*W0
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cnf_in_fwd_kernel(const float *__restrict__ Yp, const float *__restrict__ E,
+                                                         const float *__restrict__ W0, const float *__restrict__ b,
+                                                         const float *__restrict__ gate, const float *__restrict__ beta,
+                                                         long R, int n, int C, float *__restrict__ H)
+{
+    const int C4 = C >> 2;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R * C4) return;
+    const long r = t / C4;
+    const int c = (int)(t % C4) * 4;
+    const long f = r / n;
+    const float y0 = Yp[r * 3], y1 = Yp[r * 3 + 1], y2 = Yp[r * 3 + 2];
+    const float e0 = E[r * 3], e1 = E[r * 3 + 1], e2 = E[r * 3 + 2];
+    const f32x4 bb = ld4(b + c), g = ld4(gate + f * C + c), be = ld4(beta + f * C + c);
+    f32x4 hv, ht;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float *w = W0 + (long)(c + q) * 3;
+        const float zv = (w[0] * y0 + w[1] * y1) + w[2] * y2;
+        const float zt = (w[0] * e0 + w[1] * e1) + w[2] * e2;
+        const float a = (zv + bb[q]) * g[q] + be[q];
+        hv[q] = softplus_f(a);
+        ht[q] = sigmoid_f(a) * (zt * g[q]);
+    }
+    st4(H + r * C + c, hv);
+    st4(H + (R + r) * C + c, ht);
+}
+
+__global__ __launch_bounds__(256) void cnf_in_bwd_kernel(const float *__restrict__ Yp, const float *__restrict__ E,
+                                                         const float *__restrict__ W0, const float *__restrict__ b,
+                                                         const float *__restrict__ gate, const float *__restrict__ beta,
+                                                         const float *__restrict__ dH, long R, int n, int C,
+                                                         float *__restrict__ dgate, float *__restrict__ dbeta,
+                                                         float *__restrict__ dW0p, float *__restrict__ dYp)
+{
+    __shared__ float s_red[4][64][8];
+    const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, c = chunk * 64 + cl;
+    const long f = blockIdx.y;
+    const bool ok = c < C;
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f, bb = 0.f, g = 0.f, be = 0.f;
+    if (ok) { w0 = W0[(long)c * 3]; w1 = W0[(long)c * 3 + 1]; w2 = W0[(long)c * 3 + 2]; bb = b[c]; g = gate[f * C + c]; be = beta[f * C + c]; }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dgate, dbeta, dW0[0..2] (value part), dW0[0..2] (tangent part)
+    for (int p = sub; p < n; p += 4) {
+        const long r = f * n + p;
+        const float y0 = Yp[r * 3], y1 = Yp[r * 3 + 1], y2 = Yp[r * 3 + 2];
+        const float e0 = E[r * 3], e1 = E[r * 3 + 1], e2 = E[r * 3 + 2];
+        float dzv = 0.f;
+        if (ok) {
+            const float zv = (w0 * y0 + w1 * y1) + w2 * y2, zt = (w0 * e0 + w1 * e1) + w2 * e2;
+            const float a = (zv + bb) * g + be, ad = zt * g;
+            const float s = sigmoid_f(a);
+            const float dhv = dH[r * C + c], dht = dH[(R + r) * C + c];
+            const float da = dhv * s + dht * (s * (1.0f - s)) * ad;
+            const float dad = dht * s;
+            dzv = da * g;
+            const float dzt = dad * g;
+            acc[0] += da * (zv + bb) + dad * zt;
+            acc[1] += da;
+            acc[2] += dzv * y0; acc[3] += dzv * y1; acc[4] += dzv * y2;
+            acc[5] += dzt * e0; acc[6] += dzt * e1; acc[7] += dzt * e2;
+        }
+        // dy[p][j] = sum over this chunk's 64 channels of dzv * W0[c][j]: wave reduction (the tangent rows carry e, a constant)
+        float d0 = dzv * w0, d1 = dzv * w1, d2 = dzv * w2;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            d0 += __shfl_xor(d0, m, 64);
+            d1 += __shfl_xor(d1, m, 64);
+            d2 += __shfl_xor(d2, m, 64);
+        }
+        if (cl == 0) {
+            float *o = dYp + ((long)chunk * R + r) * 3;
+            o[0] = d0; o[1] = d1; o[2] = d2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_red[sub][cl][k] = acc[k];
+    __syncthreads();
+    if (sub == 0 && ok) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (s_red[0][cl][k] + s_red[1][cl][k]) + (s_red[2][cl][k] + s_red[3][cl][k]);
+        dgate[f * C + c] = t[0];
+        dbeta[f * C + c] = t[1];
+        float *o = dW0p + (f * C + c) * 3;
+        o[0] = t[2] + t[5]; o[1] = t[3] + t[6]; o[2] = t[4] + t[7];
+    }
+}
+
+extern "C" int caspr_cnf_in_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
+                                const float *beta, long R, int n, int C, float *H, void *stream)
+{
+    CASPR_REQUIRE(Y && E && W0 && b && gate && beta && H && R > 0 && n > 0 && R % n == 0 && C > 0 && C % 4 == 0, "cnf_in: bad arguments");
+    const long total = R * (C / 4);
+    cnf_in_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, R, n, C, H);
+    CASPR_CHECK_LAUNCH("cnf_in");
+    return CASPR_OK;
+}
+
+extern "C" int caspr_cnf_in_bwd_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
+                                    const float *beta, const float *dH, long R, int n, int C, float *dgate, float *dbeta,
+                                    float *dW0_part, float *dY_part, void *stream)
+{
+    CASPR_REQUIRE(Y && E && W0 && b && gate && beta && dH && dgate && dbeta && dW0_part && dY_part && R > 0 && n > 0 && R % n == 0 && C > 0,
+                  "cnf_in_bwd: bad arguments");
+    const long frames = R / n;
+    CASPR_REQUIRE(frames <= 65535, "cnf_in_bwd: %ld frames > 65535", frames);
+    cnf_in_bwd_kernel<<<dim3(ceil_div(C, 64), (unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, dH, R, n, C,
+                                                                                                      dgate, dbeta, dW0_part, dY_part);
+    CASPR_CHECK_LAUNCH("cnf_in_bwd");
+    return CASPR_OK;
+}

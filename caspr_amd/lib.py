@@ -63,6 +63,8 @@ SIGNATURES = {
                                   c_stream]),
     "caspr_cnf_act_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_cnf_act_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_long, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_stream]),
+    "caspr_cnf_in_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_fp, c_stream]),
+    "caspr_cnf_in_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_stream]),
     "caspr_gn_rows_bwd_ws_bytes": (c_long, [c_int]),
     "caspr_gn_rows_bwd_f32": (c_int, [c_fp, c_int, c_long, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_ip,
                                       c_fp, c_int, c_fp, c_fp, c_int, ctypes.c_void_p, c_long, c_stream]),

@@ -123,6 +123,41 @@ class CnfAct(torch.autograd.Function):
         return dz, db, dgate, dbeta, None
 
 
+class CnfIn(torch.autograd.Function):
+    """First ODE-function layer (3 -> C) fused with gate + softplus on value / tangent rows
+    (caspr_cnf_in_f32 / caspr_cnf_in_bwd_f32).  y, e (R,3); w0 (C,3); b0 (C); gate / beta (frames, C) -> h (2R, C)."""
+
+    @staticmethod
+    def forward(ctx, y, e, w0, b0, gate, beta, n):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        if not y.is_cuda:
+            raise ValueError("CnfIn runs on the GPU only (HIP kernels)")
+        R, C = y.shape[0], w0.shape[0]
+        y, e = y.detach().contiguous(), e.detach().contiguous()
+        w0, b0, gate, beta = w0.detach().contiguous(), b0.detach().contiguous(), gate.detach().contiguous(), beta.detach().contiguous()
+        h = torch.empty(2 * R, C, device=y.device, dtype=torch.float32)
+        _lib.check(_lib.load().caspr_cnf_in_f32(_p(y), _p(e), _p(w0), _p(b0), _p(gate), _p(beta), R, n, C, _p(h), _stream()), "caspr_cnf_in_f32")
+        ctx.save_for_backward(y, e, w0, b0, gate, beta)
+        ctx.n = n
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        y, e, w0, b0, gate, beta = ctx.saved_tensors
+        R, C = y.shape[0], w0.shape[0]
+        frames, chunks = R // ctx.n, (C + 63) // 64
+        dh = dh.contiguous()
+        dgate, dbeta = torch.empty_like(gate), torch.empty_like(beta)
+        dw_part = torch.empty(frames, C, 3, device=y.device, dtype=torch.float32)
+        dy_part = torch.empty(chunks, R, 3, device=y.device, dtype=torch.float32)
+        _lib.check(_lib.load().caspr_cnf_in_bwd_f32(_p(y), _p(e), _p(w0), _p(b0), _p(gate), _p(beta), _p(dh), R, ctx.n, C, _p(dgate), _p(dbeta),
+                                                    _p(dw_part), _p(dy_part), _stream()), "caspr_cnf_in_bwd_f32")
+        return dy_part.sum(dim=0), None, dw_part.sum(dim=0), (gate * dbeta).sum(dim=0), dgate, dbeta, None
+
+
 # ---------------------------------------------------------------------------------------------
 # latent ODE (latent_ode_model.py:45-70,139-147): z' = MLP_tanh(z), classic RK4, `steps` per requested interval
 # ---------------------------------------------------------------------------------------------
@@ -174,11 +209,14 @@ def cnf_block_train(block, x, context, logpx, e):
 
     def func(t, y, _lp):
         R = BT * n
-        h = torch.cat([y.reshape(R, 3), e_rows], dim=0)                   # value rows | tangent rows
+        h = None
         for i, l in enumerate(layers):
-            z = linear_rows(h, l._layer.weight, None)
             gate = torch.sigmoid(G[i] + t * tg[i])                        # (BT,C): context part + time column
             bias = Bb[i] + t * tb[i]
+            if i == 0:                                                    # 3 -> C: fused product + gate + softplus, value | tangent rows
+                h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n)
+                continue
+            z = linear_rows(h, l._layer.weight, None)
             if i < 3:
                 h = CnfAct.apply(z, l._layer.bias, gate, bias, n)         # fused gate + softplus on value / tangent rows
             else:                                                         # 512 -> 3 output layer: (BT,n,3) tensors

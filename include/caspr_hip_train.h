@@ -99,6 +99,16 @@ int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, const float *
                           const float *dH, int ldd, long R, int n, int C, float *dZ, int lddz,
                           float *dgate, float *dbeta, void *stream);
 
+/* First layer of the ODE function (3 -> C) fused with its gate + softplus on value (y) and tangent (e) rows:
+ * H (2R, C) as caspr_cnf_act_f32 with Z = [W0 y ; W0 e].  Y, E (R,3); W0 (C,3).  Backward: dgate / dbeta
+ * (R/n, C); dW0_part (R/n, C, 3) = per-frame partial sums (sum over frames = dW0; db0 = sum_f gate*dbeta);
+ * dY_part (ceil(C/64), R, 3) = per-64-channel partial sums of dL/dy.  All sums in a fixed order.      */
+int caspr_cnf_in_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
+                     const float *beta, long R, int n, int C, float *H, void *stream);
+int caspr_cnf_in_bwd_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
+                         const float *beta, const float *dH, long R, int n, int C, float *dgate,
+                         float *dbeta, float *dW0_part, float *dY_part, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
