@@ -197,22 +197,30 @@ def cnf_block_train(block, x, context, logpx, e):
     layers = block.odefunc.diffeq.layers
     BT, n, _ = x.shape
     c = context.contiguous()
-    # hyper networks: the context columns once per step (constant over the solve), the time column per evaluation
-    G, Bb, tg, tb = [], [], [], []
+    # hyper networks: the context columns once per step (constant over the solve), the time column per evaluation.
+    # All four layers' gate / bias rows live in ONE (BT, sum C) tensor so that the per-evaluation time update is a
+    # handful of element-wise launches instead of five per layer.
+    G, Bb, tg, tb, widths = [], [], [], [], []
     for l in layers:
         wg, wb = l._hyper_gate.weight, l._hyper_bias.weight
         G.append(linear_rows(c, wg[:, 1:].contiguous(), l._hyper_gate.bias))
         Bb.append(linear_rows(c, wb[:, 1:].contiguous(), None))
         tg.append(wg[:, 0])
         tb.append(wb[:, 0])
+        widths.append(wg.shape[0])
+    G_all, Bb_all, tg_all, tb_all = torch.cat(G, dim=1), torch.cat(Bb, dim=1), torch.cat(tg), torch.cat(tb)
+    offs = [0]
+    for w_ in widths:
+        offs.append(offs[-1] + w_)
     e_rows = e.reshape(BT * n, 3)
 
     def func(t, y, _lp):
         R = BT * n
         h = None
+        gate_all = torch.sigmoid(G_all + t * tg_all)                      # (BT, sum C): context part + time column
+        bias_all = Bb_all + t * tb_all
         for i, l in enumerate(layers):
-            gate = torch.sigmoid(G[i] + t * tg[i])                        # (BT,C): context part + time column
-            bias = Bb[i] + t * tb[i]
+            gate, bias = gate_all[:, offs[i]:offs[i + 1]], bias_all[:, offs[i]:offs[i + 1]]
             if i == 0:                                                    # 3 -> C: fused product + gate + softplus, value | tangent rows
                 h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n)
                 continue
