@@ -188,6 +188,226 @@ extern "C" int caspr_latent_rk4_f32(const float *z0, int ldz, const float *times
 }
 
 // ---------------------------------------------------------------------------------------------
+// latent ODE across 32 compute units.  The single-workgroup kernel above streams all 2.2 MB of weights from L2 through
+// ONE CU at every evaluation (51 us each, 72 evaluations at cfg-2 = 3.7 ms, a serial chain that nothing overlaps).
+// Here workgroup w of a 32-workgroup team keeps rows [16w, 16w+16) of the three 512-row layers -- and the matching 16
+// columns of the 64 x 512 output layer -- RESIDENT IN LDS (72 KB) for the whole solve.  Per evaluation:
+//   layer 0 / 1: each workgroup computes its 16 x 16 output tile (K split over its 4 waves), writes it to a global
+//                exchange buffer in B-tile layout, team barrier, everybody reads the full 512 x 16 activation back;
+//   layer 2 -> 3: the workgroup's own 16 outputs of layer 2 ARE the B fragment of its K-slice of the output layer (the
+//                D-fragment / B-fragment identity): it writes a 64 x 16 partial, team barrier, and every workgroup adds
+//                the 32 partials in index order (fixed order: results do not depend on timing).
+// Three team barriers per evaluation (monotonic counter, release / acquire at agent scope, bounded spin).  All
+// workgroups carry the RK4 state redundantly (64 x 16 floats).  32 x ceil(B/16) workgroups must be co-resident: they are
+// tiny (256 threads) and 256 CUs are available; a team member that is not yet scheduled only delays the others.
+// ---------------------------------------------------------------------------------------------
+#define LM_TEAM 32
+#define LM_SPIN_LIMIT (1u << 24)
+
+struct LatTeam {
+    unsigned *counter;     // arrivals, monotonic
+    unsigned *error;       // set if a barrier spin gave up
+    float *hbuf;           // [2][128 * 16 * 4] exchange B-tiles
+    float *pbuf;           // [LM_TEAM][4][256] output-layer partials
+};
+
+__device__ __forceinline__ void team_barrier(const LatTeam &t, unsigned &gen, bool &dead)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every wave: its exchange-buffer stores reach memory
+    __syncthreads();
+    ++gen;
+    if (threadIdx.x == 0 && !dead) {
+        __hip_atomic_fetch_add(t.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = gen * LM_TEAM;
+        unsigned spins = 0;
+        while (__hip_atomic_load(t.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > LM_SPIN_LIMIT) {   // never observed; keeps a broken launch from hanging the device
+                __hip_atomic_store(t.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (__hip_atomic_load(t.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave: later loads see the other workgroups' stores
+}
+
+__global__ __launch_bounds__(256) void latent_rk4_team_kernel(const float *__restrict__ z0, int ldz,
+                                                              const float *__restrict__ times, int B, int Tu, int D,
+                                                              int steps, const float *__restrict__ w0p,
+                                                              const float *__restrict__ b0, const float *__restrict__ w1p,
+                                                              const float *__restrict__ b1, const float *__restrict__ w2p,
+                                                              const float *__restrict__ b2, const float *__restrict__ w3p,
+                                                              const float *__restrict__ b3, float *__restrict__ out,
+                                                              char *ws, long ws_stride)
+{
+    constexpr int KCH = 32;                       // 512 / 16
+    __shared__ __attribute__((aligned(16))) float sW0[4 * 256], sW1[KCH * 256], sW2[KCH * 256], sW3[4 * 256];
+    __shared__ __attribute__((aligned(16))) float s_in[16 * LAT_NCOL * 4], s_h[128 * LAT_NCOL * 4], s_part[4][256];
+    __shared__ float s_z[64 * LAT_NCOL], s_acc[64 * LAT_NCOL], s_k[64 * LAT_NCOL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int w = blockIdx.x, grp = blockIdx.y;
+    const int b0i = grp * LAT_NCOL;
+    const int KC0 = 2 * ((D + 31) / 32);
+    char *base = ws + (long)grp * ws_stride;
+    LatTeam team{(unsigned *)base, (unsigned *)(base + 64), (float *)(base + 256), (float *)(base + 256) + 2 * 128 * LAT_NCOL * 4};
+    unsigned gen = 0;
+    bool dead = false;
+
+    // resident weights: this workgroup's row tile of layers 0-2 (packed streams are row-tile-major: contiguous), and
+    // chunk kc = w of each of the 4 row tiles of the output layer
+    for (int i = tid; i < KC0 * 64; i += 256) st4(&sW0[i * 4], ld4(w0p + ((long)w * KC0) * 256 + i * 4));
+    for (int i = tid; i < KCH * 64; i += 256) {
+        st4(&sW1[i * 4], ld4(w1p + ((long)w * KCH) * 256 + i * 4));
+        st4(&sW2[i * 4], ld4(w2p + ((long)w * KCH) * 256 + i * 4));
+    }
+    {
+        const int mt = tid >> 6;   // 4 row tiles x 64 lanes
+        st4(&sW3[tid * 4], ld4(w3p + ((long)mt * KCH + w) * 256 + lane * 4));
+    }
+    for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
+        const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+        const float v = (d < D && b0i + c < B) ? z0[(long)(b0i + c) * ldz + d] : 0.f;
+        s_z[i] = v;
+        if (w == 0 && d < D && b0i + c < B) out[((long)(b0i + c) * Tu) * D + d] = v;
+    }
+    for (int i = tid; i < 16 * LAT_NCOL * 4; i += 256) s_in[i] = 0.f;
+    __syncthreads();
+
+    // 16 x 16 output tile = sW (KC chunks of this row tile) x in ; K split over the 4 waves, combined by wave 0 in order
+    auto tile = [&](const float *sW, int KC, const float *in) -> f32x4 {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kc = wave; kc < KC; kc += 4) {
+            const f32x4 af = ld4(sW + (kc * 64 + lane) * 4);
+            const f32x4 bf = ld4(in + btile_off(kc * 4 + g, j, LAT_NCOL));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = mfma16(af[q], bf[q], acc);
+        }
+        st4(&s_part[wave][lane * 4], acc);
+        __syncthreads();
+        f32x4 r = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wave == 0) r = (ld4(&s_part[0][lane * 4]) + ld4(&s_part[1][lane * 4])) + (ld4(&s_part[2][lane * 4]) + ld4(&s_part[3][lane * 4]));
+        __syncthreads();
+        return r;
+    };
+    auto tanh_bias = [&](f32x4 a, const float *bias) {
+        const f32x4 bb = ld4(bias + w * 16 + 4 * g);
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tanhf(a[q] + bb[q]);
+        return v;
+    };
+    auto fetch_h = [&](const float *src) {   // full 512 x 16 activation of the team -> LDS
+        for (int i = tid; i < 128 * LAT_NCOL; i += 256) st4(&s_h[i * 4], ld4(src + i * 4));
+        __syncthreads();
+    };
+    auto write_in = [&](float a, const float *kv) {
+        for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
+            const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+            if (d < D) s_in[btile_off(d >> 2, c, LAT_NCOL) + (d & 3)] = kv ? s_z[i] + a * kv[i] : s_z[i];
+        }
+        __syncthreads();
+    };
+    float *hb0 = team.hbuf, *hb1 = team.hbuf + 128 * LAT_NCOL * 4;
+    auto dyn = [&]() {   // s_in -> s_k   (latent_ode_model.py:139-147)
+        f32x4 v = tanh_bias(tile(sW0, KC0, s_in), b0);
+        if (wave == 0) st4(hb0 + btile_off(w * 4 + g, j, LAT_NCOL), v);
+        team_barrier(team, gen, dead);
+        fetch_h(hb0);
+        v = tanh_bias(tile(sW1, KCH, s_h), b1);
+        if (wave == 0) st4(hb1 + btile_off(w * 4 + g, j, LAT_NCOL), v);
+        team_barrier(team, gen, dead);
+        fetch_h(hb1);
+        v = tanh_bias(tile(sW2, KCH, s_h), b2);
+        if (wave == 0) {   // own 16 hidden units x 16 columns = the B fragment of K-slice w of the output layer
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 af = ld4(&sW3[(mt * 64 + lane) * 4]);
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = mfma16(af[q], v[q], acc);
+                st4(team.pbuf + ((long)w * 4 + mt) * 256 + lane * 4, acc);
+            }
+        }
+        team_barrier(team, gen, dead);
+        {
+            const int mt = tid >> 6;
+            f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < LM_TEAM; ++k) sum = sum + ld4(team.pbuf + ((long)k * 4 + mt) * 256 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = mt * 16 + 4 * g + q;
+                if (d < D) s_k[d * LAT_NCOL + j] = sum[q] + b3[d];
+            }
+        }
+        __syncthreads();
+    };
+
+    const float t_first = times[0];
+    for (int ti = 1; ti < Tu; ++ti) {
+        const float r0 = times[ti - 1] - t_first, r1 = times[ti] - t_first;
+        const double h = ((double)r1 - (double)r0) / (double)steps;
+        const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
+        for (int s = 0; s < (r1 != r0 ? steps : 0); ++s) {
+            write_in(0.f, nullptr);
+            dyn();
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_k[i];
+            __syncthreads();
+            write_in(h2, s_k);
+            dyn();
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_acc[i] + 2.0f * s_k[i];
+            __syncthreads();
+            write_in(h2, s_k);
+            dyn();
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_acc[i] + 2.0f * s_k[i];
+            __syncthreads();
+            write_in(hh, s_k);
+            dyn();
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
+                const float a = s_acc[i] + s_k[i];
+                s_z[i] = s_z[i] + h6 * a;
+            }
+            __syncthreads();
+        }
+        if (w == 0)
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
+                const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+                // a team barrier that gave up (never observed) must not pass for a result: poison the output
+                if (d < D && b0i + c < B) out[((long)(b0i + c) * Tu + ti) * D + d] = dead ? __builtin_nanf("") : s_z[i];
+            }
+    }
+}
+
+#define LM_WS_STRIDE (256 + (2 * 128 * LAT_NCOL * 4 + LM_TEAM * 4 * 256) * 4)
+
+extern "C" long caspr_latent_team_ws_bytes(int B) { return (long)ceil_div(B, LAT_NCOL) * LM_WS_STRIDE + 256; }
+
+extern "C" int caspr_latent_rk4_team_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H,
+                                         int steps, const float *w0p, const float *b0, const float *w1p, const float *b1,
+                                         const float *w2p, const float *b2, const float *w3p, const float *b3, float *out,
+                                         void *ws, long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(z0 && times && out && w0p && w1p && w2p && w3p && b0 && b1 && b2 && b3 && ws, "latent_rk4_team: null pointer");
+    CASPR_REQUIRE(B > 0 && Tu > 0 && steps > 0 && D > 0 && D <= 64 && H == 512 && ldz >= D,
+                  "latent_rk4_team: needs D<=64, H==512 (got D=%d H=%d); use caspr_latent_rk4_f32 otherwise", D, H);
+    CASPR_REQUIRE(ws_bytes >= caspr_latent_team_ws_bytes(B) && ((uintptr_t)ws % 256) == 0, "latent_rk4_team: workspace too small or misaligned");
+    const int groups = ceil_div(B, LAT_NCOL);
+    CASPR_REQUIRE(groups * LM_TEAM <= 128, "latent_rk4_team: %d sequences need %d co-resident workgroups (> 128); use caspr_latent_rk4_f32", B, groups * LM_TEAM);
+    hipStream_t st = (hipStream_t)stream;
+    for (int gidx = 0; gidx < groups; ++gidx)
+        if (hipMemsetAsync((char *)ws + (long)gidx * LM_WS_STRIDE, 0, 256, st) != hipSuccess) {
+            caspr_set_error("latent_rk4_team: hipMemsetAsync failed");
+            return CASPR_ELAUNCH;
+        }
+    latent_rk4_team_kernel<<<dim3(LM_TEAM, groups), dim3(256), 0, st>>>(z0, ldz, times, B, Tu, D, steps, w0p, b0, w1p, b1, w2p, b2, w3p, b3,
+                                                                        out, (char *)ws, (long)LM_WS_STRIDE);
+    CASPR_CHECK_LAUNCH("latent_rk4_team");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // point CNF
 // ---------------------------------------------------------------------------------------------
 struct CnfArgs {

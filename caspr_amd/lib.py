@@ -38,6 +38,9 @@ SIGNATURES = {
     "caspr_gn_ws_bytes": (c_long, [c_int, c_int, c_int, c_int]),
     "caspr_gn_stats_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_latent_rk4_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_stream]),
+    "caspr_latent_team_ws_bytes": (c_long, [c_int]),
+    "caspr_latent_rk4_team_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                          ctypes.c_void_p, c_long, c_stream]),
     "caspr_cnf_rk4_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_float, c_int, c_int,
                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_stream]),
     "caspr_chamfer_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_stream]),

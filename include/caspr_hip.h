@@ -124,6 +124,16 @@ int caspr_latent_rk4_f32(const float *z0, int ldz, const float *times, int B, in
                          const float *w2p, const float *b2, const float *w3p, const float *b3, float *out,
                          void *stream);
 
+/* Same solve spread over a team of 32 workgroups per 16 sequences that keep the weights resident in LDS and meet at
+ * three team barriers per evaluation (see csrc/ode.hip): ~3x lower latency of this serial stage.  H must be 512 and
+ * B <= 64 (the 32*ceil(B/16) workgroups have to be co-resident); results equal caspr_latent_rk4_f32 up to the
+ * re-association of the layer sums.  ws >= caspr_latent_team_ws_bytes(B), 256-byte aligned.                    */
+long caspr_latent_team_ws_bytes(int B);
+int caspr_latent_rk4_team_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H,
+                              int steps, const float *w0p, const float *b0, const float *w1p, const float *b1,
+                              const float *w2p, const float *b2, const float *w3p, const float *b3, float *out,
+                              void *ws, long ws_bytes, void *stream);
+
 /* ---------------- point CNF: models/cnf.py:70-128 + odefunc.py:119-142 + diffeq_layers.py:83-90
  * + normalization.py:59-108 (fixed-step RK4 of the gated 3-512-512-512-3 ODE function).
  * hyper (BT, 2*(3*H+3)) = per-frame context terms, columns [gate l0 | gate l1 | gate l2 | gate l3 |

@@ -682,3 +682,29 @@ def test_hip_graph_replay_is_bit_identical(dev, seeded_sd):
         got = g(xi.to(dev), y)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(want, got))
+
+
+@pytest.mark.parametrize("B,Tu", [(1, 3), (16, 10), (17, 4), (64, 5)])
+def test_latent_team_kernel_matches_single_workgroup_kernel(ops, dev, seeded_sd, B, Tu):
+    """caspr_latent_rk4_team_f32 (32 workgroups per 16 sequences, LDS-resident weights, team barriers) against
+    caspr_latent_rk4_f32 and the oracle: same RK4, sums re-associated (K split over waves / workgroups): <= 5e-6."""
+    from caspr_amd.models import CaSPR
+    m = CaSPR()
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    z0 = rnd(B, B, 64, scale=0.5)
+    t = torch.linspace(0.0, 1.0, Tu)
+    wts = m.latent_ode._weights()
+    prev = ops.LATENT_TEAM
+    try:
+        ops.LATENT_TEAM = False
+        a = ops.latent_rk4(z0.to(dev), t.to(dev), 2, wts)
+        ops.LATENT_TEAM = True
+        b = ops.latent_rk4(z0.to(dev), t.to(dev), 2, wts)
+        c = ops.latent_rk4(z0.to(dev), t.to(dev), 2, wts)
+    finally:
+        ops.LATENT_TEAM = prev
+    assert torch.equal(b, c), "team kernel is not repeatable"
+    record("latent_team_vs_single[%d,%d]" % (B, Tu), b, a, 5e-6)
+    want = O.latent_solve(seeded_sd, z0, t, steps_per_interval=2)
+    record("latent_team_vs_oracle[%d,%d]" % (B, Tu), b, want, 1e-5)
