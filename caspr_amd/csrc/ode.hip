@@ -213,15 +213,16 @@ struct LatTeam {
 
 __device__ __forceinline__ void team_barrier(const LatTeam &t, unsigned &gen, bool &dead)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every wave: its exchange-buffer stores reach memory
+    // fence-release + relaxed arrive, relaxed poll + fence-acquire: ONE cache write-back (by the only wave that stored
+    // to the exchange buffers) and one invalidate per wave, instead of a write-back per atomic and per wave
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     ++gen;
     if (threadIdx.x == 0 && !dead) {
-        __hip_atomic_fetch_add(t.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(t.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * LM_TEAM;
         unsigned spins = 0;
-        while (__hip_atomic_load(t.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(t.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (++spins > LM_SPIN_LIMIT) {   // never observed; keeps a broken launch from hanging the device
                 __hip_atomic_store(t.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
