@@ -122,4 +122,30 @@ __device__ __forceinline__ float row_allreduce_max(float x)
     return x;
 }
 
+// wave-wide max of a 64-bit key, result uniform (SGPRs): four DPP steps inside each 16-lane row, then one lane of each
+// of the four rows read back with v_readlane -- no ds_bpermute (what __shfl_xor lowers to, ~100 cycles per dependent step)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_mov_u64(unsigned long long v)
+{
+    const int lo = dpp_mov_i32<CTRL>((int)(unsigned)v), hi = dpp_mov_i32<CTRL>((int)(unsigned)(v >> 32));
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x)
+{
+    unsigned long long o;
+    o = dpp_mov_u64<0xB1>(x);  x = o > x ? o : x;
+    o = dpp_mov_u64<0x4E>(x);  x = o > x ? o : x;
+    o = dpp_mov_u64<0x141>(x); x = o > x ? o : x;
+    o = dpp_mov_u64<0x140>(x); x = o > x ? o : x;
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, row * 16);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), row * 16);
+        const unsigned long long r = ((unsigned long long)hi << 32) | lo;
+        best = r > best ? r : best;
+    }
+    return best;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -80,8 +80,8 @@ extern "C" int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int
 // copy of xyz in LDS serves the "last selected point" broadcast.  Arg-max key = 64-bit
 // (f32 bits of the distance + 1) << 32 | ~((k mod bs) << 16 | k): max over keys reproduces the
 // oracle's total order (value desc, k mod bs asc, k asc); 0 is the identity (best=-1, besti=0).
-// Wave reduction by xor-shuffles, 4 wave results through a double-buffered LDS slot: one
-// barrier per round.
+// Wave reduction by DPP row steps + v_readlane (wave_max_u64), 4 wave results through a double-buffered LDS slot:
+// one barrier per round.
 // ---------------------------------------------------------------------------------------------
 template <int PPT>
 __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz, int n, int M, int bs,
@@ -135,13 +135,7 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
                 best = key > best ? key : best;
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned lo = __shfl_xor((unsigned)best, off);
-            const unsigned hi = __shfl_xor((unsigned)(best >> 32), off);
-            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-            best = o > best ? o : best;
-        }
+        best = wave_max_u64(best);
         unsigned long long *s = slot + (j & 1) * 4;
         if (lane == 0) s[wave] = best;
         __syncthreads();
