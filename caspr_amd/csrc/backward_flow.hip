@@ -105,6 +105,16 @@ extern "C" int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, co
 // Backward recomputes zv, zt from (y, e) and emits, per (frame, 64-channel chunk) workgroup in a fixed order:
 //   dgate, dbeta (frame, C);  dW0 partials (frame, C, 3) = sum_p dzv*y + dzt*e;  dy partials (chunk, R, 3) = sum_c dzv*W0
 // ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+static __device__ __forceinline__ float wave_sum_f(float v)   // uniform result: DPP row sums, then the four rows
+{
+    v = row_allreduce_add<16>(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+
 __global__ __launch_bounds__(256) void cnf_in_fwd_kernel(const float *__restrict__ Yp, const float *__restrict__ E,
                                                          const float *__restrict__ W0, const float *__restrict__ b,
                                                          const float *__restrict__ gate, const float *__restrict__ beta,
@@ -168,13 +178,8 @@ __global__ __launch_bounds__(256) void cnf_in_bwd_kernel(const float *__restrict
             acc[5] += dzt * e0; acc[6] += dzt * e1; acc[7] += dzt * e2;
         }
         // dy[p][j] = sum over this chunk's 64 channels of dzv * W0[c][j]: wave reduction (the tangent rows carry e, a constant)
-        float d0 = dzv * w0, d1 = dzv * w1, d2 = dzv * w2;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            d0 += __shfl_xor(d0, m, 64);
-            d1 += __shfl_xor(d1, m, 64);
-            d2 += __shfl_xor(d2, m, 64);
-        }
+        // (DPP row sums + one readlane per 16-lane row: __shfl_xor would be 18 ds_bpermute round trips per point)
+        const float d0 = wave_sum_f(dzv * w0), d1 = wave_sum_f(dzv * w1), d2 = wave_sum_f(dzv * w2);
         if (cl == 0) {
             float *o = dYp + ((long)chunk * R + r) * 3;
             o[0] = d0; o[1] = d1; o[2] = d2;
