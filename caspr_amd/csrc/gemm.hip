@@ -55,6 +55,10 @@ extern "C" int caspr_pack_weight_f32(const float *w, int ldw, int Cout, int col0
 #define GEMM_KT 32
 #define GEMM_MAXC 2048
 
+// NT = points per block (128 or 64): wave tile 32 (co) x NT.  NT = 64 halves the accumulators (4 resident waves per
+// SIMD instead of 3) and wastes nothing on the 64-point coarse levels; measured +1.4 % on the 1600x1600 layer, -0.9 ms
+// on the cfg-2 step, -8 ms on the training step, so it is the default (CASPR_GEMM_KERNEL=1 selects NT = 128).
+template <int NT>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
                                                       const float *__restrict__ bbias, const float *__restrict__ X,
                                                       int ldx, const float *__restrict__ in_scale,
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
                                                       int relu_from, float *__restrict__ Y, int ldy, int P, int Cin,
                                                       int Cout, int act, unsigned long long *trace)
 {
-    __shared__ __attribute__((aligned(16))) float sB[2][8 * GEMM_NT * 4];  // 2 x 16 KiB (K tile 32 = 2 chunks; K tile 64 measured slower: fewer blocks per CU)
+    __shared__ __attribute__((aligned(16))) float sB[2][8 * NT * 4];  // 2 x (NT/8) KiB (K tile 32 = 2 chunks; K tile 64 measured slower: fewer blocks per CU)
     // per-batch GroupNorm scale / shift of the input channels, staged once per block: reading them from global
     // memory inside store_stage exposed an L2 round trip per K tile (tools/gemm_phase_trace.py: 3.6-5.9k of 12.5k cycles)
     __shared__ __attribute__((aligned(16))) float sSS[2][GEMM_MAXC];
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const int wmt = work % Mt, wpt = (work / Mt) % Pt;
     const int b = work / (Mt * Pt);
-    const int p0 = wpt * GEMM_NT;
+    const int p0 = wpt * NT;
     const int co0 = wmt * GEMM_MT;
     const int KC = 2 * ((Cin + 31) / 32);
     const int MT16 = (Cout + 15) / 16;
@@ -121,20 +125,20 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     }
     const int rot = wpt % ntiles;
 
-    f32x4 acc[2][8];
+    f32x4 acc[2][NT / 16];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NT / 16; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // staging assignment: float4 f = tid + 256*i  ->  kq = f & 7, col = f >> 3
-    f32x4 stage[4];
+    f32x4 stage[NT / 32];
     // The global loads only ISSUE here (raw data stays in flight across the MFMA block); masking and the fused
     // GroupNorm+ReLU transform run in store_stage, when the data has long arrived -- applying them at load time
     // would put an s_waitcnt vmcnt(0) in front of the MFMAs.
     auto load_stage = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NT / 32; ++i) {
             const int f = tid + 256 * i;
             const int kq = f & 7, col = f >> 3;
             const int k = kt * GEMM_KT + kq * 4;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
     };
     auto store_stage = [&](int buf, int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NT / 32; ++i) {
             const int f = tid + 256 * i;
             const int kq = f & 7, col = f >> 3;
             const int k = kt * GEMM_KT + kq * 4;
@@ -166,28 +170,28 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
             } else {
                 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            st4(&sB[buf][btile_off(kq, col, GEMM_NT)], v);
+            st4(&sB[buf][btile_off(kq, col, NT)], v);
         }
     };
 
-    f32x4 a0[2], a1[2], b0[8];   // one activation-fragment set: a second one costs 32 VGPRs = the third resident block per CU
+    f32x4 a0[2], a1[2], b0[NT / 16];   // one activation-fragment set: a second one costs 32 VGPRs = the third resident block per CU
     auto load_a = [&](f32x4(&a)[2], int kc) {   // kc = chunk index in the packed stream (already rotated)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
             a[mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff[mi] + kc * 1024, 0));
     };
     auto tile_of = [&](int it) { const int t = it + rot; return t >= ntiles ? t - ntiles : t; };
-    auto load_b = [&](f32x4(&bf)[8], int buf, int c) {
+    auto load_b = [&](f32x4(&bf)[NT / 16], int buf, int c) {
 #pragma unroll
-        for (int ni = 0; ni < 8; ++ni) bf[ni] = ld4(&sB[buf][btile_off(c * 4 + g, ni * 16 + j, GEMM_NT)]);
+        for (int ni = 0; ni < NT / 16; ++ni) bf[ni] = ld4(&sB[buf][btile_off(c * 4 + g, ni * 16 + j, NT)]);
     };
-    auto mma = [&](const f32x4(&a)[2], const f32x4(&bf)[8]) {
+    auto mma = [&](const f32x4(&a)[2], const f32x4(&bf)[NT / 16]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = mfma16(a[mi][q], bf[ni][q], acc[mi][ni]);
+                for (int ni = 0; ni < NT / 16; ++ni) acc[mi][ni] = mfma16(a[mi][q], bf[ni][q], acc[mi][ni]);
     };
 
     load_stage(tile_of(0));
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
             add[r] = v;
         }
 #pragma unroll
-        for (int ni = 0; ni < 8; ++ni) {
+        for (int ni = 0; ni < NT / 16; ++ni) {
             const int p = p0 + ni * 16 + j;
             if (p >= P) continue;
             f32x4 v = acc[mi][ni];
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) void conv1x1_big_kernel(const float *__restric
 extern "C" int caspr_debug_gemm_occupancy(void)   // debug hook: resident conv1x1_kernel blocks per CU
 {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)conv1x1_kernel, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)conv1x1_kernel<64>, 256, 0);
     return n;
 }
 static unsigned long long *g_gemm_trace = nullptr;
@@ -467,7 +471,7 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wp % 16) == 0, "conv1x1: pointers must be 16-byte aligned");
     CASPR_REQUIRE(B <= 65535, "conv1x1: B=%d > 65535", B);
     CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 4 == 0, "conv1x1: in_relu_from=%d must be a non-negative multiple of 4", in_relu_from);
-    static const int force = getenv("CASPR_GEMM_KERNEL") ? atoi(getenv("CASPR_GEMM_KERNEL")) : 0;   // 1 = small, 2 = big (experiments)
+    static const int force = getenv("CASPR_GEMM_KERNEL") ? atoi(getenv("CASPR_GEMM_KERNEL")) : 0;   // 1 = 128-point tiles, 2 = big (experiments)
     const bool use_big = force == 2;   // measured slower than the 2-blocks-per-CU kernel on every shape of this model (profiles/r01_*)
     if (use_big) {
         const size_t shmem = 2 * 16 * BIG_NT * 4 * sizeof(float);
@@ -486,10 +490,17 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
         CASPR_CHECK_LAUNCH("conv1x1(big)");
         return CASPR_OK;
     }
-    dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, GEMM_NT), B);
     static const size_t lds_pad = getenv("CASPR_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CASPR_GEMM_LDS_PAD")) * 1024 : 0;  // occupancy experiments
-    conv1x1_kernel<<<grid, dim3(256), lds_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
-                                                                in_relu_from, Y, ldy, P, Cin, Cout, act, g_gemm_trace);
+    CASPR_REQUIRE(ceil_div(P, 128) <= 65535, "conv1x1: P=%d rows per batch entry exceed the grid (split the call)", P);
+    if (force == 1 || ceil_div(P, 64) > 65535) {
+        dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
+        conv1x1_kernel<128><<<grid, dim3(256), lds_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
+                                                                               Y, ldy, P, Cin, Cout, act, g_gemm_trace);
+    } else {
+        dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 64), B);
+        conv1x1_kernel<64><<<grid, dim3(256), lds_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
+                                                                              Y, ldy, P, Cin, Cout, act, g_gemm_trace);
+    }
     CASPR_CHECK_LAUNCH("conv1x1");
     return CASPR_OK;
 }
