@@ -266,6 +266,220 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv1x1, streaming variant: no LDS tiles, no barrier in the K loop.
+// Diagnostics on conv1x1_kernel (skipping parts of its K loop) showed the activation staging path -- global load ->
+// transform -> LDS store -> workgroup barrier -- costing more than anything else (139 TFLOP/s without it and without the
+// weight loads, 117 with staging only, 127 with weight loads only, 114 with both).  In the point-major layout the B
+// fragment of lane (g, j) for a 16-k chunk IS a contiguous 16-byte piece of row p = p0 + ni*16 + j (channels 16kc+4g..+3),
+// so each wave can fetch its own activation fragments straight from global memory (the second chunk of a 128-byte line
+// hits L1) and nothing is shared between waves: 1 x 4 waves, each 128 (co) x 32 (points) = 8 x 2 MFMA tiles.  Every wave
+// streams the whole 128-row weight slab (4x the fragment traffic of the 4 x 1 layout -- measured harmless above).
+// ---------------------------------------------------------------------------------------------
+#ifndef ST_TOUCH_A
+#define ST_TOUCH_A 0   // the same VALU touch on the weight fragments: within noise (+3 % unfused, -1.5 % fused)
+#endif
+#ifndef ST_DB
+#define ST_DB 6   // activation fragment sets in flight (chunks)
+#endif
+#ifndef ST_DA
+#define ST_DA 3   // weight fragment sets in flight (chunks); ST_DB must be a multiple of ST_DA and even
+#endif
+
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
+                                                                const float *__restrict__ bbias, const float *__restrict__ X,
+                                                                int ldx, const float *__restrict__ in_scale,
+                                                                const float *__restrict__ in_shift, int in_relu, int relu_from,
+                                                                float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int act)
+{
+    __shared__ __attribute__((aligned(16))) float sSS[2][GEMM_MAXC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int Mt = gridDim.x, Pt = gridDim.y;
+    const int nblk = Mt * Pt * gridDim.z;
+    const int lin = blockIdx.x + Mt * (blockIdx.y + Pt * blockIdx.z);
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int wmt = work % Mt, wpt = (work / Mt) % Pt;
+    const int b = work / (Mt * Pt);
+    const int p0 = wpt * 128 + wave * 32;
+    const int co0 = wmt * GEMM_MT;
+    const int KC = 2 * ((Cin + 31) / 32);
+    const int MT16 = (Cout + 15) / 16;
+    const int Cin4 = (Cin + 3) & ~3;
+
+    const float *sc = in_scale ? in_scale + (long)b * Cin : nullptr;
+    const float *sh = in_scale ? in_shift + (long)b * Cin : nullptr;
+    if (sc) {
+        for (int c = tid * 4; c < Cin; c += 1024) {
+            st4(&sSS[0][c], ld4(sc + c));
+            st4(&sSS[1][c], ld4(sh + c));
+        }
+        __syncthreads();
+    }
+
+    const int mt0 = co0 >> 4;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, MT16 * KC * 1024, 0x00020000);
+    const int wvoff = lane * 16;
+    int wsoff[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) wsoff[mi] = ((mt0 + mi) < MT16 ? mt0 + mi : 0) * KC * 1024;
+    // activation rows of this lane (two column tiles); rows past P read row P-1 (finite data, columns never stored)
+    const float *xrow[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int p = p0 + ni * 16 + j;
+        xrow[ni] = X + ((long)b * P + (p < P ? p : P - 1)) * ldx + 4 * g;
+    }
+
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 af[ST_DA][8], bfr[ST_DB][2];
+    auto load_a = [&](int set, int kc) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            af[set][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff[mi] + kc * 1024, 0));
+    };
+    // Whole chunks (all 16 k below Cin) run in an unconditional, ST_DB-times unrolled loop; the ragged end (a partial
+    // chunk and the zero padding up to an even chunk count) goes through the masked path.
+    auto load_b = [&](int set, int kc) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bfr[set][ni] = ld4(xrow[ni] + 16 * kc);
+    };
+    auto load_b_edge = [&](int set, int kc) {
+        const bool in = 16 * kc + 4 * g < Cin4;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bfr[set][ni] = in ? ld4(xrow[ni] + 16 * kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    float opaque_one = 1.0f;
+    asm volatile("" : "+v"(opaque_one));   // the compiler must not fold the multiply below away
+    auto fix_b = [&](int set, int kc) {
+        if (!FUSED) {
+            // Without the fused transform the MFMAs would read the registers the global loads returned into directly;
+            // measured 103-108 TFLOP/s that way versus 116-126 when a VALU op sits in between (as in the fused path).
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bfr[set][ni] = bfr[set][ni] * opaque_one;
+        }
+        if (FUSED) {
+            const int k = 16 * kc + 4 * g;
+            const f32x4 s4 = ld4(&sSS[0][k]), t4 = ld4(&sSS[1][k]);
+            const bool relu = in_relu && k >= relu_from;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                f32x4 v = bfr[set][ni] * s4 + t4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (relu && !(v[q] > 0.f)) ? 0.f : v[q];
+                bfr[set][ni] = v;
+            }
+        }
+    };
+    auto fix_b_edge = [&](int set, int kc) {
+        const int k = 16 * kc + 4 * g;
+        if (k < Cin) {
+            if (FUSED) fix_b(set, kc);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k + q >= Cin) bfr[set][ni][q] = 0.f;
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bfr[set][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto mma = [&](int aset, int bset) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16(af[aset][mi][q], bfr[bset][ni][q], acc[mi][ni]);
+    };
+
+    const int nfull = (Cin / 16) / ST_DB * ST_DB;   // chunks handled by the unconditional loop (multiple of ST_DB, even)
+    if (nfull > 0) {
+#pragma unroll
+        for (int d = 0; d < ST_DB - 1; ++d) load_b(d, d);   // nfull >= ST_DB
+#pragma unroll
+        for (int d = 0; d < ST_DA - 1; ++d) load_a(d, d);
+        for (int kc0 = 0; kc0 < nfull; kc0 += ST_DB) {
+#pragma unroll
+            for (int d = 0; d < ST_DB; ++d) {
+                const int kc = kc0 + d;
+                // prefetch: activations ST_DB-1 chunks ahead, weights ST_DA-1 chunks ahead (clamped re-loads at the very
+                // end keep the loop free of branches; their results are overwritten or unused)
+                const int kb = kc + ST_DB - 1 < nfull ? kc + ST_DB - 1 : nfull - 1;
+                const int ka = kc + ST_DA - 1 < KC ? kc + ST_DA - 1 : KC - 1;
+                load_b((d + ST_DB - 1) % ST_DB, kb);
+                load_a((d + ST_DA - 1) % ST_DA, ka);
+                __builtin_amdgcn_sched_barrier(0);
+                fix_b(d, kc);
+                if (ST_TOUCH_A) {
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) af[d % ST_DA][mi] = af[d % ST_DA][mi] * opaque_one;
+                }
+                mma(d % ST_DA, d);
+            }
+        }
+    }
+    // ragged end (KC and nfull are even): masked, shallow prefetch, static register sets.  Weight chunks nfull .. nfull+ST_DA-2
+    // may already sit in sets 0 .. ST_DA-2 from the loop above; they are simply fetched again.
+    for (int kc = nfull; kc < KC; kc += 2) {
+        load_a(0, kc);
+        load_a(1, kc + 1);
+        load_b_edge(0, kc);
+        load_b_edge(1, kc + 1);
+        fix_b_edge(0, kc);
+        mma(0, 0);
+        fix_b_edge(1, kc + 1);
+        mma(1, 1);
+    }
+
+    // epilogue: lane holds co = co0 + mi*16 + 4g + r for point p0 + ni*16 + j
+    const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        if (mt0 + mi >= MT16) continue;
+        const int co = co0 + mi * 16 + 4 * g;
+        float add[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+            if (co + r < Cout) {
+                if (bias) v += bias[co + r];
+                if (bb) v += bb[co + r];
+            }
+            add[r] = v;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int p = p0 + ni * 16 + j;
+            if (p >= P) continue;
+            f32x4 v = acc[mi][ni];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] += add[r];
+                if (act == 1) v[r] = sigmoid_f(v[r]);
+            }
+            float *dst = Y + ((long)b * P + p) * ldy + co;
+            if (co + 3 < Cout) {
+                st4(dst, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < Cout) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // conv1x1, large-problem variant: ONE wave per SIMD (the CNF kernel's lesson, profiles/r01_*): 256 threads,
 // block tile 128 (co) x 256 (points), wave tile 64 x 128 = 4 x 8 MFMA tiles (128 accumulator VGPRs), K tile 64
 // in a double-buffered 2 x 64 KiB LDS B-tile.  Per 16-k chunk a wave issues 4 weight-fragment loads (L2) and 8
@@ -492,6 +706,20 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     }
     static const size_t lds_pad = getenv("CASPR_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CASPR_GEMM_LDS_PAD")) * 1024 : 0;  // occupancy experiments
     CASPR_REQUIRE(ceil_div(P, 128) <= 65535, "conv1x1: P=%d rows per batch entry exceed the grid (split the call)", P);
+    // default: the streaming kernel wherever a wave's 32 points and the unrolled K loop are filled; the LDS-tiled kernel
+    // for short rows-per-batch (coarse levels) and narrow inputs (set-abstraction MLPs).  CASPR_GEMM_KERNEL: 1 / 4 force
+    // the LDS kernel with 128 / 64-point tiles, 7 forces streaming.
+    if (force == 7 || (force == 0 && P >= 128 && Cin >= 32 * ST_DB)) {
+        dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
+        if (in_scale)
+            conv1x1_stream_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
+                                                                                     in_relu_from, Y, ldy, P, Cin, Cout, act);
+        else
+            conv1x1_stream_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
+                                                                                      in_relu_from, Y, ldy, P, Cin, Cout, act);
+        CASPR_CHECK_LAUNCH("conv1x1(stream)");
+        return CASPR_OK;
+    }
     if (force == 1 || ceil_div(P, 64) > 65535) {
         dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
         conv1x1_kernel<128><<<grid, dim3(256), lds_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from,

@@ -4,7 +4,7 @@ from caspr_amd import ops
 
 dev = "cuda:0"
 for (B, P, cin, cout, fused) in [(16, 20480, 1600, 1600, True), (16, 20480, 576, 1600, True), (1, 163840, 512, 512, False), (160, 2048, 512, 512, True),
-                                 (160, 1024, 608, 512, True)]:
+                                 (160, 1024, 608, 512, True), (1, 163840, 512, 512, True), (160, 1024, 512, 512, False), (80, 2048, 512, 512, False), (16, 20480, 1600, 1600, False)]:
     x = torch.randn(B, P, cin, device=dev)
     w = torch.randn(cout, cin, device=dev) * 0.05
     pw = ops.PackedWeight(w)
