@@ -54,6 +54,9 @@ extern "C" int caspr_pack_weight_f32(const float *w, int ldw, int Cout, int col0
 #define GEMM_NT 128
 #define GEMM_KT 32
 #define GEMM_MAXC 2048
+#ifndef GEMM_TOUCH_B
+#define GEMM_TOUCH_B 1
+#endif
 
 // NT = points per block (128 or 64): wave tile 32 (co) x NT.  NT = 64 halves the accumulators (4 resident waves per
 // SIMD instead of 3) and wastes nothing on the 64-point coarse levels; measured +1.4 % on the 1600x1600 layer, -0.9 ms
@@ -185,6 +188,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
 #pragma unroll
         for (int ni = 0; ni < NT / 16; ++ni) bf[ni] = ld4(&sB[buf][btile_off(c * 4 + g, ni * 16 + j, NT)]);
     };
+    float lds_one = 1.0f;
+    asm volatile("" : "+v"(lds_one));
+    auto touch_b = [&](f32x4(&bf)[NT / 16]) {   // experiment: a VALU op between the LDS reads and the MFMAs
+        if (GEMM_TOUCH_B) {
+#pragma unroll
+            for (int ni = 0; ni < NT / 16; ++ni) bf[ni] = bf[ni] * lds_one;
+        }
+    };
     auto mma = [&](const f32x4(&a)[2], const f32x4(&bf)[NT / 16]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -212,11 +223,13 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         load_a(a1, kt * 2 + 1);
         __builtin_amdgcn_sched_barrier(0);
         GEMM_STAMP(1)
+        touch_b(b0);
         mma(a0, b0);
         GEMM_STAMP(2)
         load_b(b0, buf, 1);
         load_a(a0, ktn * 2);
         __builtin_amdgcn_sched_barrier(0);
+        touch_b(b0);
         mma(a1, b0);
         GEMM_STAMP(3)
         if (more) {
