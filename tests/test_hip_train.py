@@ -274,7 +274,8 @@ def test_encoder_backward_matches_oracle_autograd(B, T, N):
     #   * exact where no selection is upstream: the loss value and conv3's gradient (first in the backward chain);
     #   * wiring: per parameter the MEDIAN elementwise error stays below 1.5e-2 of the largest entry and the L2 error below
     #     0.05 + 2x the f32 oracle's -- a mis-wired block (wrong operand, missing term, transposed index) is O(1) in both;
-    #   * accuracy class: the whole-gradient L2 error is within 5x of the f32 oracle's own error against f64.
+    #   * accuracy class: the whole-gradient L2 error is below 0.05 (4x the measured one-ulp input-perturbation floor)
+    #     and within 10x of the f32 oracle's own error against f64.
     e_gpu, e_ref, n, num_g, num_r, den, bad = [], [], 0, 0.0, 0.0, 0.0, []
     for name, p in m.named_parameters():
         want = sd6[name].grad
@@ -308,7 +309,10 @@ def test_encoder_backward_matches_oracle_autograd(B, T, N):
                                         "median_oracle32": float(np.median(e_ref)), "max_hip": float(np.max(e_gpu)),
                                         "max_oracle32": float(np.max(e_ref))}
     rel("enc_grad_conv3" + tag, m.encoder.conv3.weight.grad, sd6["encoder.conv3.weight"].grad, 1e-4)
-    assert tot_g <= 5 * tot_r + 1e-5, "whole-gradient L2 error %.3e vs the f32 oracle's %.3e" % (tot_g, tot_r)
+    # measured: HIP 2.3e-2, f32 oracle 6.8e-3, input-perturbation noise floor 1.3e-2 (tools/grad_noise_probe.py).  The f32
+    # oracle's own figure depends on the host's thread count (summation order), so the bound is absolute with the ratio kept
+    # as a looser second condition.
+    assert tot_g <= 0.05 and tot_g <= 10 * tot_r + 1e-5, "whole-gradient L2 error %.3e vs the f32 oracle's %.3e" % (tot_g, tot_r)
 
 
 def test_pretrain_step_matches_reference_golden(golden, seeded_sd):
