@@ -433,16 +433,15 @@ def test_train_loop_checkpoint_resume(tmp_path, seeded_sd):
     out2.mkdir()
     train(m2, batches, batches[:1], dev, str(out2), num_epochs=2, log=logs.append, resume=os.path.join(str(tmp_path), "resume_0.pth"))
     # Same weights as the uninterrupted run.  Not bit-identical: the two float-atomic scatter-adds move the last bit of some
-    # gradients, and Adam's first steps (update = m / (sqrt(v) + 1e-8)) turn that into up to ~lr on the rare entries whose
-    # gradient is itself ~1e-8.  A resume that lost the optimizer state or the epoch would move EVERY entry by ~lr = 1e-4:
-    # require 99 % of the entries within 2e-6 and all within 3 * lr.
+    # gradients, and Adam's first steps (update = m / (sqrt(v) + 1e-8)) turn that into a few 1e-6 on the entries whose
+    # gradient is itself tiny (observed: up to 5e-6 on 2-5 of the 144 entries of the first set-abstraction conv).  A resume
+    # that lost the optimizer state or the epoch would move EVERY entry by ~lr = 1e-4: require max <= 2e-5, median <= 1e-6.
     for key in ("encoder.conv3.weight", "encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.0.weight",
                 "encoder.conv1.weight"):
         a, b = m.state_dict()[key], m2.state_dict()[key]
         d = (a - b).abs()
-        frac = float((d > 2e-6).float().mean())
-        REPORT["resume:" + key] = {"frac_gt_2e-6": frac, "max_abs_diff": float(d.max())}
-        assert frac <= 0.01 and float(d.max()) <= 3e-4, "%s: %.4f of the entries differ, max %.3e" % (key, frac, float(d.max()))
+        REPORT["resume:" + key] = {"median_abs_diff": float(d.median()), "max_abs_diff": float(d.max())}
+        assert float(d.max()) <= 2e-5 and float(d.median()) <= 1e-6, "%s: max %.3e median %.3e" % (key, float(d.max()), float(d.median()))
     rel("resume_flush", torch.zeros(1), torch.zeros(1), 1.0)
 
 
