@@ -461,3 +461,40 @@ extern "C" int caspr_argmax_points_f32(const float *Y, int ldy, int B, int P, in
     CASPR_CHECK_LAUNCH("argmax_points");
     return CASPR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic scatter-add = gather over precomputed segments (CSR): dst[t, c] (+)= sum_{e in seg(t)} w[e] * src[row[e], col0+c]
+// with the entries of every segment in ascending source order.  The training path uses this for the backward of
+// three_interpolate and of the grouper instead of the float-atomic kernels above: gradients become bit-reproducible.
+// One wave per target row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restrict__ src, int lds, int col0,
+                                                          const int32_t *__restrict__ seg_start, const int32_t *__restrict__ seg_row,
+                                                          const float *__restrict__ seg_w, int C, float *__restrict__ dst, int ldd,
+                                                          int accumulate, long targets)
+{
+    const int lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= targets) return;
+    const int e0 = seg_start[t], e1 = seg_start[t + 1];
+    float *d = dst + t * ldd;
+    for (int c = lane; c < C; c += 64) {
+        float acc = accumulate ? d[c] : 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const float v = src[(long)seg_row[e] * lds + col0 + c];
+            acc += seg_w ? seg_w[e] * v : v;
+        }
+        d[c] = acc;
+    }
+}
+
+extern "C" int caspr_segment_sum_f32(const float *src, int lds, int col0, const int32_t *seg_start, const int32_t *seg_row,
+                                     const float *seg_w, long targets, int C, float *dst, int ldd, int accumulate, void *stream)
+{
+    CASPR_REQUIRE(src && seg_start && seg_row && dst && targets > 0 && C > 0 && col0 >= 0 && lds >= col0 + C && ldd >= C,
+                  "segment_sum: bad arguments");
+    segment_sum_kernel<<<dim3((unsigned)((targets + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(src, lds, col0, seg_start, seg_row, seg_w,
+                                                                                                   C, dst, ldd, accumulate, targets);
+    CASPR_CHECK_LAUNCH("segment_sum");
+    return CASPR_OK;
+}

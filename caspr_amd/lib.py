@@ -62,6 +62,7 @@ SIGNATURES = {
     "caspr_three_interp_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_group_rows_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_group_rows_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
+    "caspr_segment_sum_f32": (c_int, [c_fp, c_int, c_int, c_ip, c_ip, c_fp, c_long, c_int, c_fp, c_int, c_int, c_stream]),
     "caspr_gn_rows_f32": (c_int, [c_fp, c_int, c_long, c_int, c_int, c_fp, c_fp, c_float, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_ip,
                                   c_stream]),
     "caspr_cnf_act_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_fp, c_int, c_stream]),

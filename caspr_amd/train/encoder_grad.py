@@ -90,7 +90,7 @@ def _conv_gn_bwd(packs, grads, rec, da, relu=True, dmax=None, amax=None, need_dx
 # ---------------------------------------------------------------------------------------------
 # one scale of a set-abstraction level on neighbourhood rows
 # ---------------------------------------------------------------------------------------------
-def _sa_scale_fwd(packs, pn, xyz, new_xyz, feat, C, idx, out, off):
+def _sa_scale_fwd(packs, pn, xyz, new_xyz, feat, C, idx, out, off, need_input_grad=True):
     ns = idx.shape[2]
     cur = T.group_rows(xyz, new_xyz, feat, C, idx)
     recs = []
@@ -102,7 +102,13 @@ def _sa_scale_fwd(packs, pn, xyz, new_xyz, feat, C, idx, out, off):
         A, mean, rstd, arg = T.gn_rows(y, ns, Cl, gn.weight, gn.bias, relu=not last, maxout=out[:, :, off:off + Cl] if last else None)
         recs.append({"x": cur, "y": y, "mean": mean, "rstd": rstd, "arg": arg, "conv": conv, "gn": gn})
         cur = A
-    return {"layers": recs, "idx": idx, "ns": ns, "C": C, "off": off}
+    seg = None
+    if need_input_grad and feat is not None and C > 0:
+        # deterministic backward of the gather: for every input point the neighbourhood rows that read it (ascending)
+        B, n = xyz.shape[0], xyz.shape[1]
+        base = (torch.arange(B, device=idx.device, dtype=torch.int64) * n).view(B, 1, 1)
+        seg = T.Segments(idx.long() + base, B * n)
+    return {"layers": recs, "idx": idx, "ns": ns, "C": C, "off": off, "seg": seg}
 
 
 def _sa_scale_bwd(packs, grads, rec, dout, dfeat):
@@ -124,7 +130,7 @@ def _sa_scale_bwd(packs, grads, rec, dout, dfeat):
         if l > 0 or dfeat is not None:
             d = ops.conv1x1(packs.bwd(conv), None, dy)
     if dfeat is not None:
-        T.group_rows_bwd(d, rec["idx"], rec["C"], dfeat)
+        T.segment_sum(d, rec["seg"], rec["C"], dfeat, col0=3, accumulate=True)     # fixed-order form of group_rows_bwd
 
 
 # ---------------------------------------------------------------------------------------------
@@ -170,7 +176,8 @@ def encoder_forward(enc, x):
         out = torch.empty(xyz.shape[0], sa.num_points_out, sa.get_num_features_out(), device=dev, dtype=torch.float32)
         off, scales = 0, []
         for i in range(len(sa.layers)):
-            scales.append(_sa_scale_fwd(packs, sa.pointnet_modules[i], xyz_list[-1], new_xyz, feat_list[-1], ch_list[-1], d["ball_idx"][i], out, off))
+            scales.append(_sa_scale_fwd(packs, sa.pointnet_modules[i], xyz_list[-1], new_xyz, feat_list[-1], ch_list[-1], d["ball_idx"][i], out, off,
+                                        need_input_grad=l > 0))   # level 0 reads the input coordinates' features: no gradient
             off += sa.pointnet_layer_dims_list[i][-1]
         tape.sa.append(scales)
         xyz_list.append(new_xyz)
@@ -189,7 +196,11 @@ def encoder_forward(enc, x):
         for k in range(len(fp.layer_dims)):
             cur, r, _ = _conv_gn_fwd(packs, fp.unit_pointnet[3 * k], fp.unit_pointnet[3 * k + 1], cur)
             recs.append(r)
-        tape.fp.append({"layers": recs, "idx": nidx, "w": w, "Cprev": prev.channels, "Cs": Cs, "level": len(feat_list) + target, "m": prev.raw.shape[1]})
+        nB, nn_, m_ = nidx.shape[0], nidx.shape[1], prev.raw.shape[1]
+        base = (torch.arange(nB, device=dev, dtype=torch.int64) * m_).view(nB, 1, 1)
+        rows = (torch.arange(nB * nn_, device=dev, dtype=torch.int64).view(nB, nn_, 1)).expand(nB, nn_, 3)
+        seg = T.Segments(nidx.long() + base, nB * m_, weight=w, src_rows=rows)    # deterministic backward of three_interpolate
+        tape.fp.append({"layers": recs, "seg": seg, "Cprev": prev.channels, "Cs": Cs, "level": len(feat_list) + target, "m": m_})
         prev = cur
         target -= 1
     c0, gnf, c3 = pn2.final_layers[0], pn2.final_layers[1], pn2.final_layers[3]
@@ -309,7 +320,7 @@ def encoder_backward(enc, tape, dz0, dtnocs):
             dcoarse = torch.zeros(B * T_, rec["m"], Cprev, device=dev, dtype=torch.float32)
         else:
             dcoarse = dsa[-1]                                                       # FP level 0 interpolates the last SA output
-        T.three_interp_bwd(d, rec["idx"], rec["w"], Cprev, dcoarse)
+        T.segment_sum(d, rec["seg"], Cprev, dcoarse, col0=0, accumulate=True)        # fixed-order form of three_interp_bwd
         if level >= 1:                                                              # skip connection from SA level `level`
             dsa[level - 1] += d[:, :, Cprev:Cprev + Cs]
         dprev = dcoarse

@@ -157,3 +157,30 @@ def gn_rows_bwd(y, ns, C, gamma, beta, relu, mean, rstd, dgamma, dbeta, da=None,
                                        _p(arg), _p(out), ldo, _p(dgamma), _p(dbeta), int(accumulate), _p(ws), ws.numel(), _stream()),
                "caspr_gn_rows_bwd_f32")
     return out
+
+
+class Segments:
+    """CSR of a scatter: for every target row the contributing source rows (ascending) and their weights.
+    Built from flat int tensors `target` (nnz), optional `weight` (nnz) and optional `src_rows` (nnz; default: entry e
+    reads source row e)."""
+
+    def __init__(self, target, n_targets, weight=None, src_rows=None):
+        tgt = target.reshape(-1).long()
+        order = torch.sort(tgt, stable=True)[1]            # stable: equal targets keep ascending source order
+        counts = torch.bincount(tgt, minlength=n_targets)
+        self.start = torch.zeros(n_targets + 1, device=tgt.device, dtype=torch.int32)
+        self.start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        self.row = (order if src_rows is None else src_rows.reshape(-1)[order]).to(torch.int32).contiguous()
+        self.w = None if weight is None else weight.reshape(-1)[order].contiguous().float()
+        self.n_targets = n_targets
+
+
+def segment_sum(src, seg, C, dst, col0=0, accumulate=True):
+    """dst (targets, >=C) (+)= gather-sum of src rows (any leading shape, rows flattened) through `seg`, columns col0..col0+C."""
+    src2 = src.reshape(-1, src.shape[-1])
+    dst2 = dst.reshape(-1, dst.shape[-1])
+    if src2.stride(1) != 1 or dst2.stride(1) != 1:
+        raise ValueError("segment_sum: unit column stride required")
+    _lib.check(_lib.load().caspr_segment_sum_f32(_p(src2), src2.stride(0), col0, _p(seg.start), _p(seg.row), _p(seg.w), seg.n_targets, C,
+                                                 _p(dst2), dst2.stride(0), int(accumulate), _stream()), "caspr_segment_sum_f32")
+    return dst

@@ -5,9 +5,9 @@
  * caspr_losses.py:31-70.  Each entry below names the forward call site whose autograd node it
  * replaces.  Same conventions as caspr_hip.h: device pointers, f32, point-major rows, the
  * caller's stream, int return code (0 = ok, text from caspr_last_error_string()).
- * Dense reductions (weight / GroupNorm parameter gradients) combine partial sums in a fixed order and
- * are reproducible run to run; the two scatter-adds (three_interp / group backward) use float atomics,
- * as Kaolin's CUDA kernels do.                                                                      */
+ * Dense reductions (weight / GroupNorm parameter gradients) combine partial sums in a fixed order; the two
+ * scatter-adds exist as float-atomic kernels (as in Kaolin) and as a deterministic segment gather
+ * (caspr_segment_sum_f32), which is what the training path calls: gradients are reproducible run to run. */
 #ifndef CASPR_HIP_TRAIN_H
 #define CASPR_HIP_TRAIN_H
 #include "caspr_hip.h"
@@ -73,6 +73,14 @@ int caspr_group_rows_f32(const float *xyz, const float *new_xyz, const float *fe
                          void *stream);
 int caspr_group_rows_bwd_f32(const float *dG, int ldg, const int32_t *idx, int B, int n, int M, int C,
                              int ns, float *dFeat, int ldf, void *stream);
+
+/* Deterministic form of the two scatter-adds: a gather over precomputed segments (CSR over the target rows, the entries
+ * of each segment in ascending source-row order):  dst[t, c] (+)= sum_{e in [seg_start[t], seg_start[t+1])}
+ * w[e] * src[seg_row[e], col0 + c],  c < C  (w == NULL: 1).  The training path builds the segments once per level from
+ * the three-NN / ball-query indices (a stable sort of the target ids) and calls this instead of the atomic kernels:
+ * gradients are then bit-reproducible run to run.                                                                   */
+int caspr_segment_sum_f32(const float *src, int lds, int col0, const int32_t *seg_start, const int32_t *seg_row,
+                          const float *seg_w, long targets, int C, float *dst, int ldd, int accumulate, void *stream);
 
 /* GroupNorm(16) over one neighbourhood (ns rows) at a time (PointNetFeatureExtractor, pointnet2.py:
  * 649-703).  Y (NB*ns, ldy).  Forward writes mean/rstd (NB,16) and either the dense activation

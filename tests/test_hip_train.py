@@ -540,3 +540,25 @@ def test_sharded_gradient_equals_batch_gradient(seeded_sd):
     # same kernels on the same per-sequence data: only reduction order across the batch differs (weight-gradient slabs)
     # (per tensor the difference is measured against the whole gradient's norm: some biases have a mathematically zero gradient)
     assert (num / den) ** 0.5 <= 1e-5 and worst[1] <= 1e-5 * den ** 0.5, REPORT["sharded_grad"]
+
+
+def test_encoder_gradients_are_bit_reproducible(seeded_sd):
+    """Every reduction of the training path runs in a fixed order (slab / block combines, segment gathers instead of float
+    atomics): two backward passes over the same input give bit-identical gradients."""
+    from caspr_amd.models import CaSPR
+    from caspr_amd.utils.synthetic import car_sequences
+    dev = torch.device("cuda:0")
+    m = CaSPR(pretrain_tnocs=True)
+    m.load_state_dict({k: v for k, v in seeded_sd.items() if k.startswith("encoder.")})
+    m = m.to(dev).train()
+    x, sp = (t.to(dev) for t in car_sequences(2, 2, 1024, seed=71))
+    R = rnd(9, 2, 1600, scale=0.05).to(dev)
+
+    def grads():
+        m.zero_grad()
+        z0, tn = m.encoder(x)
+        (100.0 * (tn - sp).abs().mean() + (z0 * R).sum()).backward()
+        return [p.grad.detach().clone() for p in m.parameters()]
+    a, b = grads(), grads()
+    bad = [n for (n, _), u, v in zip(m.named_parameters(), a, b) if not torch.equal(u, v)]
+    assert not bad, "gradients differ between two identical passes: %s" % bad[:5]
