@@ -562,3 +562,25 @@ def test_encoder_gradients_are_bit_reproducible(seeded_sd):
     a, b = grads(), grads()
     bad = [n for (n, _), u, v in zip(m.named_parameters(), a, b) if not torch.equal(u, v)]
     assert not bad, "gradients differ between two identical passes: %s" % bad[:5]
+
+
+def test_full_model_gradients_are_bit_reproducible(seeded_sd, golden):
+    """The same for the whole training step (encoder + latent ODE + CNF with divergence)."""
+    from caspr_amd.models import CaSPR
+    dev = torch.device("cuda:0")
+    m = CaSPR(cnf_rk4_steps=2, latent_rk4_steps=2)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).train()
+    x, sp = torch.from_numpy(golden["train_x"]).to(dev), torch.from_numpy(golden["train_sp"]).to(dev)
+    e = torch.from_numpy(golden["train_e"]).to(dev)
+    stats = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or k.endswith(".step")}
+
+    def grads():
+        m.load_state_dict(stats, strict=False)     # MovingBatchNorm statistics move at every training-mode call: rewind them
+        m.zero_grad()
+        nll, tl = m(x, sp, e=e)
+        (0.01 * nll.sum(2).mean() + 100.0 * tl[:, :, :, :4].mean()).backward()
+        return [p.grad.detach().clone() for p in m.parameters()]
+    a, b = grads(), grads()
+    bad = [n for (n, _), u, v in zip(m.named_parameters(), a, b) if not torch.equal(u, v)]
+    assert not bad, "gradients differ between two identical passes: %s" % bad[:5]
