@@ -186,7 +186,9 @@ def test_chamfer(ops, dev):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 300, 4, 64), (2, 256, 64, 128), (1, 130, 128, 1024), (3, 64, 1536, 512),
                                           (2, 200, 518, 512), (1, 256, 576, 1600), (1, 384, 1600, 1600), (2, 100, 1600, 4),
-                                          (1, 20, 1600, 3078), (1, 1, 1024, 1600)])
+                                          (1, 20, 1600, 3078), (1, 1, 1024, 1600),
+                                          # streaming kernel (P >= 128, Cin >= 192): narrow outputs, ragged rows and K, one wave's worth of rows + 1
+                                          (2, 300, 1600, 4), (1, 129, 200, 130), (2, 260, 1539, 3), (3, 128, 192, 16)])
 def test_conv1x1(ops, dev, B, P_, Cin, Cout):
     ldx = (Cin + 3) // 4 * 4
     x = torch.zeros(B, P_, ldx)
