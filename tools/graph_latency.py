@@ -1,3 +1,4 @@
+"""reconstruct() per-call latency, eager vs hipGraph replay, at small batch.  usage: PYTHONPATH=. python tools/graph_latency.py"""
 import time, torch
 from caspr_amd.models import CaSPR
 from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences

@@ -1,4 +1,5 @@
-import os, time, torch
+"""Latent ODE: 32-workgroup team kernel vs the single-workgroup kernel (difference and time).  usage: PYTHONPATH=. python tools/latent_team_bench.py"""
+import time, torch
 from caspr_amd import ops
 from caspr_amd.models import CaSPR
 from caspr_amd.utils.synthetic import seeded_state_dict
