@@ -179,3 +179,31 @@ def test_training_loss_weights():
     assert torch.allclose(loss1, 100.0 * tn.mean()) and float(c1) == 0.0
     with pytest.raises(ValueError):
         training_loss((nll, tn, tn), 0.01, 100.0)
+
+
+def test_segments_csr_is_a_stable_inverse_index():
+    """train_ops.Segments (host logic of the deterministic scatter-adds): for every target the contributing source rows in
+    ascending order, weights permuted alongside; a gather-sum through it equals index_add_."""
+    from caspr_amd.train_ops import Segments
+    g = np.random.default_rng(4)
+    n_targets, nnz, C = 37, 500, 5
+    tgt = torch.from_numpy(g.integers(0, n_targets, nnz))
+    tgt[tgt == 11] = 12                      # an empty segment
+    w = torch.from_numpy(g.normal(0, 1, nnz).astype(np.float32))
+    rows = torch.from_numpy(g.integers(0, 200, nnz))
+    seg = Segments(tgt, n_targets, weight=w, src_rows=rows)
+    assert seg.start[0] == 0 and seg.start[-1] == nnz and seg.start[12] == seg.start[11]
+    src = torch.from_numpy(g.normal(0, 1, (200, C)).astype(np.float32))
+    got = torch.zeros(n_targets, C)
+    for t in range(n_targets):
+        e0, e1 = int(seg.start[t]), int(seg.start[t + 1])
+        assert (tgt[torch.sort(tgt, stable=True)[1][e0:e1]] == t).all()
+        for e in range(e0, e1):
+            got[t] += seg.w[e] * src[int(seg.row[e])]
+    want = torch.zeros(n_targets, C).index_add_(0, tgt, w.unsqueeze(1) * src[rows])
+    assert torch.allclose(got, want, atol=1e-5)
+    # default source rows = entry positions; equal targets keep ascending positions (stable sort)
+    seg2 = Segments(tgt, n_targets)
+    for t in range(n_targets):
+        r = seg2.row[int(seg2.start[t]):int(seg2.start[t + 1])]
+        assert torch.equal(r, torch.sort(r)[0])
