@@ -1,0 +1,258 @@
+// Pointwise conv with f32 results on the bf16 matrix pipe ("bf16x6"), OPT-IN (CASPR_CONV_BF16X6=1 in ops.py; the
+// default path is the f32 MFMA kernels of gemm.hip).  Same contract as caspr_conv1x1_f32.
+//
+// Every f32 operand is written as the EXACT sum of three bf16 numbers, x = x1 + x2 + x3 (8 significand bits each, by
+// truncation, so every remainder is exact), and a*b is evaluated as a3b1 + a2b2 + a1b3 + a2b1 + a1b2 + a1b1: the six
+// partial products are exact inside v_mfma_f32_16x16x32_bf16 and accumulate in f32; the three dropped terms are below
+// 2^-23 |a||b|.  Measured against an f64 evaluation the result is as close as a sequential f32 FMA chain (max 3.3e-6 vs
+// 4.2e-6 at K=512, tools/micro/bf16x6_gemm.hip), i.e. this is f32 arithmetic on a faster pipe, not a reduced-precision
+// mode: six 16-cycle MFMAs replace eight 32-cycle v_mfma_f32_16x16x4_f32 per 16x16x32 block.
+//
+// Workgroup = 4 waves (2 x 2), tile 256 output channels x 128 points, K chunks of 32; wave tile 128 x 64 (8 x 4 MFMA
+// tiles, 128 accumulator registers).  LDS per chunk (72 KB, single buffer, two workgroups per CU): 3 weight planes of
+// 256 rows x 64 B, filled by LDS-DMA from a pre-swizzled pack (no staging registers), and 3 activation planes of 128 rows
+// x 64 B written by the threads after the split (and the fused GroupNorm/ReLU of the producer, as in gemm.hip).  A
+// row's four 16-byte pieces sit at piece ^ swz(row), swz = 0,3,2,1 per row quad: the 16 lanes of every ds_read_b128
+// lane group ({0-3,12-15,20-27}, ...) then touch 16 distinct 16-byte slots of the 256-byte bank window.
+#include "common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define X6_TM 256
+#define X6_TP 128
+#define X6_PA (X6_TM * 64)     // bytes of one weight plane of a chunk
+#define X6_PB (X6_TP * 64)     // bytes of one activation plane of a chunk
+#define X6_CHUNK (3 * X6_PA)   // packed weight bytes per (channel tile, k chunk)
+#define X6_LDS (3 * X6_PA + 3 * X6_PB)
+
+__device__ __host__ __forceinline__ int x6_swz(int row) { return (0 - (row >> 2)) & 3; }
+__device__ __forceinline__ int x6_off(int row, int piece) { return row * 64 + ((piece ^ x6_swz(row)) << 4); }
+
+// x = h1 + h2 + h3 exactly; each h keeps the top 8 significand bits of what is left (a bf16 value held in f32)
+__device__ __forceinline__ void x6_split(float x, float &h1, float &h2, float &h3)
+{
+    h1 = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r1 = x - h1;
+    h2 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float r2 = r1 - h2;
+    h3 = __uint_as_float(__float_as_uint(r2) & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned x6_pack(float lo, float hi) { return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u); }
+
+// W (Cout, ldw) f32, columns col0 .. col0+Cin-1 -> [channel tile][k chunk][plane][row 0..255][piece'][8 bf16]; rows past
+// Cout are zero.  One thread per (tile, chunk, row, piece).
+__global__ void pack_weight_bf16x3_kernel(const float *__restrict__ w, int ldw, int Cout, int col0, int Cin, unsigned char *__restrict__ out,
+                                          long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int nk = Cin / 32;
+    const int piece = (int)(i & 3), row = (int)((i >> 2) & (X6_TM - 1));
+    const long ck = i >> 10;   // tile * nk + chunk
+    const int kc = (int)(ck % nk), mt = (int)(ck / nk);
+    const int co = mt * X6_TM + row;
+    float h[3][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float v = co < Cout ? w[(long)co * ldw + col0 + kc * 32 + piece * 8 + q] : 0.f;
+        x6_split(v, h[0][q], h[1][q], h[2][q]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        u32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = x6_pack(h[pl][2 * q], h[pl][2 * q + 1]);
+        *(u32x4 *)(out + ck * X6_CHUNK + pl * X6_PA + x6_off(row, piece)) = v;
+    }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned char *__restrict__ wpk, const float *__restrict__ bias,
+                                                                const float *__restrict__ bbias, const float *__restrict__ X,
+                                                                int ldx, const float *__restrict__ in_scale,
+                                                                const float *__restrict__ in_shift, int in_relu, int relu_from,
+                                                                float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int act,
+                                                                int Mt, int Pt)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *sA = lds;
+    unsigned char *sB = lds + 3 * X6_PA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware, bijective for any block count: consecutive work items (the channel tiles of one point tile) share an L2
+    const int nblk = gridDim.x, lin = blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int mt = work % Mt, pt = (work / Mt) % Pt, b = work / (Mt * Pt);
+    const int p0 = pt * X6_TP;
+    const int nk = Cin / 32;
+    // the last channel tile may be mostly padding (zero rows in the pack): a wave without real channels skips the products
+    const int co_w = mt * X6_TM + wm * 128;
+    const bool live = co_w < Cout;   // wave-uniform; a dead wave only stages and meets the barriers
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // activation staging: thread = (row xr, 16-float half xh of the chunk); xh is wave-uniform, so the fused transform's
+    // scale / shift come through scalar loads
+    const int xr = tid & 127, xh = wave >> 1;
+    const float *xsrc = X + ((long)b * P + p0 + xr) * ldx + 16 * xh;
+    const float *sc = FUSED ? in_scale + (long)b * Cin + 16 * xh : nullptr;
+    const float *sh = FUSED ? in_shift + (long)b * Cin + 16 * xh : nullptr;
+    f32x4 xreg[4];
+    const unsigned char *wsrc = wpk + ((long)mt * nk) * X6_CHUNK + (wave * 12) * 1024 + lane * 16;
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xreg[q] = ld4(xsrc + kc * 32 + 4 * q);
+    };
+    auto dma = [&](int kc) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (long)kc * X6_CHUNK + s * 1024),
+                                             (__attribute__((address_space(3))) void *)(sA + (wave * 12 + s) * 1024), 16, 0, 0);
+    };
+    auto lstore = [&](int kc) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            float h[3][8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = xreg[2 * pc + (q >> 2)][q & 3];
+                if (FUSED) {
+                    const int k = kc * 32 + 8 * pc + q;   // relative to the 16 * xh already folded into sc / sh
+                    v = v * sc[k] + sh[k];
+                    if (in_relu && k + 16 * xh >= relu_from) v = v > 0.f ? v : 0.f;
+                }
+                x6_split(v, h[0][q], h[1][q], h[2][q]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                u32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = x6_pack(h[pl][2 * q], h[pl][2 * q + 1]);
+                *(u32x4 *)(sB + pl * X6_PB + x6_off(xr, 2 * xh + pc)) = v;
+            }
+        }
+    };
+
+    gload(0);
+    dma(0);
+    lstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int kn = kc + 1 < nk ? kc + 1 : kc;   // unconditional re-load at the end (a branch here sends registers to scratch)
+        gload(kn);
+        if (live) {
+            bf16x8 bf[3][4];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) bf[pl][ni] = *(const bf16x8 *)(sB + pl * X6_PB + x6_off(wn * 64 + ni * 16 + j, g));
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[pl] = *(const bf16x8 *)(sA + pl * X6_PA + x6_off(wm * 128 + mi * 16 + j, g));
+                // smallest terms first; term-major so four independent accumulators sit between dependent MFMAs
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        dma(kn);
+        lstore(kn);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds channels co + r (D row = 4g + r) of point p (column j); Cout % 4 == 0
+    const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int co = co_w + mi * 16 + 4 * g;
+        if (co >= Cout) continue;
+        f32x4 add = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias) add += ld4(bias + co);
+        if (bb) add += ld4(bb + co);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int p = p0 + wn * 64 + ni * 16 + j;
+            f32x4 v = acc[mi][ni] + add;
+            if (act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = sigmoid_f(v[r]);
+            }
+            st4(Y + ((long)b * P + p) * ldy + co, v);
+        }
+    }
+}
+
+extern "C" long caspr_bf16x3_packed_bytes(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || Cin % 32) return 0;
+    return (long)ceil_div(Cout, X6_TM) * (Cin / 32) * X6_CHUNK;
+}
+
+extern "C" int caspr_pack_weight_bf16x3(const float *w, int ldw, int Cout, int col0, int ncols, void *packed, void *stream)
+{
+    CASPR_REQUIRE(w && packed && Cout > 0 && ncols > 0 && col0 >= 0 && ldw >= col0 + ncols, "pack_weight_bf16x3: bad arguments");
+    CASPR_REQUIRE(ncols % 32 == 0, "pack_weight_bf16x3: the input width %d must be a multiple of 32", ncols);
+    CASPR_REQUIRE(((uintptr_t)packed % 16) == 0, "pack_weight_bf16x3: packed must be 16-byte aligned");
+    const long total = (long)ceil_div(Cout, X6_TM) * (ncols / 32) * 1024;
+    pack_weight_bf16x3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, ldw, Cout, col0, ncols, (unsigned char *)packed, total);
+    CASPR_CHECK_LAUNCH("pack_weight_bf16x3");
+    return CASPR_OK;
+}
+
+extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
+                                        const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
+                                        int ldy, int B, int P, int Cin, int Cout, int act, void *stream)
+{
+    CASPR_REQUIRE(wpk && X && Y && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1_bf16x6: bad arguments");
+    CASPR_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && P % X6_TP == 0,
+                  "conv1x1_bf16x6: needs Cin %% 32 == 0, Cout %% 4 == 0 and P %% 128 == 0 (Cin=%d Cout=%d P=%d); use caspr_conv1x1_f32", Cin, Cout, P);
+    CASPR_REQUIRE(ldx % 4 == 0 && ldx >= Cin, "conv1x1_bf16x6: ldx=%d must be a multiple of 4 and >= Cin=%d", ldx, Cin);
+    CASPR_REQUIRE(ldy % 4 == 0 && ldy >= Cout, "conv1x1_bf16x6: ldy=%d must be a multiple of 4 and >= Cout=%d", ldy, Cout);
+    CASPR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_bf16x6: in_scale/in_shift must be given together");
+    CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wpk % 16) == 0, "conv1x1_bf16x6: pointers must be 16-byte aligned");
+    CASPR_REQUIRE((bias == nullptr || ((uintptr_t)bias % 16) == 0) && (bbias == nullptr || ((uintptr_t)bbias % 16) == 0),
+                  "conv1x1_bf16x6: bias pointers must be 16-byte aligned");
+    CASPR_REQUIRE(in_relu_from >= 0, "conv1x1_bf16x6: in_relu_from=%d must be non-negative", in_relu_from);
+    const int Mt = ceil_div(Cout, X6_TM), Pt = P / X6_TP;
+    const long nblk = (long)Mt * Pt * B;
+    CASPR_REQUIRE(nblk < (1L << 31), "conv1x1_bf16x6: too many tiles (%ld)", nblk);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
+        hipError_t e2 = hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            caspr_set_error("conv1x1_bf16x6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            return CASPR_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    if (in_scale)
+        conv1x1_bf16x6_kernel<true><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(
+            (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt);
+    else
+        conv1x1_bf16x6_kernel<false><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(
+            (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt);
+    CASPR_CHECK_LAUNCH("conv1x1_bf16x6");
+    return CASPR_OK;
+}

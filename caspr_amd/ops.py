@@ -173,8 +173,15 @@ def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale
 
 
 # ---------------------------------------------------------------------------------------------
+# Opt-in: route the large pointwise convs through the bf16x6 kernel (f32-accurate products on the bf16 matrix pipe,
+# csrc/gemm_bf16x6.hip).  Off by default: the headline numbers of bench.py are measured on the f32 MFMA kernels.
+CONV_BF16X6 = os.environ.get("CASPR_CONV_BF16X6", "0") not in ("0", "")
+_X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstraction / input layers)
+
+
 class PackedWeight:
-    """A (Cout, Cin) weight matrix in MFMA A-fragment order (see csrc/common.h)."""
+    """A (Cout, Cin) weight matrix in MFMA A-fragment order (see csrc/common.h); with CASPR_CONV_BF16X6=1 also the
+    three-way bf16 split of csrc/gemm_bf16x6.hip (`x3`) when the shape is supported."""
 
     def __init__(self, w2d, col0=0, ncols=None):
         _chk_f32(w2d)
@@ -184,6 +191,12 @@ class PackedWeight:
         self.data = torch.empty(size, device=w2d.device, dtype=torch.float32)
         _lib.check(_lib.load().caspr_pack_weight_f32(_p(w2d), ldw, self.cout, col0, self.cin, _p(self.data), _stream()),
                    "caspr_pack_weight_f32")
+        self.x3 = None
+        if CONV_BF16X6 and self.cin % 32 == 0 and self.cin >= _X6_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128:
+            nbytes = _lib.load().caspr_bf16x3_packed_bytes(self.cout, self.cin)
+            self.x3 = torch.empty(nbytes, device=w2d.device, dtype=torch.uint8)
+            _lib.check(_lib.load().caspr_pack_weight_bf16x3(_p(w2d), ldw, self.cout, col0, self.cin, _p(self.x3), _stream()),
+                       "caspr_pack_weight_bf16x3")
 
 
 def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, act=0, out=None):
@@ -197,6 +210,11 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
     if out is None:
         out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
     ldy = _chk_rows(out)
+    if pw.x3 is not None and P % 128 == 0:
+        _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                                        int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()),
+                   "caspr_conv1x1_bf16x6_f32")
+        return out
     _lib.check(_lib.load().caspr_conv1x1_f32(_p(pw.data), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
                                              int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()), "caspr_conv1x1_f32")
     return out

@@ -105,6 +105,19 @@ int caspr_conv1x1_f32(const float *wp, const float *bias, const float *bbias, co
                       const float *in_scale, const float *in_shift, int in_relu, int in_relu_from,
                       float *Y, int ldy, int B, int P, int Cin, int Cout, int act, void *stream);
 
+/* The same conv with the products on the bf16 matrix pipe ("bf16x6", csrc/gemm_bf16x6.hip): every f32 operand is split
+ * EXACTLY into three bf16 numbers and six of the nine partial products (all but the three below 2^-23 |a||b|) are
+ * accumulated in f32 -- error vs f64 no larger than a sequential f32 FMA chain's (tools/micro/bf16x6_gemm.hip), at
+ * 1.5-1.8x the rate of the f32 MFMA kernels.  Same argument meaning as caspr_conv1x1_f32; restricted to Cin % 32 == 0,
+ * Cout % 4 == 0, P % 128 == 0 and ldx >= Cin (CASPR_EINVAL otherwise: the caller falls back to caspr_conv1x1_f32).
+ * wpk = the weight split and packed once by caspr_pack_weight_bf16x3 into caspr_bf16x3_packed_bytes(Cout, Cin)
+ * bytes (0 if the shape is not supported).  Opt-in in the Python host (CASPR_CONV_BF16X6=1).                       */
+long caspr_bf16x3_packed_bytes(int Cout, int Cin);
+int caspr_pack_weight_bf16x3(const float *w, int ldw, int Cout, int col0, int ncols, void *packed, void *stream);
+int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
+                             const float *in_scale, const float *in_shift, int in_relu, int in_relu_from,
+                             float *Y, int ldy, int B, int P, int Cin, int Cout, int act, void *stream);
+
 /* GroupNorm statistics of Y (B,P,C) (nn.GroupNorm(G,C), biased variance, eps):
  *   scale[b,c] = gamma[c]*rstd[b,g(c)] ; shift[b,c] = beta[c] - mean[b,g(c)]*scale[b,c]
  * and, when pmax != NULL, pmax[b,c] = max_p (Y[b,p,c]*scale+shift) (tpointnet2.py:111, pointnet.py:42).

@@ -236,6 +236,45 @@ def test_conv1x1_repeatable_under_load(ops, dev):
         exact("conv1x1_repeat", ops.conv1x1(pw, None, x, in_scale=sc, in_shift=sh, in_relu=True), y1)
 
 
+@pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 256, 512, 512), (1, 128, 1600, 1600), (3, 384, 608, 512), (1, 1024, 1536, 132)])
+def test_conv1x1_bf16x6(ops, dev, monkeypatch, B, P_, Cin, Cout):
+    """Opt-in kernel (csrc/gemm_bf16x6.hip): exact three-way bf16 split of both operands, six MFMA products, f32
+    accumulation.  Held to the SAME tolerance as the f32 MFMA kernel, and compared with it directly."""
+    w = rnd(1, Cout, Cin + 4, scale=1.0 / np.sqrt(Cin))
+    b, bb = rnd(2, Cout, scale=0.1), rnd(3, B, Cout, scale=0.1)
+    xw = rnd(Cin + Cout, B, P_, Cin + 8)            # the conv reads a column slice of a wider buffer
+    x = xw[:, :, 8:]
+    sc, sh = rnd(4, B, Cin).abs() + 0.5, rnd(5, B, Cin)
+    monkeypatch.setattr(ops, "CONV_BF16X6", False)
+    pw32 = ops.PackedWeight(w.to(dev), col0=4)
+    assert pw32.x3 is None
+    monkeypatch.setattr(ops, "CONV_BF16X6", True)
+    pw = ops.PackedWeight(w.to(dev), col0=4)
+    assert pw.x3 is not None and torch.equal(pw.data, pw32.data)
+    xd = xw.to(dev)[:, :, 8:]
+    # plain
+    want = x.double() @ w[:, 4:].double().t() + b.double()
+    got = ops.conv1x1(pw, b.to(dev), xd)
+    ref = ops.conv1x1(pw32, b.to(dev), xd)
+    tol = 2e-6 * max(1.0, float(want.abs().max()))
+    record("conv1x1_bf16x6_%dx%d" % (Cin, Cout), got[:, :, :Cout], want, tol)
+    e6, e32 = float((got.cpu().double()[:, :, :Cout] - want).abs().max()), float((ref.cpu().double()[:, :, :Cout] - want).abs().max())
+    assert e6 <= 1.5 * e32 + 1e-7, (e6, e32)         # as close to f64 as the f32 MFMA kernel
+    # fused producer GroupNorm + ReLU (from channel 64 on), per-batch bias, into a slice of a wider output
+    xin = x * sc.unsqueeze(1) + sh.unsqueeze(1)
+    xin[:, :, 64:] = torch.relu(xin[:, :, 64:])
+    want = xin.double() @ w[:, 4:].double().t() + b.double() + bb.double().unsqueeze(1)
+    buf = torch.zeros(B, P_, Cout + 8, device=dev)
+    got = ops.conv1x1(pw, b.to(dev), xd, bbias=bb.to(dev), in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True, in_relu_from=64,
+                      out=buf[:, :, 4:4 + Cout])
+    record("conv1x1_bf16x6_fused_%dx%d" % (Cin, Cout), got, want, 2e-6 * max(1.0, float(want.abs().max())))
+    assert float(buf[:, :, :4].abs().max()) == 0.0 and float(buf[:, :, 4 + Cout:].abs().max()) == 0.0
+    exact("conv1x1_bf16x6_repeat", ops.conv1x1(pw, b.to(dev), xd), ops.conv1x1(pw, b.to(dev), xd))
+    # unsupported row counts fall back to the f32 kernel
+    xs = xd[:, :100].contiguous()
+    exact("conv1x1_bf16x6_fallback", ops.conv1x1(pw, b.to(dev), xs), ops.conv1x1(pw32, b.to(dev), xs))
+
+
 @pytest.mark.parametrize("B,P_,C", [(2, 2500, 64), (1, 1024, 1600), (3, 64, 512), (2, 1100, 1024), (2, 333, 128)])
 def test_gn_stats(ops, dev, B, P_, C):
     y = rnd(C, B, P_, C) * 2.0 + 0.7

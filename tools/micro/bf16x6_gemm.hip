@@ -102,7 +102,8 @@ __device__ __forceinline__ int piece_off(int row, int piece) { return row * 64 +
 // wpk: weights packed on the host as [co tile][k chunk][plane][row 0..TM-1][piece'] (already swizzled), so the copy
 // into LDS is linear: it goes through the LDS-DMA path (global_load_lds_dwordx4, 1 KB per wave instruction, no staging
 // registers and no ds_write).  Activations are staged through registers because they are split on the way.
-template <int TM_>   // 128: wave tile 64 x 64, 48 KB LDS; 256: wave tile 128 x 64, 72 KB LDS
+template <int TM_, int DIAG = 0>   // DIAG 1: no split arithmetic, 2: no activation staging, 3: no staging at all (timing only)
+// 128: wave tile 64 x 64, 48 KB LDS; 256: wave tile 128 x 64, 72 KB LDS
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const u32x4 *__restrict__ wpk, const float *__restrict__ X,
                                                                 float *__restrict__ Y, int P, int K, int Cout)
 {
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const u32x4 *__r
         for (int pc = 0; pc < 2; ++pc) {
             float h[3][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) split3(xreg[2 * pc + (q >> 2)][q & 3], h[0][q], h[1][q], h[2][q]);
+            for (int q = 0; q < 8; ++q) {
+                if (DIAG == 1) h[0][q] = h[1][q] = h[2][q] = xreg[2 * pc + (q >> 2)][q & 3];
+                else split3(xreg[2 * pc + (q >> 2)][q & 3], h[0][q], h[1][q], h[2][q]);
+            }
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 u32x4 v;
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const u32x4 *__r
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
-        dma(kn);
-        lstore();
+        if (DIAG < 3) dma(kn);
+        if (DIAG < 2) lstore();
         __syncthreads();
     }
     // lane holds channels co0 + 4g + r of point p (D row = 4g + r, column = j)
@@ -304,6 +308,27 @@ int main(int argc, char **argv)
         };
         CHECK(hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
         CHECK(hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+        if (TMv == 256 && getenv("BX6_DIAG")) {
+            CHECK(hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+            CHECK(hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+            CHECK(hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+            for (int d = 1; d <= 3; ++d) {
+                auto dl = [&]() {
+                    if (d == 1) conv1x1_bf16x6_kernel<256, 1><<<blocks, 256, lds_bytes>>>(dW, dX, dY, P, K, Cout);
+                    if (d == 2) conv1x1_bf16x6_kernel<256, 2><<<blocks, 256, lds_bytes>>>(dW, dX, dY, P, K, Cout);
+                    if (d == 3) conv1x1_bf16x6_kernel<256, 3><<<blocks, 256, lds_bytes>>>(dW, dX, dY, P, K, Cout);
+                };
+                dl();
+                CHECK(hipEventRecord(e0));
+                for (int rep = 0; rep < 10; ++rep) dl();
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float dms;
+                CHECK(hipEventElapsedTime(&dms, e0, e1));
+                printf("  diag %d (%s): %.3f ms  %.1f TFLOP/s-equivalent\n", d, d == 1 ? "no split arithmetic" : d == 2 ? "no activation staging" : "no staging",
+                       dms / 10, 2.0 * P * (double)K * Cout / (dms / 10) / 1e9);
+            }
+        }
         for (int rep = 0; rep < 3; ++rep) launch();
         CHECK(hipDeviceSynchronize());
         const int reps = 20;
