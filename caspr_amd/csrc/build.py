@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["point_ops.hip", "gemm.hip", "gemm_bf16x6.hip", "sa_mlp.hip", "ode.hip", "backward.hip", "backward_points.hip", "backward_flow.hip", "emd.hip"]
+SOURCES = ["point_ops.hip", "gemm.hip", "gemm_bf16x6.hip", "sa_mlp.hip", "ode.hip", "ode_bf16x6.hip", "backward.hip", "backward_points.hip", "backward_flow.hip", "emd.hip"]
 EXTRA = {"point_ops.hip": ["-ffp-contract=off"], "emd.hip": ["-ffp-contract=off"]}
 OUT = os.path.join(HERE, "libcaspr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,326 @@
+// ode_bf16x6.hip -- the point-CNF sampling solve (cnf.py:70-128 reverse direction, no divergence) with the two 512x512
+// hidden layers on the bf16 matrix pipe in the exact three-way split of gemm_bf16x6.hip.  OPT-IN
+// (CASPR_CNF_BF16X6=1 in the Python host); the default is cnf_rk4_kernel of ode.hip on f32 MFMA.
+//
+// Different geometry from the f32 kernel, forced by the 2.67x faster products (weights can no longer be streamed from L2
+// into every wave's fragments: 4x the bytes per MFMA cycle):
+//  * a 256-thread workgroup owns 64 points of one frame; WAVE w owns ALL 512 hidden units of its 16 points
+//    (32 row tiles x 1 column tile = 128 accumulator registers), one wave per SIMD, one workgroup per CU;
+//  * the hidden activation never touches LDS: an accumulator (D) fragment holds rows 4g..4g+3 of a 16-row tile for
+//    column j, a bf16 B fragment holds 8 k-slots for column j -- two row tiles ARE one B fragment of the next layer
+//    once the weight pack lists its k in the same order (slot s of lane group g <-> unit 32kc + 4g + s for s < 4,
+//    32kc + 16 + 4g + s - 4 above).  The epilogue (gate * acc + bias, softplus, split) writes the next layer's 16 x 3
+//    B fragments straight into registers (192 VGPRs);
+//  * LDS is the weight stage shared by the four waves: 48 KB pieces (256 rows x 32 k x 3 planes, pre-swizzled image)
+//    arrive by LDS-DMA, double-buffered, one barrier per piece (96 MFMAs = 1536 matrix-pipe cycles per wave);
+//  * input layer 3 -> 512, output layer 512 -> 3, the RK4 state and its update are wave-local (state component d of
+//    column j lives in lane 16 d + j).
+#include "common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define XC_H 512
+#define XC_COLS 64
+#define XC_PA (256 * 64)          // one plane of a piece
+#define XC_PIECE (3 * XC_PA)      // 48 KB
+#define XC_NPIECE 32              // per layer: 16 k chunks x 2 row halves
+#define XC_LDS (2 * XC_PIECE + (6 * XC_H + 3 * XC_H + 8) * 4)
+
+__device__ __forceinline__ void xc_split(float x, float &h1, float &h2, float &h3)
+{
+    h1 = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r1 = x - h1;
+    h2 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float r2 = r1 - h2;
+    h3 = __uint_as_float(__float_as_uint(r2) & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned xc_pack(float lo, float hi) { return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u); }
+
+struct CnfX6Args {
+    const float *y_in, *hyper, *tcol, *w0, *b0, *b1, *b2, *w3, *b3, *mbn_in, *mbn_out;
+    const unsigned char *w1x, *w2x;
+    float *y_out;
+    int ldh, n, steps, reverse;
+    float t_end;
+};
+
+__global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *wbuf = lds;                                  // [2][XC_PIECE]
+    float *s_gate = (float *)(lds + 2 * XC_PIECE);              // [3][512] sigmoid gates of layers 0,1,2
+    float *s_hb = s_gate + 3 * XC_H;                            // [3][512] layer bias * gate + hyper bias
+    float *s_w0 = s_hb + 3 * XC_H;                              // [512][3]
+    float *s_g3 = s_w0 + 3 * XC_H;                              // [8]: gate3[3], hb3[3]
+
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g0 = lane0 >> 4;
+    const int bt = blockIdx.y;
+    const int col = blockIdx.x * XC_COLS + 16 * wave + (lane0 & 15);
+    const bool cvalid = col < a.n;
+    const int ccol = cvalid ? col : a.n - 1;
+    const float *hy = a.hyper + (long)bt * a.ldh;
+    constexpr int GOFF = 0, BOFF = 3 * XC_H + 3;
+    const int sd = g0 < 3 ? g0 : 0;   // state component of this lane (lanes g == 3 carry a copy of component 0, never stored)
+
+    for (int i = tid; i < 3 * XC_H; i += 256) s_w0[i] = a.w0[i];
+
+    float y, kacc = 0.f, kprev = 0.f;
+    {
+        float v = a.y_in[((long)bt * a.n + ccol) * 3 + sd];
+        if (a.mbn_in) {
+            const float w = a.mbn_in[sd], bb = a.mbn_in[3 + sd], mean = a.mbn_in[6 + sd], var = a.mbn_in[9 + sd];
+            if (a.reverse) v = (v - bb) * expf(-w) * expf(0.5f * logf(var + 1e-4f)) + mean;   // normalization.py:92-94
+            else v = (v - mean) * expf(-0.5f * logf(var + 1e-4f)) * expf(w) + bb;             // normalization.py:70-74
+        }
+        y = v;
+    }
+
+    // LDS-DMA of piece p (k chunk p >> 1, row half p & 1) of a layer's pack [row half][k chunk][48 KB image]:
+    // scalar base + one 32-bit lane offset (anything lane-dependent hoisted out of the stage loop ends up in scratch)
+    auto dma = [&](const unsigned char *wx, int p, int buf, int lane16) {
+        const unsigned char *src = wx + (long)((p & 1) * 16 + (p >> 1)) * XC_PIECE + (wave * 12) * 1024;
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + s * 1024 + lane16),
+                                             (__attribute__((address_space(3))) void *)(wbuf + buf * XC_PIECE + (wave * 12 + s) * 1024), 16, 0, 0);
+    };
+
+    const double t0 = a.reverse ? (double)a.t_end : 0.0, t1 = a.reverse ? 0.0 : (double)a.t_end;
+    const double h = (t1 - t0) / (double)a.steps;
+    const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
+
+    dma(a.w1x, 0, 0, lane0 * 16);   // first piece of layer 1; every layer pass leaves the NEXT pass's first piece in flight
+
+    bf16x8 bfr[16][3];   // B fragments of the layer input: [k chunk][plane]
+    f32x4 acc[32];
+
+    // 8 f32 activations (the 8 k-slots of this lane in chunk kc) -> three bf16 planes
+    auto to_bfr = [&](int kc, const float (&hv)[8]) {
+        float hs[3][8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xc_split(hv[s], hs[0][s], hs[1][s], hs[2][s]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            u32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = xc_pack(hs[pl][2 * q], hs[pl][2 * q + 1]);
+            bfr[kc][pl] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+
+    for (int step = 0; step < a.steps; ++step) {
+#pragma unroll 1
+        for (int stage = 0; stage < 4; ++stage) {
+            const double tc = (stage == 0) ? 0.0 : (stage == 3 ? 1.0 : 0.5);
+            const float t = (float)(t0 + (double)step * h + tc * h);
+            const float aw = (stage == 0) ? 0.f : (stage == 3 ? hh : h2);
+            // Opaque copy of the lane id: everything derived from it (LDS offsets, DMA offsets, table addresses) is
+            // recomputed per stage instead of being hoisted out of the 32-stage loop and spilled (as in ode.hip).
+            int lane = lane0;
+            asm volatile("" : "+v"(lane));
+            const int g = lane >> 4, j = lane & 15, lane16 = lane * 16;
+            // A-fragment read offset inside a plane: row (lane & 15) of a 16-row tile, piece g, swizzled as the pack
+            const int aoff = j * 64 + ((g ^ ((0 - (j >> 2)) & 3)) << 4);
+            __syncthreads();   // the previous stage's epilogues are done with the gate tables
+            for (int i = tid; i < 3 * XC_H; i += 256) {
+                const float gt = sigmoid_fast(hy[GOFF + i] + t * a.tcol[GOFF + i]);
+                const float hb = hy[BOFF + i] + t * a.tcol[BOFF + i];
+                const float bl = i < XC_H ? a.b0[i] : (i < 2 * XC_H ? a.b1[i - XC_H] : a.b2[i - 2 * XC_H]);
+                s_gate[i] = gt;
+                s_hb[i] = bl * gt + hb;
+            }
+            if (tid < 3) {
+                const float gt = sigmoid_fast(hy[GOFF + 3 * XC_H + tid] + t * a.tcol[GOFF + 3 * XC_H + tid]);
+                const float hb = hy[BOFF + 3 * XC_H + tid] + t * a.tcol[BOFF + 3 * XC_H + tid];
+                s_g3[tid] = gt;
+                s_g3[4 + tid] = a.b3[tid] * gt + hb;
+            }
+            __syncthreads();
+
+            // ---- stage input of this lane's column, all three components
+            const float ystage = (stage == 0) ? y : y + aw * kprev;
+            const float y0 = __shfl(ystage, j), y1 = __shfl(ystage, 16 + j), y2 = __shfl(ystage, 32 + j);
+
+            // ---- input layer 3 -> 512 (diffeq_layers.py:83-90 + softplus) straight into B fragments
+#pragma unroll
+            for (int kc = 0; kc < 16; ++kc) {
+                float hv[8];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int c = 32 * kc + 16 * half + 4 * g;
+                    const f32x4 gt = ld4(s_gate + c), hb = ld4(s_hb + c);
+                    const f32x4 wa = ld4(s_w0 + 3 * c), wb = ld4(s_w0 + 3 * c + 4), wc = ld4(s_w0 + 3 * c + 8);
+                    const float w[12] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0], wc[1], wc[2], wc[3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pre = (w[3 * r] * y0 + w[3 * r + 1] * y1 + w[3 * r + 2] * y2) * gt[r] + hb[r];
+                        hv[4 * half + r] = softplus_fast(pre);
+                    }
+                }
+                to_bfr(kc, hv);
+                __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every chunk's table loads (spills)
+            }
+
+            float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int L = 0; L < 2; ++L) {
+                const unsigned char *wx = L == 0 ? a.w1x : a.w2x;
+                const unsigned char *wnext = L == 0 ? a.w2x : a.w1x;
+#pragma unroll
+                for (int mi = 0; mi < 32; ++mi) acc[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < XC_NPIECE; ++p) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();   // piece p has landed for every wave; everybody is done reading the other buffer
+                    if (p + 1 < XC_NPIECE) dma(wx, p + 1, (p + 1) & 1, lane16);
+                    else dma(wnext, 0, 0, lane16);
+                    const int kc = p >> 1, mt = p & 1;
+                    const unsigned char *A = wbuf + (p & 1) * XC_PIECE + aoff;
+#pragma unroll
+                    for (int m4 = 0; m4 < 4; ++m4) {
+                        bf16x8 af[4][3];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) af[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (m4 * 4 + u) * 1024);
+                        // smallest terms first; term-major: four independent accumulators between dependent MFMAs
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][2], bfr[kc][0], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], bfr[kc][1], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], bfr[kc][2], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], bfr[kc][0], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], bfr[kc][1], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], bfr[kc][0], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+                    }
+                }
+                int le = lane;   // opaque again: the epilogue's table / w3 addresses must not be hoisted above the product loop
+                asm volatile("" : "+v"(le));
+                const int ge = le >> 4;
+                if (L == 0) {
+                    // ---- epilogue of hidden layer 1: the accumulators become layer 2's B fragments
+#pragma unroll
+                    for (int kc = 0; kc < 16; ++kc) {
+                        float hv[8];
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const int c = 32 * kc + 16 * half + 4 * ge;
+                            const f32x4 gt = ld4(s_gate + XC_H + c), hb = ld4(s_hb + XC_H + c);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hv[4 * half + r] = softplus_fast(acc[2 * kc + half][r] * gt[r] + hb[r]);
+                        }
+                        to_bfr(kc, hv);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    // ---- epilogue of hidden layer 2 + the 512 -> 3 output layer as a per-lane partial dot product
+#pragma unroll
+                    for (int mi = 0; mi < 32; ++mi) {
+                        const int c = 16 * mi + 4 * ge;
+                        const f32x4 gt = ld4(s_gate + 2 * XC_H + c), hb = ld4(s_hb + 2 * XC_H + c);
+                        const f32x4 wx3 = ld4(a.w3 + c), wy3 = ld4(a.w3 + XC_H + c), wz3 = ld4(a.w3 + 2 * XC_H + c);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float hv = softplus_fast(acc[mi][r] * gt[r] + hb[r]);
+                            part[0] += wx3[r] * hv;
+                            part[1] += wy3[r] * hv;
+                            part[2] += wz3[r] * hv;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            // ---- output ConcatSquash (no softplus: odefunc.py:103): sum the four lane groups, every lane gets all three
+            float o[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v = part[d];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                o[d] = v * s_g3[d] + s_g3[4 + d];
+            }
+            const float od = sd == 0 ? o[0] : (sd == 1 ? o[1] : o[2]);
+            kprev = od;
+            kacc = (stage == 0) ? od : ((stage == 3) ? kacc + od : kacc + 2.0f * od);
+        }
+        y = y + h6 * kacc;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetch left in flight by the last layer pass
+
+    if (cvalid && g0 < 3) {
+        float v = y;
+        if (a.mbn_out) {
+            const float w = a.mbn_out[sd], bb = a.mbn_out[3 + sd], mean = a.mbn_out[6 + sd], var = a.mbn_out[9 + sd];
+            if (a.reverse) v = (v - bb) * expf(-w) * expf(0.5f * logf(var + 1e-4f)) + mean;
+            else v = (v - mean) * expf(-0.5f * logf(var + 1e-4f)) * expf(w) + bb;
+        }
+        a.y_out[((long)bt * a.n + col) * 3 + sd] = v;
+    }
+}
+
+// (512, ldw) f32 hidden-layer weight -> [row half][k chunk][plane][row 0..255][piece'][8 bf16], k listed in the
+// D-fragment order of the producing layer (see the header): piece g, element q <-> k = 32 kc + (q < 4 ? 4g + q : 16 + 4g + q - 4)
+__global__ void pack_weight_cnf_x6_kernel(const float *__restrict__ w, int ldw, unsigned char *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (tile * 16 + chunk) * 1024 + row * 4 + piece
+    if (i >= 2L * 16 * 1024) return;
+    const int piece = (int)(i & 3), row = (int)((i >> 2) & 255);
+    const int ck = (int)(i >> 10), kc = ck & 15, mt = ck >> 4;
+    const int co = mt * 256 + row;
+    float hs[3][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = 32 * kc + (q < 4 ? 4 * piece + q : 16 + 4 * piece + q - 4);
+        xc_split(w[(long)co * ldw + k], hs[0][q], hs[1][q], hs[2][q]);
+    }
+    const int sw = (0 - (row >> 2)) & 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        u32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = xc_pack(hs[pl][2 * q], hs[pl][2 * q + 1]);
+        *(u32x4 *)(out + (long)ck * XC_PIECE + pl * XC_PA + row * 64 + ((piece ^ sw) << 4)) = v;
+    }
+}
+
+extern "C" long caspr_cnf_x6_packed_bytes(void) { return 2L * 16 * XC_PIECE; }
+
+extern "C" int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream)
+{
+    CASPR_REQUIRE(w && packed && ldw >= XC_H, "pack_weight_cnf_x6: bad arguments");
+    CASPR_REQUIRE(((uintptr_t)packed % 16) == 0, "pack_weight_cnf_x6: packed must be 16-byte aligned");
+    pack_weight_cnf_x6_kernel<<<2 * 16 * 1024 / 256, 256, 0, (hipStream_t)stream>>>(w, ldw, (unsigned char *)packed);
+    CASPR_CHECK_LAUNCH("pack_weight_cnf_x6");
+    return CASPR_OK;
+}
+
+extern "C" int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int ldh, const float *tcol, const float *w0,
+                                    const float *b0, const void *w1x, const float *b1, const void *w2x, const float *b2,
+                                    const float *w3, const float *b3, int H, float t_end, int steps, int reverse,
+                                    const float *mbn_in, const float *mbn_out, float *y_out, int BT, int n, void *stream)
+{
+    CASPR_REQUIRE(y_in && hyper && tcol && w0 && b0 && w1x && b1 && w2x && b2 && w3 && b3 && y_out, "cnf_rk4_x6: null pointer");
+    CASPR_REQUIRE(H == XC_H, "cnf_rk4_x6: hidden width %d unsupported (kernel is built for 512-512-512, flow.py:89)", H);
+    CASPR_REQUIRE(BT > 0 && BT <= 65535 && n > 0 && steps > 0 && ldh >= 2 * (3 * H + 3), "cnf_rk4_x6: bad sizes");
+    CASPR_REQUIRE(((uintptr_t)w1x % 16) == 0 && ((uintptr_t)w2x % 16) == 0 && ((uintptr_t)w0 % 16) == 0 && ((uintptr_t)w3 % 16) == 0,
+                  "cnf_rk4_x6: weights must be 16-byte aligned");
+    CnfX6Args a;
+    a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.b1 = b1; a.b2 = b2; a.w3 = w3; a.b3 = b3;
+    a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.w1x = (const unsigned char *)w1x; a.w2x = (const unsigned char *)w2x;
+    a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
+    hipError_t err = hipFuncSetAttribute((const void *)cnf_rk4_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
+    if (err != hipSuccess) {
+        caspr_set_error("cnf_rk4_x6: hipFuncSetAttribute(%d) failed: %s", XC_LDS, hipGetErrorString(err));
+        return CASPR_ELAUNCH;
+    }
+    cnf_rk4_x6_kernel<<<dim3(ceil_div(n, XC_COLS), BT), dim3(256), XC_LDS, (hipStream_t)stream>>>(a);
+    CASPR_CHECK_LAUNCH("cnf_rk4_x6");
+    return CASPR_OK;
+}

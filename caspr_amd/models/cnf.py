@@ -58,6 +58,9 @@ class CNF(nn.Module):
                 "w1p": ops.PackedWeight(layers[1]._layer.weight.detach().contiguous()), "b1": layers[1]._layer.bias.detach().contiguous(),
                 "w2p": ops.PackedWeight(layers[2]._layer.weight.detach().contiguous()), "b2": layers[2]._layer.bias.detach().contiguous(),
                 "w3": layers[3]._layer.weight.detach().contiguous(), "b3": layers[3]._layer.bias.detach().contiguous(),
+                # opt-in bf16x6 sampling kernel (ops.CNF_BF16X6): three-plane bf16 packs of the hidden layers
+                "w1x": ops.pack_cnf_x6(layers[1]._layer.weight.detach().contiguous()) if ops.CNF_BF16X6 and H == 512 else None,
+                "w2x": ops.pack_cnf_x6(layers[2]._layer.weight.detach().contiguous()) if ops.CNF_BF16X6 and H == 512 else None,
             }
         return self._cache.get("w", srcs, build)
 
@@ -86,7 +89,7 @@ class CNF(nn.Module):
             self.odefunc._e = e
         res = ops.cnf_rk4(x.contiguous(), hyper, w["tcol"], w["w0"], w["b0"], w["w1p"], w["b1"], w["w2p"], w["b2"], w["w3"], w["b3"],
                           self.end_time(), self.rk4_steps, reverse, mbn_in, mbn_out, e=e,
-                          logp=None if logpx is None else logpx.contiguous())
+                          logp=None if logpx is None else logpx.contiguous(), w1x=w["w1x"], w2x=w["w2x"])
         self.odefunc._num_evals += 4 * self.rk4_steps
         return res
 

@@ -305,12 +305,33 @@ def latent_rk4(z0, times, steps, wts):
     return out
 
 
+# Opt-in: the sampling solve of the point CNF on the bf16 matrix pipe (csrc/ode_bf16x6.hip), see DESIGN.md section 3.
+CNF_BF16X6 = os.environ.get("CASPR_CNF_BF16X6", "0") not in ("0", "")
+
+
+def pack_cnf_x6(w):
+    """(512,512) hidden-layer weight of the ODE function -> the three-plane bf16 pack of caspr_cnf_rk4_x6_f32."""
+    _chk_f32(w)
+    if tuple(w.shape) != (512, 512):
+        raise ValueError("pack_cnf_x6: expected a (512,512) weight, got %s" % (tuple(w.shape),))
+    out = torch.empty(_lib.load().caspr_cnf_x6_packed_bytes(), device=w.device, dtype=torch.uint8)
+    _lib.check(_lib.load().caspr_pack_weight_cnf_x6(_p(w), w.stride(0), _p(out), _stream()), "caspr_pack_weight_cnf_x6")
+    return out
+
+
 def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reverse, mbn_in=None, mbn_out=None,
-            e=None, logp=None):
-    """Fixed-step RK4 of one CNF block (cnf.py:70-128).  y (BT,n,3); hyper (BT,ldh).  Returns x or (x, logp)."""
+            e=None, logp=None, w1x=None, w2x=None):
+    """Fixed-step RK4 of one CNF block (cnf.py:70-128).  y (BT,n,3); hyper (BT,ldh).  Returns x or (x, logp).
+    w1x / w2x (pack_cnf_x6): when given and no divergence is integrated, the bf16x6 kernel runs the solve."""
     _chk_f32(y, hyper, tcol, w0, b0, b1, b2, w3, b3, mbn_in, mbn_out, e, logp)
     BT, n, _ = y.shape
     out = torch.empty_like(y)
+    if e is None and w1x is not None and w2x is not None:
+        with timed("cnf_rk4"):
+            _lib.check(_lib.load().caspr_cnf_rk4_x6_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1x), _p(b1), _p(w2x),
+                                                        _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps), int(bool(reverse)),
+                                                        _p(mbn_in), _p(mbn_out), _p(out), BT, n, _stream()), "caspr_cnf_rk4_x6_f32")
+        return out
     lp_out = torch.empty(BT, n, 1, device=y.device, dtype=torch.float32) if e is not None else None
     with timed("cnf_rk4"):
         _lib.check(_lib.load().caspr_cnf_rk4_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1p.data), _p(b1),

@@ -164,6 +164,20 @@ int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const floa
                       const float *e, const float *logp_in, float *logp_out, float *y_out, int BT,
                       int n, void *stream);
 
+/* The same solve WITHOUT the divergence (sampling, e == NULL) with the two hidden layers on the bf16 matrix pipe in the
+ * exact three-way split of caspr_conv1x1_bf16x6_f32 (csrc/ode_bf16x6.hip): a workgroup owns 64 points, each wave keeps
+ * all 512 hidden units of its 16 points in registers across the layers (accumulator fragments are the next layer's
+ * operand fragments), LDS only stages the shared weight pieces.  w1x / w2x = the (512,512) hidden weights packed by
+ * caspr_pack_weight_cnf_x6 (caspr_cnf_x6_packed_bytes() bytes each); other arguments as caspr_cnf_rk4_f32.  Opt-in in
+ * the Python host (CASPR_CNF_BF16X6=1).                                                                              */
+long caspr_cnf_x6_packed_bytes(void);
+int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream);
+int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int ldh, const float *tcol,
+                         const float *w0, const float *b0, const void *w1x, const float *b1,
+                         const void *w2x, const float *b2, const float *w3, const float *b3, int H,
+                         float t_end, int steps, int reverse, const float *mbn_in, const float *mbn_out,
+                         float *y_out, int BT, int n, void *stream);
+
 /* ---------------- Chamfer (tk3dv.extern.chamfer.ChamferDistance): utils/evaluations.py:40 --------
  * p (B,n,3), q (B,m,3) -> dist1 (B,n) = min_j |p_i-q_j|^2 , dist2 (B,m).                            */
 int caspr_chamfer_f32(const float *p, const float *q, int B, int n, int m, float *dist1, float *dist2,

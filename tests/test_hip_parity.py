@@ -342,6 +342,33 @@ def test_cnf_sample(dev, seeded_sd, model, n, steps):
     record("cnf_sample_n%d_s%d" % (n, steps), got, want, 1e-5)
 
 
+@pytest.mark.parametrize("n,steps", [(256, 8), (100, 3), (2048, 2)])
+def test_cnf_sample_bf16x6(dev, seeded_sd, model, n, steps):
+    """Opt-in sampling kernel (csrc/ode_bf16x6.hip): hidden layers as six bf16 MFMA products of exactly split operands,
+    activations kept in registers between the layers.  Same 1e-5 criterion against the oracle as the f32 kernel, and
+    within 5e-6 of the f32 kernel itself."""
+    from caspr_amd import ops
+    BT = 3
+    c, y = rnd(31, BT, 1600), rnd(32, BT, n, 3)
+    want = O.point_cnf(seeded_sd, y, c, None, True, "rk4", steps)
+    cnf = model.point_cnf.chain[1]
+    cnf.rk4_steps = steps
+    w = cnf._weights()
+    layers = cnf.odefunc.diffeq.layers
+    try:
+        ref = model.point_cnf(y.to(dev), c.to(dev), reverse=True)
+        w["w1x"] = ops.pack_cnf_x6(layers[1]._layer.weight.detach().contiguous())
+        w["w2x"] = ops.pack_cnf_x6(layers[2]._layer.weight.detach().contiguous())
+        got = model.point_cnf(y.to(dev), c.to(dev), reverse=True)
+        again = model.point_cnf(y.to(dev), c.to(dev), reverse=True)
+    finally:
+        w["w1x"] = w["w2x"] = None
+        cnf.rk4_steps = 8
+    record("cnf_sample_bf16x6_n%d_s%d" % (n, steps), got, want, 1e-5)
+    record("cnf_sample_bf16x6_vs_f32_n%d_s%d" % (n, steps), got, ref, 5e-6)
+    exact("cnf_sample_bf16x6_repeat", again, got)
+
+
 def test_cnf_forward_with_divergence(dev, seeded_sd, model):
     BT, n = 2, 96
     c, x, e = rnd(41, BT, 1600), rnd(42, BT, n, 3, scale=0.5), rnd(43, BT, n, 3)
