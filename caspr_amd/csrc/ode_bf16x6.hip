@@ -11,8 +11,9 @@
 //    once the weight pack lists its k in the same order (slot s of lane group g <-> unit 32kc + 4g + s for s < 4,
 //    32kc + 16 + 4g + s - 4 above).  The epilogue (gate * acc + bias, softplus, split) writes the next layer's 16 x 3
 //    B fragments straight into registers (192 VGPRs);
-//  * LDS is the weight stage shared by the four waves: 48 KB pieces (256 rows x 32 k x 3 planes, pre-swizzled image)
-//    arrive by LDS-DMA, double-buffered, one barrier per piece (96 MFMAs = 1536 matrix-pipe cycles per wave);
+//  * LDS is the weight stage shared by the four waves: 24 KB pieces (128 rows x 32 k x 3 planes, pre-swizzled image)
+//    arrive by LDS-DMA into a ring of four, three in flight while one is used (counted s_waitcnt vmcnt + raw
+//    s_barrier per piece of 48 MFMAs = 768 matrix-pipe cycles per wave);
 //  * input layer 3 -> 512, output layer 512 -> 3, the RK4 state and its update are wave-local (state component d of
 //    column j lives in lane 16 d + j).
 #include "common.h"
@@ -22,10 +23,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define XC_H 512
 #define XC_COLS 64
-#define XC_PA (256 * 64)          // one plane of a piece
-#define XC_PIECE (3 * XC_PA)      // 48 KB
-#define XC_NPIECE 32              // per layer: 16 k chunks x 2 row halves
-#define XC_LDS (2 * XC_PIECE + (6 * XC_H + 3 * XC_H + 8) * 4)
+#define XC_PA (128 * 64)          // one plane of a piece
+#define XC_PIECE (3 * XC_PA)      // 24 KB: 128 rows x 32 k x 3 planes
+#define XC_NPIECE 64              // per layer: 16 k chunks x 4 row blocks
+#define XC_PARK 10                // k chunks whose B fragments are parked in AGPRs
+#define XC_RING 4                 // LDS ring of pieces: three are in flight while one is being used
+#define XC_LDS (XC_RING * XC_PIECE + (6 * XC_H + 3 * XC_H + 8) * 4)
 
 __device__ __forceinline__ void xc_split(float x, float &h1, float &h2, float &h3)
 {
@@ -43,13 +46,14 @@ struct CnfX6Args {
     float *y_out;
     int ldh, n, steps, reverse;
     float t_end;
+    int diag;   // timing experiments only (CASPR_X6_DIAG): 1 = no weight DMA, 2 = no product loop, 4 = no piece barriers
 };
 
 __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char *wbuf = lds;                                  // [2][XC_PIECE]
-    float *s_gate = (float *)(lds + 2 * XC_PIECE);              // [3][512] sigmoid gates of layers 0,1,2
+    unsigned char *wbuf = lds;                                  // [XC_RING][XC_PIECE]
+    float *s_gate = (float *)(lds + XC_RING * XC_PIECE);              // [3][512] sigmoid gates of layers 0,1,2
     float *s_hb = s_gate + 3 * XC_H;                            // [3][512] layer bias * gate + hyper bias
     float *s_w0 = s_hb + 3 * XC_H;                              // [512][3]
     float *s_g3 = s_w0 + 3 * XC_H;                              // [8]: gate3[3], hb3[3]
@@ -78,24 +82,49 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
         y = v;
     }
 
-    // LDS-DMA of piece p (k chunk p >> 1, row half p & 1) of a layer's pack [row half][k chunk][48 KB image]:
-    // scalar base + one 32-bit lane offset (anything lane-dependent hoisted out of the stage loop ends up in scratch)
-    auto dma = [&](const unsigned char *wx, int p, int buf, int lane16) {
-        const unsigned char *src = wx + (long)((p & 1) * 16 + (p >> 1)) * XC_PIECE + (wave * 12) * 1024;
+    // LDS-DMA of piece q (k chunk q >> 2, 128-row block q & 3) of a layer's pack [row block][k chunk][24 KB image] into
+    // ring slot q & 3: scalar base + one 32-bit lane offset (anything lane-dependent that is hoisted out of the stage
+    // loop ends up in scratch).  6 wave-instructions of 1 KB per wave.
+    auto dma = [&](const unsigned char *wx, int q, int lane16) {
+        const unsigned char *src = wx + (long)((q & 3) * 16 + (q >> 2)) * XC_PIECE + (wave * 6) * 1024;
 #pragma unroll
-        for (int s = 0; s < 12; ++s)
+        for (int s = 0; s < 6; ++s)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + s * 1024 + lane16),
-                                             (__attribute__((address_space(3))) void *)(wbuf + buf * XC_PIECE + (wave * 12 + s) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(wbuf + (q & 3) * XC_PIECE + (wave * 6 + s) * 1024), 16, 0, 0);
     };
-
     const double t0 = a.reverse ? (double)a.t_end : 0.0, t1 = a.reverse ? 0.0 : (double)a.t_end;
     const double h = (t1 - t0) / (double)a.steps;
     const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
 
-    dma(a.w1x, 0, 0, lane0 * 16);   // first piece of layer 1; every layer pass leaves the NEXT pass's first piece in flight
+    // the first three pieces of layer 1; every layer pass leaves the NEXT pass's first three pieces in flight
+    dma(a.w1x, 0, lane0 * 16);
+    dma(a.w1x, 1, lane0 * 16);
+    dma(a.w1x, 2, lane0 * 16);
 
-    bf16x8 bfr[16][3];   // B fragments of the layer input: [k chunk][plane]
+    // B fragments of the layer input, [k chunk][plane] (192 registers).  The architectural VGPR file is 256 registers and
+    // the accumulators already fill half of the AGPR file, so the fragments of the first XC_PARK chunks are PARKED in
+    // AGPRs (v_accvgpr_write / _read, 12 moves per chunk and layer) and only the rest stays in VGPRs: with all 192 in
+    // VGPRs the A-fragment reads had two registers to rotate through and every LDS latency was exposed.
+    unsigned park[XC_PARK * 12];
+    bf16x8 bfr[16 - XC_PARK][3];
     f32x4 acc[32];
+    auto set_b = [&](int kc, int pl, u32x4 v) {
+        if (kc < XC_PARK) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm("v_accvgpr_write_b32 %0, %1" : "=a"(park[(kc * 3 + pl) * 4 + c]) : "v"(v[c]));
+        } else {
+            bfr[kc < XC_PARK ? 0 : kc - XC_PARK][pl] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    auto get_b = [&](int kc, int pl) -> bf16x8 {
+        if (kc < XC_PARK) {
+            u32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(park[(kc * 3 + pl) * 4 + c]));
+            return __builtin_bit_cast(bf16x8, v);
+        }
+        return bfr[kc < XC_PARK ? 0 : kc - XC_PARK][pl];
+    };
 
     // 8 f32 activations (the 8 k-slots of this lane in chunk kc) -> three bf16 planes
     auto to_bfr = [&](int kc, const float (&hv)[8]) {
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
             u32x4 v;
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = xc_pack(hs[pl][2 * q], hs[pl][2 * q + 1]);
-            bfr[kc][pl] = __builtin_bit_cast(bf16x8, v);
+            set_b(kc, pl, v);
         }
     };
 
@@ -171,35 +200,75 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
                 const unsigned char *wnext = L == 0 ? a.w2x : a.w1x;
 #pragma unroll
                 for (int mi = 0; mi < 32; ++mi) acc[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bf16x8 bk[2][3];   // the three planes of the current / previous k chunk (by chunk parity)
+                // 24 MFMAs of four row tiles: smallest terms first; term-major, i.e. four independent accumulators between
+                // dependent MFMAs
+                auto mma_head = [&](const bf16x8 (&af)[4][3], const bf16x8 (&b)[3], int m0) __attribute__((always_inline)) {
 #pragma unroll
-                for (int p = 0; p < XC_NPIECE; ++p) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();   // piece p has landed for every wave; everybody is done reading the other buffer
-                    if (p + 1 < XC_NPIECE) dma(wx, p + 1, (p + 1) & 1, lane16);
-                    else dma(wnext, 0, 0, lane16);
-                    const int kc = p >> 1, mt = p & 1;
-                    const unsigned char *A = wbuf + (p & 1) * XC_PIECE + aoff;
+                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][2], b[0], acc[m0 + u], 0, 0, 0);
+                };
+                auto mma_tail = [&](const bf16x8 (&af)[4][3], const bf16x8 (&b)[3], int m0) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int m4 = 0; m4 < 4; ++m4) {
-                        bf16x8 af[4][3];
+                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], b[1], acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b[2], acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], b[0], acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b[1], acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b[0], acc[m0 + u], 0, 0, 0);
+                };
+                // Skewed by half a piece so that no LDS latency is exposed: after the barrier of piece q its first four row
+                // tiles are requested (set 0), then the 24 MFMAs of the SECOND half of piece q-1 run from set 1 (already in
+                // registers), then the second half of piece q is requested into set 1, then the 24 MFMAs of its first half
+                // run.  sched_barrier pins the phases (hipcc otherwise sinks every read to just before its use).
+                if (!(a.diag & 2)) {
+                    bf16x8 af0[4][3], af1[4][3];
+#pragma unroll
+                    for (int q = 0; q < XC_NPIECE; ++q) {
+                        // pieces q, q+1, q+2 are in flight (6 DMA instructions each, retired in order): piece q has landed once
+                        // at most 12 are outstanding.  Counted wait + raw barrier: __syncthreads() would drain all of them.
+                        if (!(a.diag & 4)) {
+                            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // + this wave's LDS reads of the slot about to be refilled
+                            __builtin_amdgcn_s_barrier();   // piece q is there for every wave; everybody is done with slot (q + 3) & 3
+                        }
+                        asm volatile("" ::: "memory");
+                        // hipcc waits with lgkmcnt(0) -- never a counted wait -- before the first use of a fragment set (and does
+                        // not see the wait in the asm above).  So the first four MFMAs of each set are placed where that wait
+                        // is free: set 1 (second half of piece q-1) BEFORE piece q's first reads are requested ...
+                        if (q > 0) mma_head(af1, bk[((q - 1) >> 2) & 1], 8 * ((q - 1) & 3) + 4);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(a.diag & 1)) {
+                            if (q + 3 < XC_NPIECE) dma(wx, q + 3, lane16);
+                            else dma(wnext, q + 3 - XC_NPIECE, lane16);
+                        }
+                        const int kc = q >> 2, rb = q & 3;
+                        const unsigned char *A = wbuf + (q & 3) * XC_PIECE + aoff;
+                        if (rb == 0) {
+                            bk[kc & 1][0] = get_b(kc, 0);
+                            bk[kc & 1][1] = get_b(kc, 1);
+                            bk[kc & 1][2] = get_b(kc, 2);
+                        }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) af[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (m4 * 4 + u) * 1024);
-                        // smallest terms first; term-major: four independent accumulators between dependent MFMAs
+                            for (int pl = 0; pl < 3; ++pl) af0[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + u * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q > 0) mma_tail(af1, bk[((q - 1) >> 2) & 1], 8 * ((q - 1) & 3) + 4);
+                        // ... and set 0 after the 20 remaining MFMAs of set 1, before set 1 is requested again
+                        mma_head(af0, bk[kc & 1], 8 * rb);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][2], bfr[kc][0], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+                        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], bfr[kc][1], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], bfr[kc][2], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], bfr[kc][0], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], bfr[kc][1], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[16 * mt + 4 * m4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], bfr[kc][0], acc[16 * mt + 4 * m4 + u], 0, 0, 0);
+                            for (int pl = 0; pl < 3; ++pl) af1[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (4 + u) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_tail(af0, bk[kc & 1], 8 * rb);
+                        __builtin_amdgcn_sched_barrier(0);   // keep these MFMAs (they cover the reads just issued) ahead of the wait
                     }
+                    mma_head(af1, bk[((XC_NPIECE - 1) >> 2) & 1], 8 * ((XC_NPIECE - 1) & 3) + 4);
+                    mma_tail(af1, bk[((XC_NPIECE - 1) >> 2) & 1], 8 * ((XC_NPIECE - 1) & 3) + 4);
                 }
                 int le = lane;   // opaque again: the epilogue's table / w3 addresses must not be hoisted above the product loop
                 asm volatile("" : "+v"(le));
@@ -265,15 +334,15 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     }
 }
 
-// (512, ldw) f32 hidden-layer weight -> [row half][k chunk][plane][row 0..255][piece'][8 bf16], k listed in the
+// (512, ldw) f32 hidden-layer weight -> [row block 4][k chunk 16][plane 3][row 0..127][piece'][8 bf16], k listed in the
 // D-fragment order of the producing layer (see the header): piece g, element q <-> k = 32 kc + (q < 4 ? 4g + q : 16 + 4g + q - 4)
 __global__ void pack_weight_cnf_x6_kernel(const float *__restrict__ w, int ldw, unsigned char *__restrict__ out)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (tile * 16 + chunk) * 1024 + row * 4 + piece
-    if (i >= 2L * 16 * 1024) return;
-    const int piece = (int)(i & 3), row = (int)((i >> 2) & 255);
-    const int ck = (int)(i >> 10), kc = ck & 15, mt = ck >> 4;
-    const int co = mt * 256 + row;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (row block * 16 + chunk) * 512 + row * 4 + piece
+    if (i >= 4 * 16 * 512) return;
+    const int piece = i & 3, row = (i >> 2) & 127;
+    const int ck = i >> 9, kc = ck & 15, rb = ck >> 4;
+    const int co = rb * 128 + row;
     float hs[3][8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -290,13 +359,13 @@ __global__ void pack_weight_cnf_x6_kernel(const float *__restrict__ w, int ldw, 
     }
 }
 
-extern "C" long caspr_cnf_x6_packed_bytes(void) { return 2L * 16 * XC_PIECE; }
+extern "C" long caspr_cnf_x6_packed_bytes(void) { return 4L * 16 * XC_PIECE; }
 
 extern "C" int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream)
 {
     CASPR_REQUIRE(w && packed && ldw >= XC_H, "pack_weight_cnf_x6: bad arguments");
     CASPR_REQUIRE(((uintptr_t)packed % 16) == 0, "pack_weight_cnf_x6: packed must be 16-byte aligned");
-    pack_weight_cnf_x6_kernel<<<2 * 16 * 1024 / 256, 256, 0, (hipStream_t)stream>>>(w, ldw, (unsigned char *)packed);
+    pack_weight_cnf_x6_kernel<<<4 * 16 * 512 / 256, 256, 0, (hipStream_t)stream>>>(w, ldw, (unsigned char *)packed);
     CASPR_CHECK_LAUNCH("pack_weight_cnf_x6");
     return CASPR_OK;
 }
@@ -314,6 +383,7 @@ extern "C" int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int l
     CnfX6Args a;
     a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.b1 = b1; a.b2 = b2; a.w3 = w3; a.b3 = b3;
     a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.w1x = (const unsigned char *)w1x; a.w2x = (const unsigned char *)w2x;
+    a.diag = getenv("CASPR_X6_DIAG") ? atoi(getenv("CASPR_X6_DIAG")) : 0;
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
     hipError_t err = hipFuncSetAttribute((const void *)cnf_rk4_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
     if (err != hipSuccess) {
