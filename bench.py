@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3            # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_MFMA_BF16_TFLOPS = 2500.0          # same guide: dense bf16 MFMA peak (only used by the opt-in bf16x6 run)
 CNF_FLOP_PER_POINT_EVAL = 2 * (3 * 512 + 512 * 512 + 512 * 512 + 512 * 3)   # 1,054,720 (no divergence)
 
 
@@ -126,6 +127,13 @@ def main():
                     "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launch_ms": round(cnf_ms, 3), "launches_timed": len(ev), "flop_per_launch": flop}
+        if ops.CNF_BF16X6:
+            # opt-in run (CASPR_CNF_BF16X6=1): the same algorithmic f32 FLOPs, carried as six bf16 MFMA products each --
+            # priced against the dense bf16 MFMA peak / 6; no PMC pass exists for this kernel
+            peak = PEAK_MFMA_BF16_TFLOPS / 6.0
+            roofline.update({"kernel": "cnf_rk4_x6_kernel (opt-in bf16x6: exact three-way bf16 split, six products per f32 product)",
+                             "peak": round(peak, 1), "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": None,
+                             "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 6 products; 157.3 is the f32 MFMA peak this run is not bound by"})
         breakdown = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in ops.TIMERS.items()}
 
         cpu = None
@@ -165,11 +173,15 @@ def main():
         print(json.dumps({
             "metric": "sequences/sec (CaSPR.reconstruct, rigid-cars T=10 N=2048)", "value": round(value, 3), "unit": "sequences/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not (ops.CNF_BF16X6 or ops.CONV_BF16X6) else "f32 (opt-in bf16x6: f32 operands split exactly into 3 bf16, 6 bf16-MFMA products, f32 accumulation)",
+            "data": "synthetic",
             "config": {"workload": "cars.cfg rigid recon (BASELINE.json configs[1]): reconstruct(), B=%d sequences/GPU, T=%d, N=%d, "
                                    "num_points=%d, all steps observed; seeded random-init weights" % (B, T, N, N),
                        "global_batch": world * B, "seq_len": T, "num_pts": N, "cnf_rk4_steps": args.cnf_steps,
-                       "latent_rk4_steps": args.latent_steps, "cnf_divergence": "skipped (sampling)", "parallelism": "seq-shard x%d" % world},
+                       "latent_rk4_steps": args.latent_steps, "cnf_divergence": "skipped (sampling)", "parallelism": "seq-shard x%d" % world,
+                       "matrix_products": "f32 MFMA" if not (ops.CNF_BF16X6 or ops.CONV_BF16X6) else
+                       "bf16x6 opt-in (CASPR_CONV_BF16X6=%d, CASPR_CNF_BF16X6=%d)" % (int(ops.CONV_BF16X6), int(ops.CNF_BF16X6))},
             "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_step": breakdown,
         }))
     if world > 1:
