@@ -16,6 +16,11 @@
 //    s_barrier per piece of 48 MFMAs = 768 matrix-pipe cycles per wave);
 //  * input layer 3 -> 512, output layer 512 -> 3, the RK4 state and its update are wave-local (state component d of
 //    column j lives in lane 16 d + j).
+//
+// Measured at cfg-2 (160 frames x 2048 points, 8 RK4 steps): 61.4 ms per launch against 80.4 ms for the f32 kernel.
+// With the CASPR_X6_DIAG timing switches: VALU stages (gates, input layer, epilogues) 11.0 ms, exposed -- one wave per
+// SIMD has nothing to overlap them with; product loop 34 ms (MFMA issue floor 26 ms); 128 piece barriers per stage
+// 6.7 ms; weight DMA 9.5 ms (the 3 MB of split weights go L2 -> LDS once per 64 points and stage: ~8 TB/s).
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -85,10 +90,10 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     // LDS-DMA of piece q (k chunk q >> 2, 128-row block q & 3) of a layer's pack [row block][k chunk][24 KB image] into
     // ring slot q & 3: scalar base + one 32-bit lane offset (anything lane-dependent that is hoisted out of the stage
     // loop ends up in scratch).  6 wave-instructions of 1 KB per wave.
-    auto dma = [&](const unsigned char *wx, int q, int lane16) {
+    auto dma = [&](const unsigned char *wx, int q, int lane16, int s0 = 0, int s1 = 6) {
         const unsigned char *src = wx + (long)((q & 3) * 16 + (q >> 2)) * XC_PIECE + (wave * 6) * 1024;
 #pragma unroll
-        for (int s = 0; s < 6; ++s)
+        for (int s = s0; s < s1; ++s)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + s * 1024 + lane16),
                                              (__attribute__((address_space(3))) void *)(wbuf + (q & 3) * XC_PIECE + (wave * 6 + s) * 1024), 16, 0, 0);
     };
@@ -239,10 +244,11 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
                         // is free: set 1 (second half of piece q-1) BEFORE piece q's first reads are requested ...
                         if (q > 0) mma_head(af1, bk[((q - 1) >> 2) & 1], 8 * ((q - 1) & 3) + 4);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!(a.diag & 1)) {
-                            if (q + 3 < XC_NPIECE) dma(wx, q + 3, lane16);
-                            else dma(wnext, q + 3 - XC_NPIECE, lane16);
-                        }
+                        // the six DMA instructions of piece q+3 are spread over the piece (two here, two in each MFMA run;
+                        // measured the same as issuing all six here: their cost is not an issue-slot cost)
+                        const unsigned char *wq = q + 3 < XC_NPIECE ? wx : wnext;
+                        const int qn = q + 3 < XC_NPIECE ? q + 3 : q + 3 - XC_NPIECE;
+                        if (!(a.diag & 1)) dma(wq, qn, lane16, 0, 2);
                         const int kc = q >> 2, rb = q & 3;
                         const unsigned char *A = wbuf + (q & 3) * XC_PIECE + aoff;
                         if (rb == 0) {
@@ -255,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 #pragma unroll
                             for (int pl = 0; pl < 3; ++pl) af0[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + u * 1024);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (!(a.diag & 1)) dma(wq, qn, lane16, 2, 4);
                         if (q > 0) mma_tail(af1, bk[((q - 1) >> 2) & 1], 8 * ((q - 1) & 3) + 4);
                         // ... and set 0 after the 20 remaining MFMAs of set 1, before set 1 is requested again
                         mma_head(af0, bk[kc & 1], 8 * rb);
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 #pragma unroll
                             for (int pl = 0; pl < 3; ++pl) af1[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (4 + u) * 1024);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (!(a.diag & 1)) dma(wq, qn, lane16, 4, 6);
                         mma_tail(af0, bk[kc & 1], 8 * rb);
                         __builtin_amdgcn_sched_barrier(0);   // keep these MFMAs (they cover the reads just issued) ahead of the wait
                     }
