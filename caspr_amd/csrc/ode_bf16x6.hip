@@ -11,9 +11,10 @@
 //    once the weight pack lists its k in the same order (slot s of lane group g <-> unit 32kc + 4g + s for s < 4,
 //    32kc + 16 + 4g + s - 4 above).  The epilogue (gate * acc + bias, softplus, split) writes the next layer's 16 x 3
 //    B fragments straight into registers (192 VGPRs);
-//  * LDS is the weight stage shared by the four waves: 24 KB pieces (128 rows x 32 k x 3 planes, pre-swizzled image)
-//    arrive by LDS-DMA into a ring of four, three in flight while one is used (counted s_waitcnt vmcnt + raw
-//    s_barrier per piece of 48 MFMAs = 768 matrix-pipe cycles per wave);
+//  * LDS is the weight stage shared by the four waves: 48 KB pieces (256 rows x 32 k x 3 planes, pre-swizzled image)
+//    arrive by LDS-DMA, double-buffered, one raw s_barrier per piece of 96 MFMAs = 1536 matrix-pipe cycles per wave
+//    (a ring of four 24 KB pieces with counted vmcnt waits, three in flight, measured the same DMA cost and twice the
+//    barrier cost: 61.4 ms);
 //  * input layer 3 -> 512, output layer 512 -> 3, the RK4 state and its update are wave-local (state component d of
 //    column j lives in lane 16 d + j).
 //
@@ -28,11 +29,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define XC_H 512
 #define XC_COLS 64
-#define XC_PA (128 * 64)          // one plane of a piece
-#define XC_PIECE (3 * XC_PA)      // 24 KB: 128 rows x 32 k x 3 planes
-#define XC_NPIECE 64              // per layer: 16 k chunks x 4 row blocks
+#define XC_PA (256 * 64)          // one plane of a piece
+#define XC_PIECE (3 * XC_PA)      // 48 KB: 256 rows x 32 k x 3 planes
+#define XC_NPIECE 32              // per layer: 16 k chunks x 2 row halves
 #define XC_PARK 10                // k chunks whose B fragments are parked in AGPRs
-#define XC_RING 4                 // LDS ring of pieces: three are in flight while one is being used
+#define XC_RING 2                 // LDS double buffer of pieces
 #define XC_LDS (XC_RING * XC_PIECE + (6 * XC_H + 3 * XC_H + 8) * 4)
 
 __device__ __forceinline__ void xc_split(float x, float &h1, float &h2, float &h3)
@@ -51,7 +52,8 @@ struct CnfX6Args {
     float *y_out;
     int ldh, n, steps, reverse;
     float t_end;
-    int diag;   // timing experiments only (CASPR_X6_DIAG): 1 = no weight DMA, 2 = no product loop, 4 = no piece barriers
+    int diag;   // timing experiment only (CASPR_X6_DIAG=2): no product loop.  (Switches for 'no weight DMA' and 'no piece
+                // barriers' gave the breakdown in the header; as runtime branches they split the scheduling regions.)
 };
 
 __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
@@ -87,24 +89,22 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
         y = v;
     }
 
-    // LDS-DMA of piece q (k chunk q >> 2, 128-row block q & 3) of a layer's pack [row block][k chunk][24 KB image] into
-    // ring slot q & 3: scalar base + one 32-bit lane offset (anything lane-dependent that is hoisted out of the stage
-    // loop ends up in scratch).  6 wave-instructions of 1 KB per wave.
-    auto dma = [&](const unsigned char *wx, int q, int lane16, int s0 = 0, int s1 = 6) {
-        const unsigned char *src = wx + (long)((q & 3) * 16 + (q >> 2)) * XC_PIECE + (wave * 6) * 1024;
+    // LDS-DMA of piece p (k chunk p >> 1, row half p & 1) of a layer's pack [row half][k chunk][48 KB image] into
+    // buffer p & 1: scalar base + one 32-bit lane offset (anything lane-dependent that is hoisted out of the stage
+    // loop ends up in scratch).  12 wave-instructions of 1 KB per wave, issued in three parts.
+    auto dma = [&](const unsigned char *wx, int p, int lane16, int s0 = 0, int s1 = 12) {
+        const unsigned char *src = wx + (long)((p & 1) * 16 + (p >> 1)) * XC_PIECE + (wave * 12) * 1024;
 #pragma unroll
         for (int s = s0; s < s1; ++s)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + s * 1024 + lane16),
-                                             (__attribute__((address_space(3))) void *)(wbuf + (q & 3) * XC_PIECE + (wave * 6 + s) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(wbuf + (p & 1) * XC_PIECE + (wave * 12 + s) * 1024), 16, 0, 0);
     };
     const double t0 = a.reverse ? (double)a.t_end : 0.0, t1 = a.reverse ? 0.0 : (double)a.t_end;
     const double h = (t1 - t0) / (double)a.steps;
     const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
 
-    // the first three pieces of layer 1; every layer pass leaves the NEXT pass's first three pieces in flight
+    // the first piece of layer 1; every layer pass leaves the NEXT pass's first piece in flight
     dma(a.w1x, 0, lane0 * 16);
-    dma(a.w1x, 1, lane0 * 16);
-    dma(a.w1x, 2, lane0 * 16);
 
     // B fragments of the layer input, [k chunk][plane] (192 registers).  The architectural VGPR file is 256 registers and
     // the accumulators already fill half of the AGPR file, so the fragments of the first XC_PARK chunks are PARKED in
@@ -224,59 +224,69 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b[0], acc[m0 + u], 0, 0, 0);
                 };
-                // Skewed by half a piece so that no LDS latency is exposed: after the barrier of piece q its first four row
-                // tiles are requested (set 0), then the 24 MFMAs of the SECOND half of piece q-1 run from set 1 (already in
-                // registers), then the second half of piece q is requested into set 1, then the 24 MFMAs of its first half
-                // run.  sched_barrier pins the phases (hipcc otherwise sinks every read to just before its use).
+                // A piece is four groups of four row tiles (24 MFMAs each), read into two fragment sets alternately and
+                // skewed by one group: a scheduling region = the 12 reads of group G+1, interleaved two per MFMA with the
+                // first MFMAs of the 20 that remain of group G ("tail"), and then the first four MFMAs of group G+1
+                // ("head").  hipcc waits with lgkmcnt(0) -- never a counted wait -- before the first use of a set: at the
+                // head that wait is free (the reads were requested >= 14 MFMAs earlier and nothing younger is in flight).
+                // sched_group_barrier builds the pattern, sched_barrier(0) closes the region (hipcc otherwise sinks every
+                // read to just before its use).  The last group of piece p-1 finishes after the barrier of piece p.
+#define XC_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define XC_INTERLEAVE                                                                                                          \
+    XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2)       \
+    XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x008, 18)                       \
+    __builtin_amdgcn_sched_barrier(0);
                 if (!(a.diag & 2)) {
                     bf16x8 af0[4][3], af1[4][3];
+                    auto rd = [&](bf16x8 (&af)[4][3], const unsigned char *A, int G) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int q = 0; q < XC_NPIECE; ++q) {
-                        // pieces q, q+1, q+2 are in flight (6 DMA instructions each, retired in order): piece q has landed once
-                        // at most 12 are outstanding.  Counted wait + raw barrier: __syncthreads() would drain all of them.
-                        if (!(a.diag & 4)) {
-                            asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // + this wave's LDS reads of the slot about to be refilled
-                            __builtin_amdgcn_s_barrier();   // piece q is there for every wave; everybody is done with slot (q + 3) & 3
-                        }
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) af[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (4 * G + u) * 1024);
+                    };
+#pragma unroll
+                    for (int p = 0; p < XC_NPIECE; ++p) {
+                        // piece p (its DMA was issued one piece ago) has landed once nothing is outstanding; lgkmcnt: this wave's
+                        // reads of the buffer about to be refilled.  Raw barrier: no compiler-added waits.
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();   // piece p is there for every wave; everybody is done with buffer (p + 1) & 1
                         asm volatile("" ::: "memory");
-                        // hipcc waits with lgkmcnt(0) -- never a counted wait -- before the first use of a fragment set (and does
-                        // not see the wait in the asm above).  So the first four MFMAs of each set are placed where that wait
-                        // is free: set 1 (second half of piece q-1) BEFORE piece q's first reads are requested ...
-                        if (q > 0) mma_head(af1, bk[((q - 1) >> 2) & 1], 8 * ((q - 1) & 3) + 4);
-                        __builtin_amdgcn_sched_barrier(0);
-                        // the six DMA instructions of piece q+3 are spread over the piece (two here, two in each MFMA run;
-                        // measured the same as issuing all six here: their cost is not an issue-slot cost)
-                        const unsigned char *wq = q + 3 < XC_NPIECE ? wx : wnext;
-                        const int qn = q + 3 < XC_NPIECE ? q + 3 : q + 3 - XC_NPIECE;
-                        if (!(a.diag & 1)) dma(wq, qn, lane16, 0, 2);
-                        const int kc = q >> 2, rb = q & 3;
-                        const unsigned char *A = wbuf + (q & 3) * XC_PIECE + aoff;
-                        if (rb == 0) {
+                        const int kc = p >> 1, mt = p & 1;
+                        const int kcp = (p - 1) >> 1, mtp = (p - 1) & 1;
+                        const unsigned char *wq = p + 1 < XC_NPIECE ? wx : wnext;
+                        const int pn = p + 1 < XC_NPIECE ? p + 1 : 0;
+                        const unsigned char *A = wbuf + (p & 1) * XC_PIECE + aoff;
+                        if (mt == 0) {
                             bk[kc & 1][0] = get_b(kc, 0);
                             bk[kc & 1][1] = get_b(kc, 1);
                             bk[kc & 1][2] = get_b(kc, 2);
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) af0[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + u * 1024);
+                        // region 0: read group 0 | the rest of the previous piece's group 3 | first MFMAs of group 0
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!(a.diag & 1)) dma(wq, qn, lane16, 2, 4);
-                        if (q > 0) mma_tail(af1, bk[((q - 1) >> 2) & 1], 8 * ((q - 1) & 3) + 4);
-                        // ... and set 0 after the 20 remaining MFMAs of set 1, before set 1 is requested again
-                        mma_head(af0, bk[kc & 1], 8 * rb);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) af1[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (4 + u) * 1024);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (!(a.diag & 1)) dma(wq, qn, lane16, 4, 6);
-                        mma_tail(af0, bk[kc & 1], 8 * rb);
-                        __builtin_amdgcn_sched_barrier(0);   // keep these MFMAs (they cover the reads just issued) ahead of the wait
+                        rd(af0, A, 0);
+                        dma(wq, pn, lane16, 0, 4);
+                        if (p > 0) mma_tail(af1, bk[kcp & 1], 16 * mtp + 12);
+                        mma_head(af0, bk[kc & 1], 16 * mt);
+                        XC_INTERLEAVE
+                        // region 1
+                        rd(af1, A, 1);
+                        dma(wq, pn, lane16, 4, 8);
+                        mma_tail(af0, bk[kc & 1], 16 * mt);
+                        mma_head(af1, bk[kc & 1], 16 * mt + 4);
+                        XC_INTERLEAVE
+                        // region 2
+                        rd(af0, A, 2);
+                        dma(wq, pn, lane16, 8, 12);
+                        mma_tail(af1, bk[kc & 1], 16 * mt + 4);
+                        mma_head(af0, bk[kc & 1], 16 * mt + 8);
+                        XC_INTERLEAVE
+                        // region 3
+                        rd(af1, A, 3);
+                        mma_tail(af0, bk[kc & 1], 16 * mt + 8);
+                        mma_head(af1, bk[kc & 1], 16 * mt + 12);
+                        XC_INTERLEAVE
                     }
-                    mma_head(af1, bk[((XC_NPIECE - 1) >> 2) & 1], 8 * ((XC_NPIECE - 1) & 3) + 4);
-                    mma_tail(af1, bk[((XC_NPIECE - 1) >> 2) & 1], 8 * ((XC_NPIECE - 1) & 3) + 4);
+                    mma_tail(af1, bk[((XC_NPIECE - 1) >> 1) & 1], 16 * ((XC_NPIECE - 1) & 1) + 12);
                 }
                 int le = lane;   // opaque again: the epilogue's table / w3 addresses must not be hoisted above the product loop
                 asm volatile("" : "+v"(le));
@@ -342,15 +352,15 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     }
 }
 
-// (512, ldw) f32 hidden-layer weight -> [row block 4][k chunk 16][plane 3][row 0..127][piece'][8 bf16], k listed in the
+// (512, ldw) f32 hidden-layer weight -> [row half 2][k chunk 16][plane 3][row 0..255][piece'][8 bf16], k listed in the
 // D-fragment order of the producing layer (see the header): piece g, element q <-> k = 32 kc + (q < 4 ? 4g + q : 16 + 4g + q - 4)
 __global__ void pack_weight_cnf_x6_kernel(const float *__restrict__ w, int ldw, unsigned char *__restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (row block * 16 + chunk) * 512 + row * 4 + piece
-    if (i >= 4 * 16 * 512) return;
-    const int piece = i & 3, row = (i >> 2) & 127;
-    const int ck = i >> 9, kc = ck & 15, rb = ck >> 4;
-    const int co = rb * 128 + row;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (row half * 16 + chunk) * 1024 + row * 4 + piece
+    if (i >= 2 * 16 * 1024) return;
+    const int piece = i & 3, row = (i >> 2) & 255;
+    const int ck = i >> 10, kc = ck & 15, mt = ck >> 4;
+    const int co = mt * 256 + row;
     float hs[3][8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -367,13 +377,13 @@ __global__ void pack_weight_cnf_x6_kernel(const float *__restrict__ w, int ldw, 
     }
 }
 
-extern "C" long caspr_cnf_x6_packed_bytes(void) { return 4L * 16 * XC_PIECE; }
+extern "C" long caspr_cnf_x6_packed_bytes(void) { return 2L * 16 * XC_PIECE; }
 
 extern "C" int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream)
 {
     CASPR_REQUIRE(w && packed && ldw >= XC_H, "pack_weight_cnf_x6: bad arguments");
     CASPR_REQUIRE(((uintptr_t)packed % 16) == 0, "pack_weight_cnf_x6: packed must be 16-byte aligned");
-    pack_weight_cnf_x6_kernel<<<4 * 16 * 512 / 256, 256, 0, (hipStream_t)stream>>>(w, ldw, (unsigned char *)packed);
+    pack_weight_cnf_x6_kernel<<<2 * 16 * 1024 / 256, 256, 0, (hipStream_t)stream>>>(w, ldw, (unsigned char *)packed);
     CASPR_CHECK_LAUNCH("pack_weight_cnf_x6");
     return CASPR_OK;
 }
