@@ -38,6 +38,21 @@ __device__ __forceinline__ void x6_split(float x, float &h1, float &h2, float &h
     const float r2 = r1 - h2;
     h3 = __uint_as_float(__float_as_uint(r2) & 0xffff0000u);
 }
+// the same exact split for a pair with the hardware round-to-nearest conversion (v_cvt_pk_bf16_f32): the three packed words
+// are the pair's entries of the three planes (remainders after rounding 24 -> 8 bits have <= 15, then <= 7 significant bits)
+typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float x6_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void x6_split_pair(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    x6_f32x2 v = {x0, x1};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
+    x6_f32x2 h = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+    v = v - h;
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
+    h = (x6_f32x2){__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
+    v = v - h;
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
+}
 __device__ __forceinline__ unsigned x6_pack(float lo, float hi) { return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u); }
 
 // W (Cout, ldw) f32, columns col0 .. col0+Cin-1 -> [channel tile][k chunk][plane][row 0..255][piece'][8 bf16]; rows past
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     auto lstore = [&](int kc) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
-            float h[3][8];
+            float xv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float v = xreg[2 * pc + (q >> 2)][q & 3];
@@ -130,15 +145,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
                     v = v * sc[k] + sh[k];
                     if (in_relu && k + 16 * xh >= relu_from) v = v > 0.f ? v : 0.f;
                 }
-                x6_split(v, h[0][q], h[1][q], h[2][q]);
+                xv[q] = v;
+            }
+            u32x4 pv[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned p1, p2, p3;
+                x6_split_pair(xv[2 * q], xv[2 * q + 1], p1, p2, p3);
+                pv[0][q] = p1;
+                pv[1][q] = p2;
+                pv[2][q] = p3;
             }
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                u32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = x6_pack(h[pl][2 * q], h[pl][2 * q + 1]);
-                *(u32x4 *)(sB + pl * X6_PB + x6_off(xr, 2 * xh + pc)) = v;
-            }
+            for (int pl = 0; pl < 3; ++pl) *(u32x4 *)(sB + pl * X6_PB + x6_off(xr, 2 * xh + pc)) = pv[pl];
         }
     };
 
