@@ -34,7 +34,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define XC_NPIECE 32              // per layer: 16 k chunks x 2 row halves
 #define XC_PARK 10                // k chunks whose B fragments are parked in AGPRs
 #define XC_RING 2                 // LDS double buffer of pieces
-#define XC_LDS (XC_RING * XC_PIECE + (6 * XC_H + 3 * XC_H + 8) * 4)
+#define XC_LDS (XC_RING * XC_PIECE + (6 * XC_H + 3 * XC_H + 3 * XC_H + 8) * 4)
 
 __device__ __forceinline__ void xc_split(float x, float &h1, float &h2, float &h3)
 {
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     float *s_gate = (float *)(lds + XC_RING * XC_PIECE);              // [3][512] sigmoid gates of layers 0,1,2
     float *s_hb = s_gate + 3 * XC_H;                            // [3][512] layer bias * gate + hyper bias
     float *s_w0 = s_hb + 3 * XC_H;                              // [512][3]
-    float *s_g3 = s_w0 + 3 * XC_H;                              // [8]: gate3[3], hb3[3]
+    float *s_w3 = s_w0 + 3 * XC_H;                              // [3][512] output layer
+    float *s_g3 = s_w3 + 3 * XC_H;                              // [8]: gate3[3], hb3[3]
 
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     constexpr int GOFF = 0, BOFF = 3 * XC_H + 3;
     const int sd = g0 < 3 ? g0 : 0;   // state component of this lane (lanes g == 3 carry a copy of component 0, never stored)
 
-    for (int i = tid; i < 3 * XC_H; i += 256) s_w0[i] = a.w0[i];
+    for (int i = tid; i < 3 * XC_H; i += 256) {
+        s_w0[i] = a.w0[i];
+        s_w3[i] = a.w3[i];
+    }
 
     float y, kacc = 0.f, kprev = 0.f;
     {
@@ -195,24 +199,42 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
             const float ystage = (stage == 0) ? y : y + aw * kprev;
             const float y0 = __shfl(ystage, j), y1 = __shfl(ystage, 16 + j), y2 = __shfl(ystage, 32 + j);
 
-            // ---- input layer 3 -> 512 (diffeq_layers.py:83-90 + softplus) straight into B fragments
+            // ---- input layer 3 -> 512 (diffeq_layers.py:83-90 + softplus) straight into B fragments.  The table values of
+            // chunk kc+1 are requested before chunk kc is computed (two static register sets); sched_barrier keeps hipcc
+            // from hoisting ALL sixteen chunks' loads (spills) and from sinking them to their use (exposed LDS latency).
+            {
+                f32x4 tg[2][2], tb[2][2], tw[2][2][3];
+                auto ld_in = [&](int set, int kc) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kc = 0; kc < 16; ++kc) {
-                float hv[8];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int c = 32 * kc + 16 * half + 4 * g;
-                    const f32x4 gt = ld4(s_gate + c), hb = ld4(s_hb + c);
-                    const f32x4 wa = ld4(s_w0 + 3 * c), wb = ld4(s_w0 + 3 * c + 4), wc = ld4(s_w0 + 3 * c + 8);
-                    const float w[12] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0], wc[1], wc[2], wc[3]};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pre = (w[3 * r] * y0 + w[3 * r + 1] * y1 + w[3 * r + 2] * y2) * gt[r] + hb[r];
-                        hv[4 * half + r] = softplus_fast(pre);
+                    for (int half = 0; half < 2; ++half) {
+                        const int c = 32 * kc + 16 * half + 4 * g;
+                        tg[set][half] = ld4(s_gate + c);
+                        tb[set][half] = ld4(s_hb + c);
+                        tw[set][half][0] = ld4(s_w0 + 3 * c);
+                        tw[set][half][1] = ld4(s_w0 + 3 * c + 4);
+                        tw[set][half][2] = ld4(s_w0 + 3 * c + 8);
                     }
+                };
+                ld_in(0, 0);
+#pragma unroll
+                for (int kc = 0; kc < 16; ++kc) {
+                    if (kc + 1 < 16) ld_in((kc + 1) & 1, kc + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    float hv[8];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const f32x4 gt = tg[kc & 1][half], hb = tb[kc & 1][half];
+                        const f32x4 wa = tw[kc & 1][half][0], wb = tw[kc & 1][half][1], wc = tw[kc & 1][half][2];
+                        const float w[12] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0], wc[1], wc[2], wc[3]};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pre = (w[3 * r] * y0 + w[3 * r + 1] * y1 + w[3 * r + 2] * y2) * gt[r] + hb[r];
+                            hv[4 * half + r] = softplus_fast(pre);
+                        }
+                    }
+                    to_bfr(kc, hv);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                to_bfr(kc, hv);
-                __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every chunk's table loads (spills)
             }
 
             float part[3] = {0.f, 0.f, 0.f};
@@ -309,14 +331,25 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
                 asm volatile("" : "+v"(le));
                 const int ge = le >> 4;
                 if (L == 0) {
-                    // ---- epilogue of hidden layer 1: the accumulators become layer 2's B fragments
-#pragma unroll
-                    for (int kc = 0; kc < 16; ++kc) {
-                        float hv[8];
+                    // ---- epilogue of hidden layer 1: the accumulators become layer 2's B fragments (tables one chunk ahead)
+                    f32x4 tg[2][2], tb[2][2];
+                    auto ld_e1 = [&](int set, int kc) __attribute__((always_inline)) {
 #pragma unroll
                         for (int half = 0; half < 2; ++half) {
                             const int c = 32 * kc + 16 * half + 4 * ge;
-                            const f32x4 gt = ld4(s_gate + XC_H + c), hb = ld4(s_hb + XC_H + c);
+                            tg[set][half] = ld4(s_gate + XC_H + c);
+                            tb[set][half] = ld4(s_hb + XC_H + c);
+                        }
+                    };
+                    ld_e1(0, 0);
+#pragma unroll
+                    for (int kc = 0; kc < 16; ++kc) {
+                        if (kc + 1 < 16) ld_e1((kc + 1) & 1, kc + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        float hv[8];
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const f32x4 gt = tg[kc & 1][half], hb = tb[kc & 1][half];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) hv[4 * half + r] = softplus_fast(acc[2 * kc + half][r] * gt[r] + hb[r]);
                         }
@@ -325,11 +358,21 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
                     }
                 } else {
                     // ---- epilogue of hidden layer 2 + the 512 -> 3 output layer as a per-lane partial dot product
+                    f32x4 tq[2][5];
+                    auto ld_e2 = [&](int set, int mi) __attribute__((always_inline)) {
+                        const int c = 16 * mi + 4 * ge;
+                        tq[set][0] = ld4(s_gate + 2 * XC_H + c);
+                        tq[set][1] = ld4(s_hb + 2 * XC_H + c);
+                        tq[set][2] = ld4(s_w3 + c);
+                        tq[set][3] = ld4(s_w3 + XC_H + c);
+                        tq[set][4] = ld4(s_w3 + 2 * XC_H + c);
+                    };
+                    ld_e2(0, 0);
 #pragma unroll
                     for (int mi = 0; mi < 32; ++mi) {
-                        const int c = 16 * mi + 4 * ge;
-                        const f32x4 gt = ld4(s_gate + 2 * XC_H + c), hb = ld4(s_hb + 2 * XC_H + c);
-                        const f32x4 wx3 = ld4(a.w3 + c), wy3 = ld4(a.w3 + XC_H + c), wz3 = ld4(a.w3 + 2 * XC_H + c);
+                        if (mi + 1 < 32) ld_e2((mi + 1) & 1, mi + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f32x4 gt = tq[mi & 1][0], hb = tq[mi & 1][1], wx3 = tq[mi & 1][2], wy3 = tq[mi & 1][3], wz3 = tq[mi & 1][4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float hv = softplus_fast(acc[mi][r] * gt[r] + hb[r]);
