@@ -18,10 +18,10 @@
 //  * input layer 3 -> 512, output layer 512 -> 3, the RK4 state and its update are wave-local (state component d of
 //    column j lives in lane 16 d + j).
 //
-// Measured at cfg-2 (160 frames x 2048 points, 8 RK4 steps): 61.4 ms per launch against 80.4 ms for the f32 kernel.
-// With the CASPR_X6_DIAG timing switches: VALU stages (gates, input layer, epilogues) 11.0 ms, exposed -- one wave per
-// SIMD has nothing to overlap them with; product loop 34 ms (MFMA issue floor 26 ms); 128 piece barriers per stage
-// 6.7 ms; weight DMA 9.5 ms (the 3 MB of split weights go L2 -> LDS once per 64 points and stage: ~8 TB/s).
+// Measured at cfg-2 (160 frames x 2048 points, 8 RK4 steps): 54.5 ms per launch against 80.4 ms for the f32 kernel.
+// Of that (timing switches of the first version): VALU stages (gates, input layer, epilogues) ~10 ms, exposed -- one wave
+// per SIMD has nothing to overlap them with; MFMA issue floor of the product loop 26 ms; piece barriers ~6 ms; weight DMA
+// 8-9.5 ms (the 3 MB of split weights go L2 -> LDS once per 64 points and stage: ~9 TB/s).
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
