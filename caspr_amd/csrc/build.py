@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["point_ops.hip", "gemm.hip", "gemm_bf16x6.hip", "sa_mlp.hip", "ode.hip", "ode_bf16x6.hip", "backward.hip", "backward_points.hip", "backward_flow.hip", "emd.hip"]
 EXTRA = {"point_ops.hip": ["-ffp-contract=off"], "emd.hip": ["-ffp-contract=off"],
          # the 64-piece product loop of the bf16x6 CNF kernel must unroll completely (static register indices)
-         "ode_bf16x6.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+         "ode_bf16x6.hip": ["-mllvm", "-pragma-unroll-threshold=400000"]}
 OUT = os.path.join(HERE, "libcaspr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

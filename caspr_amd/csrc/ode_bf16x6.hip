@@ -126,45 +126,14 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     // the first piece of layer 1; every layer pass leaves the NEXT pass's first piece in flight
     dma(a.w1x, 0, lane0 * 16);
 
-    // B fragments of the layer input, [k chunk][plane] (192 registers).  The architectural VGPR file is 256 registers and
-    // the accumulators already fill half of the AGPR file, so the fragments of the first XC_PARK chunks are PARKED in
-    // AGPRs (v_accvgpr_write / _read, 12 moves per chunk and layer) and only the rest stays in VGPRs: with all 192 in
-    // VGPRs the A-fragment reads had two registers to rotate through and every LDS latency was exposed.
-    unsigned park[XC_PARK * 12];
-    bf16x8 bfr[16 - XC_PARK][3];
-    f32x4 acc[32];
-    auto set_b = [&](int kc, int pl, u32x4 v) {
-        if (kc < XC_PARK) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) asm("v_accvgpr_write_b32 %0, %1" : "=a"(park[(kc * 3 + pl) * 4 + c]) : "v"(v[c]));
-        } else {
-            bfr[kc < XC_PARK ? 0 : kc - XC_PARK][pl] = __builtin_bit_cast(bf16x8, v);
-        }
-    };
-    auto get_b = [&](int kc, int pl) -> bf16x8 {
-        if (kc < XC_PARK) {
-            u32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) asm("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(park[(kc * 3 + pl) * 4 + c]));
-            return __builtin_bit_cast(bf16x8, v);
-        }
-        return bfr[kc < XC_PARK ? 0 : kc - XC_PARK][pl];
-    };
-
-    // 8 f32 activations (the 8 k-slots of this lane in chunk kc) -> three bf16 planes
-    auto to_bfr = [&](int kc, const float (&hv)[8]) {
-        u32x4 v[3];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned p1, p2, p3;
-            xc_split_pair(hv[2 * q], hv[2 * q + 1], p1, p2, p3);
-            v[0][q] = p1;
-            v[1][q] = p2;
-            v[2][q] = p3;
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) set_b(kc, pl, v[pl]);
-    };
+    // The B fragments of a layer input are PRODUCED WHILE THE LAYER RUNS: the pieces go k-chunk-major, so chunk kc+1's three
+    // planes (12 registers) are only needed when chunk kc's two pieces are done -- its input-layer values (layer 1) or its
+    // slice of layer 1's epilogue (layer 2: gate * acc + bias, softplus, split) are computed in quarters inside the
+    // MFMA runs of chunk kc, where the VALU work hides behind the matrix pipe.  Two accumulator sets (layer 1's is
+    // consumed chunk by chunk while layer 2 fills its own) instead of 192 fragment registers.
+    f32x4 acc1[32], acc2[32];
+    u32x4 bkw[2][3];              // B-fragment planes of the current / next k chunk, by chunk parity
+    f32x4 tg, tb, tw[3];          // table values of the half chunk being produced
 
     for (int step = 0; step < a.steps; ++step) {
 #pragma unroll 1
@@ -199,189 +168,208 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
             const float ystage = (stage == 0) ? y : y + aw * kprev;
             const float y0 = __shfl(ystage, j), y1 = __shfl(ystage, 16 + j), y2 = __shfl(ystage, 32 + j);
 
-            // ---- input layer 3 -> 512 (diffeq_layers.py:83-90 + softplus) straight into B fragments.  The table values of
-            // chunk kc+1 are requested before chunk kc is computed (two static register sets); sched_barrier keeps hipcc
-            // from hoisting ALL sixteen chunks' loads (spills) and from sinking them to their use (exposed LDS latency).
-            {
-                f32x4 tg[2][2], tb[2][2], tw[2][2][3];
-                auto ld_in = [&](int set, int kc) __attribute__((always_inline)) {
+            // ---- producers of B fragments, a quarter (two k-slots) at a time; the tables of a half chunk one region earlier
+            auto put_pair = [&](int kc, int q, float v0, float v1) __attribute__((always_inline)) {
+                unsigned p1, p2, p3;
+                xc_split_pair(v0, v1, p1, p2, p3);
+                bkw[kc & 1][0][q] = p1;
+                bkw[kc & 1][1][q] = p2;
+                bkw[kc & 1][2][q] = p3;
+            };
+            // input layer 3 -> 512 (diffeq_layers.py:83-90 + softplus): slots 2q, 2q+1 of chunk kc = units 32kc + 16h + 4g + r
+            auto tab_in = [&](int kc, int hf) __attribute__((always_inline)) {
+                const int c = 32 * kc + 16 * hf + 4 * g;
+                tg = ld4(s_gate + c);
+                tb = ld4(s_hb + c);
+                tw[0] = ld4(s_w0 + 3 * c);
+                tw[1] = ld4(s_w0 + 3 * c + 4);
+                tw[2] = ld4(s_w0 + 3 * c + 8);
+            };
+            auto quad_in = [&](int kc, int q) __attribute__((always_inline)) {
+                const float w[12] = {tw[0][0], tw[0][1], tw[0][2], tw[0][3], tw[1][0], tw[1][1], tw[1][2], tw[1][3], tw[2][0], tw[2][1], tw[2][2], tw[2][3]};
+                float v[2];
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int c = 32 * kc + 16 * half + 4 * g;
-                        tg[set][half] = ld4(s_gate + c);
-                        tb[set][half] = ld4(s_hb + c);
-                        tw[set][half][0] = ld4(s_w0 + 3 * c);
-                        tw[set][half][1] = ld4(s_w0 + 3 * c + 4);
-                        tw[set][half][2] = ld4(s_w0 + 3 * c + 8);
-                    }
-                };
-                ld_in(0, 0);
-#pragma unroll
-                for (int kc = 0; kc < 16; ++kc) {
-                    if (kc + 1 < 16) ld_in((kc + 1) & 1, kc + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    float hv[8];
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const f32x4 gt = tg[kc & 1][half], hb = tb[kc & 1][half];
-                        const f32x4 wa = tw[kc & 1][half][0], wb = tw[kc & 1][half][1], wc = tw[kc & 1][half][2];
-                        const float w[12] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3], wc[0], wc[1], wc[2], wc[3]};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pre = (w[3 * r] * y0 + w[3 * r + 1] * y1 + w[3 * r + 2] * y2) * gt[r] + hb[r];
-                            hv[4 * half + r] = softplus_fast(pre);
-                        }
-                    }
-                    to_bfr(kc, hv);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * (q & 1) + e;
+                    const float pre = (w[3 * r] * y0 + w[3 * r + 1] * y1 + w[3 * r + 2] * y2) * tg[r] + tb[r];
+                    v[e] = softplus_fast(pre);
                 }
-            }
+                put_pair(kc, q, v[0], v[1]);
+            };
+            // epilogue of hidden layer 1 for chunk kc of layer 2: units 32kc + 16h + 4g + r = rows of acc1[2kc + h]
+            auto tab_e1 = [&](int kc, int hf) __attribute__((always_inline)) {
+                const int c = 32 * kc + 16 * hf + 4 * g;
+                tg = ld4(s_gate + XC_H + c);
+                tb = ld4(s_hb + XC_H + c);
+            };
+            auto quad_e1 = [&](int kc, int q) __attribute__((always_inline)) {
+                float v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * (q & 1) + e;
+                    v[e] = softplus_fast(acc1[2 * kc + (q >> 1)][r] * tg[r] + tb[r]);
+                }
+                put_pair(kc, q, v[0], v[1]);
+            };
 
-            float part[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int L = 0; L < 2; ++L) {
-                const unsigned char *wx = L == 0 ? a.w1x : a.w2x;
-                const unsigned char *wnext = L == 0 ? a.w2x : a.w1x;
+            // 4 / 20 MFMAs of four row tiles: smallest terms first; term-major, i.e. four independent accumulators between
+            // dependent MFMAs
+            auto mma_head = [&](f32x4 (&acc)[32], const bf16x8 (&af)[4][3], const u32x4 (&b)[3], int m0) __attribute__((always_inline)) {
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][2], b0, acc[m0 + u], 0, 0, 0);
+            };
+            auto mma_tail = [&](f32x4 (&acc)[32], const bf16x8 (&af)[4][3], const u32x4 (&b)[3], int m0) __attribute__((always_inline)) {
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0]), b1 = __builtin_bit_cast(bf16x8, b[1]), b2 = __builtin_bit_cast(bf16x8, b[2]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], b1, acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b2, acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], b0, acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b1, acc[m0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b0, acc[m0 + u], 0, 0, 0);
+            };
+
+            // One layer pass.  A piece (48 KB, k chunk p >> 1, row half p & 1) is four groups of four row tiles (24 MFMAs each),
+            // read into two fragment sets alternately and skewed by one group: a scheduling region = the 12 reads of group
+            // G+1, interleaved two per MFMA with the first MFMAs of the 20 that remain of group G ("tail"), then the first
+            // four MFMAs of group G+1 ("head") -- hipcc waits with lgkmcnt(0), never a counted wait, before the first use of
+            // a set, and at the head that wait is free.  Six of the eight regions of a k chunk also carry a quarter of the
+            // next chunk's B fragments (VALU) or the table reads for it.  sched_group_barrier builds the patterns,
+            // sched_barrier(0) closes a region (hipcc otherwise sinks every read to just before its use).  The last group of
+            // piece p-1 finishes after the barrier of piece p.
+#define XC_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define XC_RM6 XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) \
+    XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1)
+#define XC_VM4 XC_SGB(0x002, 2) XC_SGB(0x008, 1) XC_SGB(0x002, 2) XC_SGB(0x008, 1) XC_SGB(0x002, 2) XC_SGB(0x008, 1) XC_SGB(0x002, 2) XC_SGB(0x008, 1)
+#define XC_REGION_PLAIN XC_RM6 XC_SGB(0x008, 18) __builtin_amdgcn_sched_barrier(0);
+#define XC_REGION_TAB XC_RM6 XC_SGB(0x100, 5) XC_SGB(0x008, 18) __builtin_amdgcn_sched_barrier(0);
+#define XC_REGION_VALU XC_RM6 XC_VM4 XC_VM4 XC_VM4 XC_VM4 XC_SGB(0x002, 2) XC_SGB(0x008, 2) __builtin_amdgcn_sched_barrier(0);
+            auto layer = [&](const unsigned char *wx, const unsigned char *wnext, f32x4 (&acc)[32], auto tab, auto quad) __attribute__((always_inline)) {
 #pragma unroll
                 for (int mi = 0; mi < 32; ++mi) acc[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                bf16x8 bk[2][3];   // the three planes of the current / previous k chunk (by chunk parity)
-                // 24 MFMAs of four row tiles: smallest terms first; term-major, i.e. four independent accumulators between
-                // dependent MFMAs
-                auto mma_head = [&](const bf16x8 (&af)[4][3], const bf16x8 (&b)[3], int m0) __attribute__((always_inline)) {
+                bf16x8 af0[4][3], af1[4][3];
+                auto rd = [&](bf16x8 (&af)[4][3], const unsigned char *A, int G) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][2], b[0], acc[m0 + u], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) af[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (4 * G + u) * 1024);
                 };
-                auto mma_tail = [&](const bf16x8 (&af)[4][3], const bf16x8 (&b)[3], int m0) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], b[1], acc[m0 + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b[2], acc[m0 + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][1], b[0], acc[m0 + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b[1], acc[m0 + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[m0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][0], b[0], acc[m0 + u], 0, 0, 0);
-                };
-                // A piece is four groups of four row tiles (24 MFMAs each), read into two fragment sets alternately and
-                // skewed by one group: a scheduling region = the 12 reads of group G+1, interleaved two per MFMA with the
-                // first MFMAs of the 20 that remain of group G ("tail"), and then the first four MFMAs of group G+1
-                // ("head").  hipcc waits with lgkmcnt(0) -- never a counted wait -- before the first use of a set: at the
-                // head that wait is free (the reads were requested >= 14 MFMAs earlier and nothing younger is in flight).
-                // sched_group_barrier builds the pattern, sched_barrier(0) closes the region (hipcc otherwise sinks every
-                // read to just before its use).  The last group of piece p-1 finishes after the barrier of piece p.
-#define XC_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
-#define XC_INTERLEAVE                                                                                                          \
-    XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2)       \
-    XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x100, 2) XC_SGB(0x008, 1) XC_SGB(0x008, 18)                       \
-    __builtin_amdgcn_sched_barrier(0);
-                if (!(a.diag & 2)) {
-                    bf16x8 af0[4][3], af1[4][3];
-                    auto rd = [&](bf16x8 (&af)[4][3], const unsigned char *A, int G) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) af[u][pl] = *(const bf16x8 *)(A + pl * XC_PA + (4 * G + u) * 1024);
-                    };
-#pragma unroll
-                    for (int p = 0; p < XC_NPIECE; ++p) {
-                        // piece p (its DMA was issued one piece ago) has landed once nothing is outstanding; lgkmcnt: this wave's
-                        // reads of the buffer about to be refilled.  Raw barrier: no compiler-added waits.
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();   // piece p is there for every wave; everybody is done with buffer (p + 1) & 1
-                        asm volatile("" ::: "memory");
-                        const int kc = p >> 1, mt = p & 1;
-                        const int kcp = (p - 1) >> 1, mtp = (p - 1) & 1;
-                        const unsigned char *wq = p + 1 < XC_NPIECE ? wx : wnext;
-                        const int pn = p + 1 < XC_NPIECE ? p + 1 : 0;
-                        const unsigned char *A = wbuf + (p & 1) * XC_PIECE + aoff;
-                        if (mt == 0) {
-                            bk[kc & 1][0] = get_b(kc, 0);
-                            bk[kc & 1][1] = get_b(kc, 1);
-                            bk[kc & 1][2] = get_b(kc, 2);
-                        }
-                        // region 0: read group 0 | the rest of the previous piece's group 3 | first MFMAs of group 0
-                        __builtin_amdgcn_sched_barrier(0);
-                        rd(af0, A, 0);
-                        dma(wq, pn, lane16, 0, 4);
-                        if (p > 0) mma_tail(af1, bk[kcp & 1], 16 * mtp + 12);
-                        mma_head(af0, bk[kc & 1], 16 * mt);
-                        XC_INTERLEAVE
-                        // region 1
-                        rd(af1, A, 1);
-                        dma(wq, pn, lane16, 4, 8);
-                        mma_tail(af0, bk[kc & 1], 16 * mt);
-                        mma_head(af1, bk[kc & 1], 16 * mt + 4);
-                        XC_INTERLEAVE
-                        // region 2
-                        rd(af0, A, 2);
-                        dma(wq, pn, lane16, 8, 12);
-                        mma_tail(af1, bk[kc & 1], 16 * mt + 4);
-                        mma_head(af0, bk[kc & 1], 16 * mt + 8);
-                        XC_INTERLEAVE
-                        // region 3
-                        rd(af1, A, 3);
-                        mma_tail(af0, bk[kc & 1], 16 * mt + 8);
-                        mma_head(af1, bk[kc & 1], 16 * mt + 12);
-                        XC_INTERLEAVE
+                for (int p = 0; p < XC_NPIECE; ++p) {
+                    // piece p (its DMA was issued one piece ago) has landed once nothing is outstanding; lgkmcnt: this wave's
+                    // reads of the buffer about to be refilled.  Raw barrier: no compiler-added waits.
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // piece p is there for every wave; everybody is done with buffer (p + 1) & 1
+                    asm volatile("" ::: "memory");
+                    const int kc = p >> 1, mt = p & 1;
+                    const int kcp = (p - 1) >> 1, mtp = (p - 1) & 1;
+                    const bool more = kc + 1 < 16;   // a next chunk to produce
+                    const unsigned char *wq = p + 1 < XC_NPIECE ? wx : wnext;
+                    const int pn = p + 1 < XC_NPIECE ? p + 1 : 0;
+                    const unsigned char *A = wbuf + (p & 1) * XC_PIECE + aoff;
+                    // region 0: read group 0 | the rest of the previous piece's group 3 | first MFMAs of group 0
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd(af0, A, 0);
+                    dma(wq, pn, lane16, 0, 4);
+                    if (p > 0) mma_tail(acc, af1, bkw[kcp & 1], 16 * mtp + 12);
+                    mma_head(acc, af0, bkw[kc & 1], 16 * mt);
+                    if (more && mt == 0) {
+                        tab(kc + 1, 0);
+                        XC_REGION_TAB
+                    } else if (more) {
+                        quad(kc + 1, 2);
+                        XC_REGION_VALU
+                    } else {
+                        XC_REGION_PLAIN
                     }
-                    mma_tail(af1, bk[((XC_NPIECE - 1) >> 1) & 1], 16 * ((XC_NPIECE - 1) & 1) + 12);
+                    // region 1
+                    rd(af1, A, 1);
+                    dma(wq, pn, lane16, 4, 8);
+                    mma_tail(acc, af0, bkw[kc & 1], 16 * mt);
+                    mma_head(acc, af1, bkw[kc & 1], 16 * mt + 4);
+                    if (more) {
+                        quad(kc + 1, mt == 0 ? 0 : 3);
+                        XC_REGION_VALU
+                    } else {
+                        XC_REGION_PLAIN
+                    }
+                    // region 2
+                    rd(af0, A, 2);
+                    dma(wq, pn, lane16, 8, 12);
+                    mma_tail(acc, af1, bkw[kc & 1], 16 * mt + 4);
+                    mma_head(acc, af0, bkw[kc & 1], 16 * mt + 8);
+                    if (more && mt == 0) {
+                        quad(kc + 1, 1);
+                        XC_REGION_VALU
+                    } else {
+                        XC_REGION_PLAIN
+                    }
+                    // region 3
+                    rd(af1, A, 3);
+                    mma_tail(acc, af0, bkw[kc & 1], 16 * mt + 8);
+                    mma_head(acc, af1, bkw[kc & 1], 16 * mt + 12);
+                    if (more && mt == 0) {
+                        tab(kc + 1, 1);
+                        XC_REGION_TAB
+                    } else {
+                        XC_REGION_PLAIN
+                    }
                 }
-                int le = lane;   // opaque again: the epilogue's table / w3 addresses must not be hoisted above the product loop
+                mma_tail(acc, af1, bkw[((XC_NPIECE - 1) >> 1) & 1], 16 * ((XC_NPIECE - 1) & 1) + 12);
+            };
+
+            float part[3] = {0.f, 0.f, 0.f};
+            if (!(a.diag & 2)) {
+                // chunk 0 of layer 1 up front (exposed: 1/16 of the input layer)
+                tab_in(0, 0);
+                quad_in(0, 0);
+                quad_in(0, 1);
+                tab_in(0, 1);
+                quad_in(0, 2);
+                quad_in(0, 3);
+                layer(a.w1x, a.w2x, acc1, tab_in, quad_in);
+                // chunk 0 of layer 2
+                tab_e1(0, 0);
+                quad_e1(0, 0);
+                quad_e1(0, 1);
+                tab_e1(0, 1);
+                quad_e1(0, 2);
+                quad_e1(0, 3);
+                layer(a.w2x, a.w1x, acc2, tab_e1, quad_e1);
+            }
+            {
+                // ---- epilogue of hidden layer 2 + the 512 -> 3 output layer as a per-lane partial dot product (tables one
+                // row tile ahead)
+                int le = lane;   // opaque again: the table addresses must not be hoisted above the product loop
                 asm volatile("" : "+v"(le));
                 const int ge = le >> 4;
-                if (L == 0) {
-                    // ---- epilogue of hidden layer 1: the accumulators become layer 2's B fragments (tables one chunk ahead)
-                    f32x4 tg[2][2], tb[2][2];
-                    auto ld_e1 = [&](int set, int kc) __attribute__((always_inline)) {
+                f32x4 tq[2][5];
+                auto ld_e2 = [&](int set, int mi) __attribute__((always_inline)) {
+                    const int c = 16 * mi + 4 * ge;
+                    tq[set][0] = ld4(s_gate + 2 * XC_H + c);
+                    tq[set][1] = ld4(s_hb + 2 * XC_H + c);
+                    tq[set][2] = ld4(s_w3 + c);
+                    tq[set][3] = ld4(s_w3 + XC_H + c);
+                    tq[set][4] = ld4(s_w3 + 2 * XC_H + c);
+                };
+                ld_e2(0, 0);
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const int c = 32 * kc + 16 * half + 4 * ge;
-                            tg[set][half] = ld4(s_gate + XC_H + c);
-                            tb[set][half] = ld4(s_hb + XC_H + c);
-                        }
-                    };
-                    ld_e1(0, 0);
+                for (int mi = 0; mi < 32; ++mi) {
+                    if (mi + 1 < 32) ld_e2((mi + 1) & 1, mi + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x4 gt = tq[mi & 1][0], hb = tq[mi & 1][1], wx3 = tq[mi & 1][2], wy3 = tq[mi & 1][3], wz3 = tq[mi & 1][4];
 #pragma unroll
-                    for (int kc = 0; kc < 16; ++kc) {
-                        if (kc + 1 < 16) ld_e1((kc + 1) & 1, kc + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        float hv[8];
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const f32x4 gt = tg[kc & 1][half], hb = tb[kc & 1][half];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) hv[4 * half + r] = softplus_fast(acc[2 * kc + half][r] * gt[r] + hb[r]);
-                        }
-                        to_bfr(kc, hv);
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int r = 0; r < 4; ++r) {
+                        const float hv = softplus_fast(acc2[mi][r] * gt[r] + hb[r]);
+                        part[0] += wx3[r] * hv;
+                        part[1] += wy3[r] * hv;
+                        part[2] += wz3[r] * hv;
                     }
-                } else {
-                    // ---- epilogue of hidden layer 2 + the 512 -> 3 output layer as a per-lane partial dot product
-                    f32x4 tq[2][5];
-                    auto ld_e2 = [&](int set, int mi) __attribute__((always_inline)) {
-                        const int c = 16 * mi + 4 * ge;
-                        tq[set][0] = ld4(s_gate + 2 * XC_H + c);
-                        tq[set][1] = ld4(s_hb + 2 * XC_H + c);
-                        tq[set][2] = ld4(s_w3 + c);
-                        tq[set][3] = ld4(s_w3 + XC_H + c);
-                        tq[set][4] = ld4(s_w3 + 2 * XC_H + c);
-                    };
-                    ld_e2(0, 0);
-#pragma unroll
-                    for (int mi = 0; mi < 32; ++mi) {
-                        if (mi + 1 < 32) ld_e2((mi + 1) & 1, mi + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const f32x4 gt = tq[mi & 1][0], hb = tq[mi & 1][1], wx3 = tq[mi & 1][2], wy3 = tq[mi & 1][3], wz3 = tq[mi & 1][4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float hv = softplus_fast(acc[mi][r] * gt[r] + hb[r]);
-                            part[0] += wx3[r] * hv;
-                            part[1] += wy3[r] * hv;
-                            part[2] += wz3[r] * hv;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- output ConcatSquash (no softplus: odefunc.py:103): sum the four lane groups, every lane gets all three
