@@ -9,19 +9,18 @@
 //  * the hidden activation never touches LDS: an accumulator (D) fragment holds rows 4g..4g+3 of a 16-row tile for
 //    column j, a bf16 B fragment holds 8 k-slots for column j -- two row tiles ARE one B fragment of the next layer
 //    once the weight pack lists its k in the same order (slot s of lane group g <-> unit 32kc + 4g + s for s < 4,
-//    32kc + 16 + 4g + s - 4 above).  The epilogue (gate * acc + bias, softplus, split) writes the next layer's 16 x 3
-//    B fragments straight into registers (192 VGPRs);
+//    32kc + 16 + 4g + s - 4 above);
+//  * B fragments are produced WHILE the layer runs (pieces go k-chunk-major): chunk kc+1's input-layer values (layer 1)
+//    or its slice of layer 1's epilogue (layer 2) are computed in quarters inside chunk kc's MFMA runs, hidden behind
+//    the matrix pipe; two accumulator sets instead of 192 fragment registers;
 //  * LDS is the weight stage shared by the four waves: 48 KB pieces (256 rows x 32 k x 3 planes, pre-swizzled image)
-//    arrive by LDS-DMA, double-buffered, one raw s_barrier per piece of 96 MFMAs = 1536 matrix-pipe cycles per wave
-//    (a ring of four 24 KB pieces with counted vmcnt waits, three in flight, measured the same DMA cost and twice the
-//    barrier cost: 61.4 ms);
-//  * input layer 3 -> 512, output layer 512 -> 3, the RK4 state and its update are wave-local (state component d of
-//    column j lives in lane 16 d + j).
+//    arrive by LDS-DMA, double-buffered, one raw s_barrier per piece of 96 MFMAs = 1536 matrix-pipe cycles per wave;
+//  * output layer 512 -> 3, the RK4 state and its update are wave-local (state component d of column j lives in lane
+//    16 d + j).
 //
-// Measured at cfg-2 (160 frames x 2048 points, 8 RK4 steps): 54.5 ms per launch against 80.4 ms for the f32 kernel.
-// Of that (timing switches of the first version): VALU stages (gates, input layer, epilogues) ~10 ms, exposed -- one wave
-// per SIMD has nothing to overlap them with; MFMA issue floor of the product loop 26 ms; piece barriers ~6 ms; weight DMA
-// 8-9.5 ms (the 3 MB of split weights go L2 -> LDS once per 64 points and stage: ~9 TB/s).
+// Measured at cfg-2 (160 frames x 2048 points, 8 RK4 steps): 51.3 ms per launch against 80.4 ms for the f32 kernel
+// (DESIGN.md section 3 lists the steps from 64.8 ms and what is left: MFMA issue floor 26 ms, exposed VALU 3.6 ms,
+// piece barriers ~6 ms, weight DMA 8-9.5 ms -- the 3 MB of split weights go L2 -> LDS once per 64 points and stage).
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -32,7 +31,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define XC_PA (256 * 64)          // one plane of a piece
 #define XC_PIECE (3 * XC_PA)      // 48 KB: 256 rows x 32 k x 3 planes
 #define XC_NPIECE 32              // per layer: 16 k chunks x 2 row halves
-#define XC_PARK 10                // k chunks whose B fragments are parked in AGPRs
 #define XC_RING 2                 // LDS double buffer of pieces
 #define XC_LDS (XC_RING * XC_PIECE + (6 * XC_H + 3 * XC_H + 3 * XC_H + 8) * 4)
 
