@@ -248,3 +248,47 @@ def test_train_loop_cadence_and_resume_on_cpu(tmp_path):
     assert val2 == val
     for k in init:
         assert torch.equal(m1.state_dict()[k], m2.state_dict()[k]), k
+
+
+def test_bf16x6_split_is_exact_and_six_products_are_f32_accurate():
+    """The arithmetic behind csrc/gemm_bf16x6.hip / ode_bf16x6.hip, restated with torch on the CPU: (1) both three-way
+    bf16 splits (truncating, as the weight packs; round-to-nearest, as v_cvt_pk_bf16_f32 in the kernels) reproduce every
+    f32 value EXACTLY; (2) the six retained partial products, accumulated in f32, are as close to the f64 dot product as a
+    plain f32 evaluation."""
+    g = torch.Generator().manual_seed(0)
+    mag = torch.exp(torch.empty(200000).uniform_(-30.0, 30.0, generator=g))
+    x = (torch.randn(200000, generator=g) * mag).float()
+    x = torch.cat([x, torch.tensor([0.0, 1.0, -1.0, 3.0e38, 1.1754944e-38, 1e-30, -7.3e-12])])
+
+    def split_rn(v):
+        h1 = v.bfloat16().float()
+        r1 = v - h1
+        h2 = r1.bfloat16().float()
+        r2 = r1 - h2
+        return h1, h2, r2.bfloat16().float()
+
+    def split_trunc(v):
+        def top(u):
+            return (u.view(torch.int32) & -65536).view(torch.float32)
+        h1 = top(v)
+        r1 = v - h1
+        h2 = top(r1)
+        return h1, h2, top(r1 - h2)
+
+    for split in (split_rn, split_trunc):
+        h1, h2, h3 = split(x)
+        for h in (h1, h2, h3):
+            assert torch.equal(h.bfloat16().float(), h)                       # each part IS a bf16 number
+        assert torch.equal(h1.double() + h2.double() + h3.double(), x.double())  # and the three add up exactly
+
+    K, M, N = 512, 64, 96
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).float()
+    a = torch.nn.functional.softplus(torch.randn(K, N, generator=g)).float()
+    ref = w.double() @ a.double()
+    w1, w2, w3 = split_trunc(w)
+    a1, a2, a3 = split_rn(a)
+    six = ((w3 @ a1) + (w2 @ a2) + (w1 @ a3)) + ((w2 @ a1) + (w1 @ a2)) + (w1 @ a1)   # f32 accumulation, smallest terms first
+    e6, e32 = float((six.double() - ref).abs().max()), float(((w @ a).double() - ref).abs().max())
+    assert e6 <= 1.5 * e32 + 1e-7, (e6, e32)
+    three = (w1 @ a1) + (w1 @ a2) + (w2 @ a1)                                  # what "bf16x3" would give: not f32-accurate
+    assert float((three.double() - ref).abs().max()) > 3.0 * e32
