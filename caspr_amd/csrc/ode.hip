@@ -447,6 +447,14 @@ __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// The prefetch of the next chunk (8 weight buffer loads, 2 LDS reads) is spread through the 128 MFMAs of the current one
+// by sched_group_barrier -- one load per 8 MFMAs -- instead of being issued as a burst in front of them (hipcc on its
+// own sinks the loads to just before their use: no prefetch at all); sched_barrier(0) closes the region.
+#define CNF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define CNF_PREFETCH_PATTERN                                                                                                  \
+    CNF_SGB(0x100, 2) CNF_SGB(0x008, 4) CNF_SGB(0x020, 1) CNF_SGB(0x008, 8) CNF_SGB(0x020, 1) CNF_SGB(0x008, 8) CNF_SGB(0x020, 1) \
+    CNF_SGB(0x008, 8) CNF_SGB(0x020, 1) CNF_SGB(0x008, 8) CNF_SGB(0x020, 1) CNF_SGB(0x008, 8) CNF_SGB(0x020, 1) CNF_SGB(0x008, 8) \
+    CNF_SGB(0x020, 1) CNF_SGB(0x008, 8) CNF_SGB(0x020, 1) CNF_SGB(0x008, 68) __builtin_amdgcn_sched_barrier(0);
 __device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, const float *Hbuf, int wave, int lane, int rot,
                                                f32x4 (&acc)[CNF_MI][CNF_CT])
 {
@@ -478,13 +486,13 @@ __device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, con
             for (int mi = 0; mi < CNF_MI; ++mi) a1[mi] = buf_ld4(rs, voff, sbase + (mi * CNF_KC + k1) * 1024);
 #pragma unroll
             for (int ct = 0; ct < CNF_CT; ++ct) b1[ct] = ld4(Hbuf + (k1 - (u + 1)) * 4 * CNF_NCOL * 4 + boff[u + 1][ct]);
-            __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks these loads to just before their use (no prefetch)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int mi = 0; mi < CNF_MI; ++mi)
 #pragma unroll
                     for (int ct = 0; ct < CNF_CT; ++ct) acc[mi][ct] = mfma16(a0[mi][q], b0[ct][q], acc[mi][ct]);
+            CNF_PREFETCH_PATTERN
             // prefetch the chunk after that into set 0 (wraps harmlessly on the last pair)
             const int un = (u + 2) & 3;
             const int k2 = (kc + u + 2 + rot) & (CNF_KC - 1);
@@ -492,13 +500,13 @@ __device__ __forceinline__ void cnf_mfma_layer(const float *__restrict__ wp, con
             for (int mi = 0; mi < CNF_MI; ++mi) a0[mi] = buf_ld4(rs, voff, sbase + (mi * CNF_KC + k2) * 1024);
 #pragma unroll
             for (int ct = 0; ct < CNF_CT; ++ct) b0[ct] = ld4(Hbuf + (k2 - un) * 4 * CNF_NCOL * 4 + boff[un][ct]);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int mi = 0; mi < CNF_MI; ++mi)
 #pragma unroll
                     for (int ct = 0; ct < CNF_CT; ++ct) acc[mi][ct] = mfma16(a1[mi][q], b1[ct][q], acc[mi][ct]);
+            CNF_PREFETCH_PATTERN
         }
     }
 }
