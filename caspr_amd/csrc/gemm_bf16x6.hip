@@ -12,8 +12,11 @@
 // tiles, 128 accumulator registers).  LDS per chunk (72 KB, single buffer, two workgroups per CU): 3 weight planes of
 // 256 rows x 64 B, filled by LDS-DMA from a pre-swizzled pack (no staging registers), and 3 activation planes of 128 rows
 // x 64 B written by the threads after the split (and the fused GroupNorm/ReLU of the producer, as in gemm.hip).  A
-// row's four 16-byte pieces sit at piece ^ swz(row), swz = 0,3,2,1 per row quad: the 16 lanes of every ds_read_b128
-// lane group ({0-3,12-15,20-27}, ...) then touch 16 distinct 16-byte slots of the 256-byte bank window.
+// row's four 16-byte pieces sit at piece ^ swz(row), swz = (row >> 1) & 3: the 16 lanes of every ds_read_b128 lane
+// group ({0-3,12-15,20-27}, ...) touch 16 distinct 16-byte slots of the 256-byte bank window, AND the 8 consecutive
+// lanes of a ds_write_b128 group (rows r..r+7 of one piece column) touch 8 distinct slots of the 128-byte store
+// window (swz = 0,3,2,1 per row QUAD, as in ode_bf16x6.hip, is conflict-free for the reads only: 21 % of this
+// kernel's LDS cycles were store conflicts, profiles/r01_bf16x6_optin_pmc_summary.txt).
 #include "common.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -26,7 +29,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define X6_CHUNK (3 * X6_PA)   // packed weight bytes per (channel tile, k chunk)
 #define X6_LDS (3 * X6_PA + 3 * X6_PB)
 
-__device__ __host__ __forceinline__ int x6_swz(int row) { return (0 - (row >> 2)) & 3; }
+__device__ __host__ __forceinline__ int x6_swz(int row) { return (row >> 1) & 3; }
 __device__ __forceinline__ int x6_off(int row, int piece) { return row * 64 + ((piece ^ x6_swz(row)) << 4); }
 
 // x = h1 + h2 + h3 exactly; each h keeps the top 8 significand bits of what is left (a bf16 value held in f32)
