@@ -29,6 +29,7 @@ struct SaArgs {
     unsigned long long *trace;   // debug stamps (NULL in production)
 };
 
+#define SAM_STAMP(i) if (a.trace && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = __builtin_amdgcn_s_memtime();
 template <int NS, int NCOL>
 __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
 {
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     const int b = blockIdx.y;
     const int m0 = blockIdx.x * NCEN;
 
+    SAM_STAMP(0)
     // ---- neighbour indices + centres
     if (tid < NCOL) {
         const int cen = tid / NS, s = tid % NS;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     }
     __syncthreads();
 
+    SAM_STAMP(1)
     float *bin = bufA, *bout = bufB;
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
             }
         }
         __syncthreads();
+        SAM_STAMP(2 + 3 * l)
 
         // ---- GroupNorm statistics per (centre, group): two-pass over cpg*NS elements in LDS, in f64.
         // Most first-level neighbourhoods are padded with duplicates of one or two points; GroupNorm then
@@ -143,26 +147,41 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
             const int stat = tid / TPS, sub = tid % TPS;
             const int cen = stat >> 4, grp = stat & 15;
             const int cnt = cpg * NS;
-            double s = 0.0;
-            for (int e = sub; e < cnt; e += TPS) {
-                const int co = grp * cpg + e / NS, col = cen * NS + e % NS;
-                s += (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)];
+            // One pass in f64 (sum and sum of squares: with 53 bits the cancellation in E[x^2] - mean^2 is ~1e-14 absolute,
+            // nothing next to eps = 1e-5), 16-byte reads where a group is made of whole channel quads: the scalar two-pass
+            // version was a quarter to a third of this kernel's time (4-way bank conflicts on 16-byte-strided b32 reads).
+            double s = 0.0, ss = 0.0;
+            if ((cpg & 3) == 0) {
+                const int nq = cpg >> 2;
+                for (int e = sub; e < nq * NS; e += TPS) {
+                    const f32x4 x4 = ld4(bout + btile_off(grp * nq + e / NS, cen * NS + e % NS, NCOL));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double d = (double)x4[q];
+                        s += d;
+                        ss += d * d;
+                    }
+                }
+            } else {
+                for (int e = sub; e < cnt; e += TPS) {
+                    const int co = grp * cpg + e / NS, col = cen * NS + e % NS;
+                    const double d = (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)];
+                    s += d;
+                    ss += d * d;
+                }
             }
             s = row_allreduce_add<TPS>(s);
+            ss = row_allreduce_add<TPS>(ss);
             const double mean = s / (double)cnt;
-            double v = 0.0;
-            for (int e = sub; e < cnt; e += TPS) {
-                const int co = grp * cpg + e / NS, col = cen * NS + e % NS;
-                const double d = (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)] - mean;
-                v += d * d;
-            }
-            v = row_allreduce_add<TPS>(v);
+            double v = ss / (double)cnt - mean * mean;
+            v = v > 0.0 ? v * (double)cnt : 0.0;
             if (sub == 0) {
                 s_mean[stat] = mean;
                 s_rstd[stat] = __builtin_amdgcn_rsqf((float)(v / (double)cnt) + 1e-5f);
             }
         }
         __syncthreads();
+        SAM_STAMP(3 + 3 * l)
 
         if (l < 2) {
             // ---- normalise + ReLU in place; zero the K padding rows of the next layer's operand
@@ -187,6 +206,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                 st4(p, v);
             }
             __syncthreads();
+            SAM_STAMP(4 + 3 * l)
             float *t = bin;
             bin = bout;
             bout = t;
@@ -205,6 +225,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                 }
                 a.out[((long)b * a.M + m0 + cen) * a.ldo + a.out_off + co] = mx;
             }
+            SAM_STAMP(10)
         }
     }
 }

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Phase cycle breakdown of sa_mlp_kernel (thread 0 of one workgroup) via s_memtime stamps, for SA3..SA5."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from caspr_amd import lib, ops
+from caspr_amd.models import CaSPR
+from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences
+dev = torch.device("cuda:0")
+m = CaSPR(); m.load_state_dict(seeded_state_dict(m.state_dict(), 0)); m = m.to(dev).eval()
+so = ctypes.CDLL(lib.SO_PATH)
+x, _ = car_sequences(16, 10, 2048)
+xyz, feat = ops.prep_input(x.to(dev))
+names = ["setup+gather", "L1 mfma", "L1 stats", "L1 norm", "L2 mfma", "L2 stats", "L2 norm", "L3 mfma", "L3 stats", "L3 max"]
+sa = m.encoder.local_extract.set_abstractions
+cur_xyz, cur_feat, C = xyz, feat, 6
+for lvl in range(5):
+    idx = sa[lvl].indices(cur_xyz)
+    if lvl >= 2:
+        for sc in range(2):
+            out = torch.empty(cur_xyz.shape[0], sa[lvl].num_points_out, sa[lvl].get_num_features_out(), device=dev)
+            buf = torch.zeros(16, dtype=torch.int64, device=dev)
+            layers = sa[lvl].pointnet_modules[sc].kernel_layers()
+            ops.sa_mlp_max(cur_xyz, idx["new_xyz"], cur_feat, idx["ball_idx"][sc], C, layers, out, 0); torch.cuda.synchronize()
+            so.caspr_debug_set_sa_trace(ctypes.c_void_p(buf.data_ptr()))
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t0.record()
+            ops.sa_mlp_max(cur_xyz, idx["new_xyz"], cur_feat, idx["ball_idx"][sc], C, layers, out, 0)
+            t1.record(); torch.cuda.synchronize()
+            so.caspr_debug_set_sa_trace(ctypes.c_void_p(0))
+            t = buf.cpu()
+            d = (t[1:11] - t[0:10]).tolist()
+            print("SA%d scale %d: kernel %.3f ms; total %d cycles: " % (lvl + 1, sc, t0.elapsed_time(t1), int(t[10] - t[0])) + ", ".join("%s %d" % (n, v) for n, v in zip(names, d)))
+    cur_xyz, cur_feat = sa[lvl].run(cur_xyz, cur_feat, C, idx=idx)
+    C = cur_feat.shape[2]
