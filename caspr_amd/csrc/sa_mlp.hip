@@ -103,18 +103,26 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float *wrow = L.wp + ((long)rt * L.kc) * 256 + lane * 4;
-                f32x4 af = ld4(wrow);
-                for (int kc = 0; kc < L.kc; ++kc) {
-                    f32x4 an = af;
-                    if (kc + 1 < L.kc) an = ld4(wrow + (long)(kc + 1) * 256);
-                    f32x4 bf[CT];
+                // weight fragments two chunks ahead (two static registers, K chunk counts are even; clamped re-loads at the end
+                // keep the loop free of branches -- with a branch hipcc waits for ALL outstanding loads at every chunk)
+                const int klast = L.kc - 1;
+                f32x4 a0 = ld4(wrow), a1 = ld4(wrow + 256);
+                for (int kc = 0; kc < L.kc; kc += 2) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) bf[ct] = ld4(bin + btile_off(kc * 4 + g, ct * 16 + j, NCOL));
+                    for (int d = 0; d < 2; ++d) {
+                        const f32x4 af = d == 0 ? a0 : a1;
+                        const int ka = kc + d + 2 < klast ? kc + d + 2 : klast;
+                        if (d == 0) a0 = ld4(wrow + (long)ka * 256);
+                        else a1 = ld4(wrow + (long)ka * 256);
+                        f32x4 bf[CT];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                        for (int ct = 0; ct < CT; ++ct) bf[ct] = ld4(bin + btile_off((kc + d) * 4 + g, ct * 16 + j, NCOL));
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(af[q], bf[ct][q], acc[ct]);
-                    af = an;
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(af[q], bf[ct][q], acc[ct]);
+                    }
                 }
                 f32x4 bias4 = ld4(L.bias + rt * 16 + 4 * g);
 #pragma unroll
