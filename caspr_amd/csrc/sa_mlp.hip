@@ -106,23 +106,32 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                 // weight fragments two chunks ahead (two static registers, K chunk counts are even; clamped re-loads at the end
                 // keep the loop free of branches -- with a branch hipcc waits for ALL outstanding loads at every chunk)
                 const int klast = L.kc - 1;
-                f32x4 a0 = ld4(wrow), a1 = ld4(wrow + 256);
-                for (int kc = 0; kc < L.kc; kc += 2) {
+                f32x4 aq[4];
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        const f32x4 af = d == 0 ? a0 : a1;
-                        const int ka = kc + d + 2 < klast ? kc + d + 2 : klast;
-                        if (d == 0) a0 = ld4(wrow + (long)ka * 256);
-                        else a1 = ld4(wrow + (long)ka * 256);
-                        f32x4 bf[CT];
+                for (int d = 0; d < 4; ++d) aq[d] = ld4(wrow + (long)(d < klast ? d : klast) * 256);
+                auto step = [&](int d, int kc) __attribute__((always_inline)) {
+                    const f32x4 af = aq[d];
+                    const int ka = kc + 4 < klast ? kc + 4 : klast;
+                    aq[d] = ld4(wrow + (long)ka * 256);
+                    f32x4 bf[CT];
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) bf[ct] = ld4(bin + btile_off((kc + d) * 4 + g, ct * 16 + j, NCOL));
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int ct = 0; ct < CT; ++ct) bf[ct] = ld4(bin + btile_off(kc * 4 + g, ct * 16 + j, NCOL));
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                            for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(af[q], bf[ct][q], acc[ct]);
-                    }
+                        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(af[q], bf[ct][q], acc[ct]);
+                };
+                const int k4 = L.kc & ~3;
+                for (int kc = 0; kc < k4; kc += 4) {
+                    step(0, kc);
+                    step(1, kc + 1);
+                    step(2, kc + 2);
+                    step(3, kc + 3);
+                }
+                if (k4 < L.kc) {   // chunk counts are even: a tail of two
+                    step(0, k4);
+                    step(1, k4 + 1);
                 }
                 f32x4 bias4 = ld4(L.bias + rt * 16 + 4 * g);
 #pragma unroll
