@@ -22,7 +22,8 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "caspr_hip.h")]
+    inc = os.path.join(HERE, "..", "..", "include")
+    hdrs = [os.path.join(HERE, "common.h")] + sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(HERE, s)

@@ -2,8 +2,10 @@
 // stack for gfx950: farthest point sampling, ball query, grouping, three-NN, three-interpolate,
 // Chamfer, input preparation.  HBM/LDS-bound integer + f32-compare work: wave64 ballot / shuffle
 // reductions, clouds resident in registers / LDS.  Compiled with -ffp-contract=off: the squared
-// distances must round exactly like oracle/point_ops.c (every op rounded to f32, no FMA) because
-// the integer outputs are compared bit-exactly.
+// distances must round exactly like the upstream CUDA binaries' (restated in oracle/point_ops.c)
+// because the integer outputs are compared bit-exactly.  The only fused multiply-adds are the two
+// explicit ones of sqsum3(): nvcc's default -fmad=true turns  a*a + b*b + c*c  into
+// mul(b,b); fma(a,a,.); fma(c,c,.).
 #include <stdarg.h>
 #include <string.h>
 
@@ -25,12 +27,14 @@ void caspr_set_error(const char *fmt, ...)
 extern "C" const char *caspr_last_error_string(void) { return g_err; }
 extern "C" int caspr_abi_version(void) { return 1; }
 
+__device__ __forceinline__ float sqsum3(float a, float b, float c)
+{
+    const float yy = b * b;
+    return __builtin_fmaf(c, c, __builtin_fmaf(a, a, yy));
+}
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
 {
-    const float dx = ax - bx, dy = ay - by, dz = az - bz;
-    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-    const float s = xx + yy;
-    return s + zz;
+    return sqsum3(ax - bx, ay - by, az - bz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -78,13 +82,15 @@ extern "C" int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int
 // farthest point sampling (pointnet2.py:384).  One 256-thread workgroup per cloud; the cloud and
 // the running min-distance live in registers (PPT points per thread, point k = tid + 256*i), a
 // copy of xyz in LDS serves the "last selected point" broadcast.  Arg-max key = 64-bit
-// (f32 bits of the distance + 1) << 32 | ~((k mod bs) << 16 | k): max over keys reproduces the
-// oracle's total order (value desc, k mod bs asc, k asc); 0 is the identity (best=-1, besti=0).
+// (f32 bits of the distance + 1) << 32 | ~(bitrev(k mod bs) << 16 | k): max over keys reproduces the
+// upstream block reduction's total order (value desc, bit-reversed k mod bs asc -- the shared-memory
+// tree keeps the lower slot on equality, its last level deciding on bit 0 --, k asc); 0 is the identity
+// (best=-1, besti=0).
 // Wave reduction by DPP row steps + v_readlane (wave_max_u64), 4 wave results through a double-buffered LDS slot:
 // one barrier per round.
 // ---------------------------------------------------------------------------------------------
 template <int PPT>
-__global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz, int n, int M, int bs,
+__global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz, int n, int M, int bs_bits,
                                                   int guard, int32_t *__restrict__ idx,
                                                   float *__restrict__ new_xyz)
 {
@@ -107,11 +113,11 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
         py[i] = in ? sx[k * 3 + 1] : 0.f;
         pz[i] = in ? sx[k * 3 + 2] : 0.f;
         tmp[i] = 1e10f;
-        const float xx = px[i] * px[i], yy = py[i] * py[i], zz = pz[i] * pz[i];
-        const float m0 = xx + yy;
-        const float mag = m0 + zz;
+        const float mag = sqsum3(px[i], py[i], pz[i]);
         ok[i] = in && !(guard && mag <= 1e-3f);
-        kkey[i] = ~((((unsigned)k & (unsigned)(bs - 1)) << 16) | (unsigned)k);
+        // bit reversal of (k mod bs) over bs_bits bits (bs_bits = 0: a one-thread block, no tie key)
+        const unsigned rev = bs_bits ? (__brev((unsigned)k) >> (32 - bs_bits)) : 0u;
+        kkey[i] = ~((rev << 16) | (unsigned)k);
     }
     int32_t *out = idx + (long)b * M;
     float *oxyz = new_xyz ? new_xyz + (long)b * M * 3 : nullptr;
@@ -168,10 +174,12 @@ extern "C" int caspr_fps_f32(const float *xyz, int B, int n, int M, int guard, i
     CASPR_REQUIRE(xyz && idx && B > 0 && n > 0 && M > 0, "fps: bad arguments");
     CASPR_REQUIRE(n <= 4096, "fps: n=%d > 4096 unsupported", n);
     const int bs = fps_block_size(n);
+    int bs_bits = 0;
+    while ((1 << bs_bits) < bs) ++bs_bits;
     const size_t sh = (size_t)((n * 3 + 3) & ~3) * 4 + 64;
     hipStream_t st = (hipStream_t)stream;
     const int ppt = ceil_div(n, 256);
-#define FPS_LAUNCH(P) fps_kernel<P><<<dim3(B), dim3(256), sh, st>>>(xyz, n, M, bs, guard, idx, new_xyz)
+#define FPS_LAUNCH(P) fps_kernel<P><<<dim3(B), dim3(256), sh, st>>>(xyz, n, M, bs_bits, guard, idx, new_xyz)
     if (ppt <= 1) FPS_LAUNCH(1);
     else if (ppt <= 2) FPS_LAUNCH(2);
     else if (ppt <= 4) FPS_LAUNCH(4);

@@ -11,21 +11,47 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *
- * All float arithmetic is single precision, evaluated left-to-right exactly as written,
- * with no fused multiply-add (compile with -ffp-contract=off).
+ * All float arithmetic is single precision.  Compile with -ffp-contract=off: the ONLY fused
+ * multiply-adds are the explicit fmaf() calls of sqdist3()/sqmag3(), which restate what nvcc's default
+ * -fmad=true makes of the upstream expression  a*a + b*b + c*c  (Pointnet2_PyTorch sampling_gpu.cu /
+ * ball_query_gpu.cu / interpolate_gpu.cu, chrdiller chamfer): the NVPTX FADD combine fuses the LEFT
+ * product of (a*a + b*b) first and then the remaining product of the outer sum, i.e. the PTX is
+ *     mul.f32 t, b, b ;  fma.rn.f32 t, a, a, t ;  fma.rn.f32 t, c, c, t
+ * (recalled from the public sources and LLVM's NVPTX backend -- unverifiable offline like the rest of
+ * this file; -DORACLE_NO_FMA restores the uncontracted form).  Everything else is evaluated left to
+ * right exactly as written.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-static inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
+/* a*a + b*b + c*c as the upstream binaries evaluate it (see the header) */
+static inline float sqsum3(float a, float b, float c)
 {
-    /* ((dx*dx) + (dy*dy)) + (dz*dz), every op rounded to f32 */
-    volatile float dx = ax - bx, dy = ay - by, dz = az - bz;
-    volatile float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+#ifdef ORACLE_NO_FMA
+    volatile float xx = a * a, yy = b * b, zz = c * c;
     volatile float s = xx + yy;
     return s + zz;
+#else
+    volatile float yy = b * b;
+    volatile float s = fmaf(a, a, yy);
+    return fmaf(c, c, s);
+#endif
+}
+
+static inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    volatile float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sqsum3(dx, dy, dz);
+}
+
+/* bit reversal of t over `bits` bits */
+static inline unsigned bitrev(unsigned t, int bits)
+{
+    unsigned r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((t >> i) & 1u) << (bits - 1 - i);
+    return r;
 }
 
 static int fps_block_size(int n)
@@ -40,14 +66,20 @@ static int fps_block_size(int n)
  * Farthest point sampling (call site pointnet2.py:384).
  *   xyz (B,n,3) f32 -> idx (B,M) int32.  temp[] starts at 1e10, first index 0.
  *   Points with x*x+y*y+z*z <= 1e-3 are skipped when guard != 0 (upstream "padding guard").
- *   Arg-max tie rule = upstream block reduction: among equal maxima the winner has the
- *   smallest (k mod blockDim), then the smallest k; blockDim = fps_block_size(n).
+ *   Arg-max tie rule = the upstream block reduction (sampling_gpu.cu): thread tid = k mod blockDim
+ *   keeps the FIRST k of its stride (strict '>'), then a shared-memory tree runs
+ *   __update(tid, tid+s) for s = blockDim/2 ... 1, keeping the LOWER slot on equality.  The last
+ *   level (s = 1) decides on bit 0 of tid, the one before on bit 1, ...: among equal maxima the
+ *   winner has the smallest BIT-REVERSED tid (over log2(blockDim) bits), then the smallest k;
+ *   blockDim = fps_block_size(n).  (tid 130 beats tid 3 at blockDim 512.)
  *   A thread that saw no admissible point contributes (best=-1, besti=0).
  */
 void oracle_fps(const float *xyz, int B, int n, int M, int guard, int32_t *idx)
 {
     float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     const int bs = fps_block_size(n);
+    int bits = 0;
+    while ((1 << bits) < bs) ++bits;
     for (int b = 0; b < B; ++b) {
         const float *p = xyz + (size_t)b * n * 3;
         int32_t *out = idx + (size_t)b * M;
@@ -59,21 +91,19 @@ void oracle_fps(const float *xyz, int B, int n, int M, int guard, int32_t *idx)
             const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
             float best = -1.0f;
             int besti = 0;
-            int best_tid = 0;
+            unsigned best_tid = 0;   /* bit-reversed thread id of the current winner */
             for (int k = 0; k < n; ++k) {
                 const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
                 if (guard) {
-                    volatile float xx = x2 * x2, yy = y2 * y2, zz = z2 * z2;
-                    volatile float m0 = xx + yy;
-                    const float mag = m0 + zz;
+                    const float mag = sqsum3(x2, y2, z2);
                     if (mag <= 1e-3f) continue;
                 }
                 const float d = sqdist3(x2, y2, z2, x1, y1, z1);
                 const float d2 = d < temp[k] ? d : temp[k];
                 temp[k] = d2;
-                const int tid = k % bs;
-                /* total order: value desc, tid asc, k asc.  (best=-1,besti=0,tid=0) is the
-                 * identity contributed by an empty thread 0. */
+                const unsigned tid = bitrev((unsigned)(k % bs), bits);
+                /* total order: value desc, bit-reversed tid asc, k asc.  (best=-1,besti=0,tid=0) is
+                 * the identity contributed by an empty thread 0. */
                 if (d2 > best || (d2 == best && (tid < best_tid || (tid == best_tid && k < besti)))) {
                     best = d2;
                     besti = k;

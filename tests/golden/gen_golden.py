@@ -194,6 +194,12 @@ def main():
     g["ops_ball_idx"] = P.ball_query(0.1, 16, cloud, new_xyz).numpy()
     d, i3 = P.three_nn(cloud, new_xyz)
     g["ops_three_nn_idx"], g["ops_three_nn_dist"] = i3.numpy(), d.numpy()
+    # exact ties as dataset padding makes them (caspr_dataset.py:188-195 appends copies of leading points): duplicates at an
+    # offset that is not a multiple of the 512-thread block, so the winner among equal maxima is decided by the upstream
+    # tree reduction's order (bit-reversed k mod 512), not by the smallest k
+    dup = cloud.clone()
+    dup[:, 700:1024] = dup[:, 37:361]
+    g["ops_fps_idx_dup"] = P.furthest_point_sampling(dup, 1024).numpy()       # M = n: every duplicate pair ends in a tie
 
     odef.before_odeint = orig   # back to the reference's own noise handling (randn_like per solve)
     # ---- 4. real data: data/demo through the reference's own loader and model (BASELINE.json configs[0]) ----

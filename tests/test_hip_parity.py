@@ -111,6 +111,22 @@ def test_fps_guard_and_origin(ops, dev):
         exact("fps_guard%d" % guard, ops.furthest_point_sampling(c.to(dev), 64, guard=guard), P.furthest_point_sampling(c, 64, guard=guard))
 
 
+def test_fps_tie_order_tree_reduction(ops, dev, golden):
+    """Exact ties: duplicates at an offset that is not a multiple of the 512-thread block (dataset padding,
+    caspr_dataset.py:188-195) and grid clouds where every round ties.  The winner follows the upstream shared-memory
+    tree (bit-reversed k mod blockDim, then k) -- fixture produced by oracle/point_ops.c, itself checked against a
+    literal restatement of the block algorithm in tests/test_oracle_golden.py."""
+    x, _ = car_sequences(1, 2, 1024, seed=1234)
+    dup = x.reshape(2, 1024, 4)[:, :, :3].contiguous()
+    dup[:, 700:1024] = dup[:, 37:361].clone()
+    got = ops.furthest_point_sampling(dup.to(dev), 1024)
+    exact("fps_dup_offset700_vs_golden", got, torch.from_numpy(golden["ops_fps_idx_dup"]))
+    for n, M in [(8, 8), (23, 23), (100, 100), (700, 300), (2048, 600), (4096, 512)]:
+        rng = np.random.default_rng(n)
+        pts = torch.from_numpy((rng.integers(0, 6, (2, n, 3)) / 4.0 + np.array([1.0, 0.5, 2.0])).astype(np.float32))
+        exact("fps_grid_ties_n%d" % n, ops.furthest_point_sampling(pts.to(dev), M), P.furthest_point_sampling(pts, M))
+
+
 @pytest.mark.parametrize("n,M,r,ns", [(2048, 1024, 0.02, 16), (2048, 1024, 0.05, 32), (1024, 512, 0.1, 32), (256, 64, 0.4, 32),
                                      (64, 16, 0.8, 32), (64, 16, 0.4, 16), (300, 50, 0.2, 16)])
 def test_ball_query_bit_exact(ops, dev, n, M, r, ns):

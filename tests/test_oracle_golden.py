@@ -117,11 +117,59 @@ def test_point_ops_regression(golden):
     d, i3 = P.three_nn(cloud, new_xyz)
     assert np.array_equal(i3.numpy(), golden["ops_three_nn_idx"])
     assert np.array_equal(d.numpy(), golden["ops_three_nn_dist"])
+    dup = cloud.clone()
+    dup[:, 700:1024] = dup[:, 37:361]      # exact ties at an offset that is not a multiple of the block size
+    assert np.array_equal(P.furthest_point_sampling(dup, 1024).numpy(), golden["ops_fps_idx_dup"])
+
+
+def _fps_block_literal(pts, M):
+    """The upstream block algorithm restated LITERALLY (Pointnet2_PyTorch sampling_gpu.cu, what Kaolin v0.1 adapts):
+    block_size threads with a strided scan and a strict '>' each, then the shared-memory tree
+    __update(tid, tid + s) for s = block_size/2 ... 1 that keeps the lower slot unless the upper value is strictly
+    larger.  Coordinates are dyadic rationals here, so every f32 operation is exact and fused / unfused arithmetic agree."""
+    n = pts.shape[0]
+    bs = 1
+    while bs * 2 <= n and bs * 2 <= 512:
+        bs *= 2
+    temp = np.full(n, 1e10, np.float32)
+    out, old = [0], 0
+    for _ in range(1, M):
+        dists, dists_i = np.full(bs, -1.0, np.float32), np.zeros(bs, np.int64)
+        for tid in range(bs):
+            best, besti = np.float32(-1.0), 0
+            for k in range(tid, n, bs):
+                if np.float32((pts[k] * pts[k]).sum()) <= np.float32(1e-3):
+                    continue
+                d = np.float32(((pts[k] - pts[old]) ** 2).sum())
+                d2 = min(d, temp[k])
+                temp[k] = d2
+                if d2 > best:
+                    best, besti = d2, k
+            dists[tid], dists_i[tid] = best, besti
+        s_ = bs // 2
+        while s_ >= 1:
+            for tid in range(s_):
+                if dists[tid + s_] > dists[tid]:
+                    dists[tid], dists_i[tid] = dists[tid + s_], dists_i[tid + s_]
+            s_ //= 2
+        old = int(dists_i[0])
+        out.append(old)
+    return out
+
+
+@pytest.mark.parametrize("n,M", [(8, 8), (23, 23), (64, 40), (100, 100), (700, 48)])
+def test_fps_tie_order_is_the_upstream_tree_reduction(n, M):
+    """Grid clouds with many duplicates and equidistant points: every round is a tie, decided by the bit-reversed thread id."""
+    rng = np.random.default_rng(n)
+    pts = (rng.integers(0, 4, (n, 3)) / 4.0 + np.array([1.0, 0.5, 2.0])).astype(np.float32)
+    want = _fps_block_literal(pts, M)
+    got = P.furthest_point_sampling(torch.from_numpy(pts).unsqueeze(0), M)[0].tolist()
+    assert got == want
 
 
 def test_point_ops_semantics():
     """Hand-checkable cases of the operator contracts."""
-    # FPS: start at 0, farthest next; duplicates -> tie broken by (k mod bs, k); M > n repeats index 0
+    # FPS: start at 0, farthest next; duplicates -> tie broken by (bit-reversed k mod bs, k); M > n repeats index 0
     pts = torch.tensor([[[1.0, 1, 1], [3.0, 1, 1], [2.0, 1, 1], [3.0, 1, 1]]])
     assert P.furthest_point_sampling(pts, 3).tolist() == [[0, 1, 2]]
     assert P.furthest_point_sampling(pts, 6).tolist()[0][:3] == [0, 1, 2]
@@ -129,7 +177,9 @@ def test_point_ops_semantics():
     # padding guard: points with |p|^2 <= 1e-3 are never selected (and never update temp)
     pts = torch.tensor([[[1.0, 0, 0], [0.0, 0, 0], [2.0, 0, 0], [-5.0, 0.0, 0.0]]])
     assert P.furthest_point_sampling(pts, 3).tolist() == [[0, 3, 2]]
-    assert P.furthest_point_sampling(pts, 3, guard=False).tolist() == [[0, 3, 1]]   # tie (d=1): lower k mod bs wins
+    # tie (d=1) between k=1 and k=2 at block size 4: the tree's last level compares slots 0|1 after slot 0 took slot 2
+    # -> the even thread (k=2, bit-reversed id 1) beats k=1 (bit-reversed id 2)
+    assert P.furthest_point_sampling(pts, 3, guard=False).tolist() == [[0, 3, 2]]
     # ball query: first hit pads, strict <, ascending index order, at most ns
     xyz = torch.tensor([[[0.0, 0, 0], [0.05, 0, 0], [0.2, 0, 0], [0.09, 0, 0], [0.1, 0, 0]]])
     ctr = torch.tensor([[[0.0, 0, 0], [0.2, 0, 0]]])
