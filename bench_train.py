@@ -49,9 +49,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU: a plain `python bench_train.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1);
+    # under an external launcher WORLD_SIZE must equal --gpus
+    from caspr_amd.utils.launch import ensure_ranks
+    rank, local_rank, world = ensure_ranks(args.gpus, __file__, sys.argv[1:], device_count=torch.cuda.device_count)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -51,7 +51,7 @@ class CaSPR(nn.Module):
     def forward(self, x, sample_points, aggregate_points=None, e=None):
         """caspr.py:76-122.  x, sample_points (B,T,N,4) -> (recon_loss (B,T,N), tnocs_loss (B,T,N,4)).
         `e` (B*T,N,3) optionally fixes the Hutchinson noise (odefunc.py:115-117)."""
-        if self.training and torch.is_grad_enabled():
+        if self._differentiable(x, sample_points):
             return self._forward_train(x, sample_points, e)
         with torch.no_grad():
             z0, tnocs_pred = self.encode(x)
@@ -72,6 +72,14 @@ class CaSPR(nn.Module):
             cnf_result = self.point_cnf(pts, z, init_logprob, e=e)
             recon_loss = self.get_nll_loss(cnf_result, B, T)
             return tuple([recon_loss, tnocs_loss])
+
+    def _differentiable(self, *inputs):
+        """The reference's forward is differentiable whenever autograd records (train() or eval() alike; its callers wrap
+        evaluation in torch.no_grad(), train.py:152, test.py:124,141).  Same rule here: the taped path runs iff grad mode
+        is on and a parameter or an input asks for a gradient; under no_grad the inference kernels run."""
+        if not torch.is_grad_enabled():
+            return False
+        return any(t.requires_grad for t in inputs if torch.is_tensor(t)) or any(p.requires_grad for p in self.parameters())
 
     def _forward_train(self, x, sample_points, e=None):
         """Differentiable forward (train_utils.py:125 calls it under model.train()): the encoder is one autograd node with
@@ -113,7 +121,7 @@ class CaSPR(nn.Module):
         B, T = time_tensor.size()
         z_init = z0[:, :self.latent_ode.input_size]
         z_global = z0[:, self.latent_ode.input_size:]
-        if z0.is_cuda and not (self.training and torch.is_grad_enabled()):
+        if z0.is_cuda and not self._differentiable(z0, time_tensor):
             sample_feats = self.latent_ode.solve_at(z_init, time_tensor)
         else:
             solve_t, time_map = torch.unique(time_tensor, sorted=True, return_inverse=True)

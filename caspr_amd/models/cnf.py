@@ -97,7 +97,7 @@ class CNF(nn.Module):
         """Reference signature (cnf.py:70).  integration_times must be None (the learned end time is used)."""
         if integration_times is not None:
             raise ValueError("custom integration_times are not supported by the fused RK4 kernel")
-        self.odefunc.before_odeint(self.odefunc._e)
+        self.odefunc.before_odeint()        # cnf.py:100: clears the Hutchinson noise -> a fresh draw per solve (odefunc.py:127-128)
         return self.integrate(x, context, logpx, reverse)
 
     def num_evals(self):

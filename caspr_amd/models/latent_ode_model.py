@@ -48,7 +48,7 @@ class LatentODE(nn.Module):
         self.ode_func._num_evals.fill_(0)
         if z0.shape[1] != self.input_size:
             raise ValueError("expected %d latent dims, got %d" % (self.input_size, z0.shape[1]))
-        if self.training and torch.is_grad_enabled() and (z0.requires_grad or any(p.requires_grad for p in self.ode_func.parameters())):
+        if torch.is_grad_enabled() and (z0.requires_grad or any(p.requires_grad for p in self.ode_func.parameters())):
             from ..train.flow_grad import latent_solve_train                                    # differentiable RK4 (training)
             return latent_solve_train(self, z0, t)
         # z0 may be the view z[:, :H] of the (B,1600) encoder output: the kernel takes its row stride

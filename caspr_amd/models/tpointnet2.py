@@ -132,8 +132,8 @@ class TPointNet2(nn.Module):
         pre: optional index handle from launch_indices (inference only)."""
         if not x.is_cuda:
             raise ValueError("caspr_amd.TPointNet2 runs on the GPU only (HIP kernels); got a %s tensor" % x.device)
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training: one autograd node with a taped forward and a HIP backward (train/encoder_grad.py)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # autograd is recording (train() or eval() alike, as in the reference): one autograd node with a taped forward and a HIP backward (train/encoder_grad.py)
             from ..train.encoder_grad import encode_with_grad
             return encode_with_grad(self, x)
         B, T, N, _ = x.size()

@@ -45,6 +45,14 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_current_device(t):
+    """The C entries launch on the CURRENT device's stream and never call hipSetDevice (include/caspr_hip.h): a tensor of
+    another GPU would be dereferenced by the wrong device.  One process per GPU sets its device once (bench.py)."""
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise ValueError("tensor lives on %s but the current device is cuda:%d: wrap the call in torch.cuda.device(t.device)"
+                         % (t.device, torch.cuda.current_device()))
+
+
 def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -55,6 +63,7 @@ def _chk_f32(*ts):
             continue
         if not t.is_cuda:
             raise ValueError("caspr_amd kernels need tensors on the GPU (got %s): there is no CPU fallback" % t.device)
+        _on_current_device(t)
         if t.dtype != torch.float32:
             raise TypeError("expected float32, got %s" % t.dtype)
         if not t.is_contiguous():
@@ -67,6 +76,7 @@ def _chk_rows(t):
         return 0
     if not t.is_cuda:
         raise ValueError("caspr_amd kernels need tensors on the GPU (got %s): there is no CPU fallback" % t.device)
+    _on_current_device(t)
     if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
         raise ValueError("expected a float32 (B,P,C) tensor with unit channel stride and packed rows")
     if t.stride(1) % 4 != 0 or t.data_ptr() % 16 != 0:
@@ -325,6 +335,17 @@ def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reve
     w1x / w2x (pack_cnf_x6): when given and no divergence is integrated, the bf16x6 kernel runs the solve."""
     _chk_f32(y, hyper, tcol, w0, b0, b1, b2, w3, b3, mbn_in, mbn_out, e, logp)
     BT, n, _ = y.shape
+    if y.dim() != 3 or y.shape[2] != 3:
+        raise ValueError("cnf_rk4: y must be (BT,n,3), got %s" % (tuple(y.shape),))
+    if hyper.dim() != 2 or hyper.shape[0] != BT:
+        raise ValueError("cnf_rk4: hyper has %s rows for %d frames" % (tuple(hyper.shape), BT))
+    if (e is None) != (logp is None):
+        raise ValueError("cnf_rk4: the Hutchinson noise e and the initial log-density come together")
+    if e is not None and (tuple(e.shape) != tuple(y.shape) or tuple(logp.shape) != (BT, n, 1)):
+        raise ValueError("cnf_rk4: e %s / logp %s do not match y %s" % (tuple(e.shape), tuple(logp.shape), tuple(y.shape)))
+    for name, m_ in (("mbn_in", mbn_in), ("mbn_out", mbn_out)):
+        if m_ is not None and m_.numel() != 12:
+            raise ValueError("cnf_rk4: %s must hold 12 floats [weight | bias | running_mean | running_var]" % name)
     out = torch.empty_like(y)
     if e is None and w1x is not None and w2x is not None:
         with timed("cnf_rk4"):

@@ -6,8 +6,11 @@ mean(L1 tnocs) (train_utils.py:151-165), Adam, periodic checkpoints `time_model_
 
 Multi-GPU: instead of nn.DataParallel (one process, scatter/gather, train.py:131-132) each rank owns a
 contiguous block of the batch's sequences; the only collective is ONE all-reduce (RCCL over xGMI on the GPU box) of a
-flat bucket holding every gradient, after which each rank applies the same Adam step.  With equal shard sizes the
-averaged per-rank means equal the reference's mean over the global batch.  MovingBatchNorm running statistics are
+flat bucket holding every gradient, after which each rank applies the same Adam step.  The bucket carries each rank's
+gradient of its LOCAL mean weighted by its shard size (plus the shard size itself in one extra slot), so the reduced
+gradient is the gradient of the reference's mean over the GLOBAL batch (train_utils.py:154,163) for any split --
+including a rank whose shard is empty (a last batch shorter than the world size): it contributes zeros, still enters
+the collective and applies the same step, so replicas never diverge or deadlock.  MovingBatchNorm running statistics are
 rank-local (the reference's DataParallel keeps replica 0's); rank 0's are the ones checkpointed.
 """
 import math
@@ -52,7 +55,7 @@ class GradBucket:
     def pack(self):
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(sum(self.sizes), device=dev, dtype=torch.float32)
+            self.flat = torch.zeros(sum(self.sizes) + 1, device=dev, dtype=torch.float32)   # last slot: this rank's weight
         off = 0
         for p, n in zip(self.params, self.sizes):
             if p.grad is None:
@@ -72,13 +75,20 @@ class GradBucket:
                 p.grad.copy_(g)
             off += n
 
-    def all_reduce_mean(self):
-        """Average the gradients over the ranks (no-op without an initialised process group)."""
+    def all_reduce_mean(self, weight=1.0):
+        """Weighted average of the gradients over the ranks: sum_r weight_r * grad_r / sum_r weight_r, with weight = the
+        number of sequences behind this rank's (mean-reduced) loss; weight 0 = a rank without data (its gradients are
+        taken as zero whatever .grad holds).  ONE collective.  No-op without an initialised process group."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         flat = self.pack()
+        if weight == 0:
+            flat.zero_()
+        else:
+            flat[:-1].mul_(float(weight))
+            flat[-1] = float(weight)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(dist.get_world_size())
+        flat[:-1].div_(flat[-1].clamp_min(1e-30))
         self.unpack()
 
 
@@ -87,11 +97,20 @@ def train_step(model, optimizer, pcl_in, nocs_out, cnf_loss_weight=0.01, tnocs_l
     (loss, cnf_loss, tnocs_loss) of the local shard."""
     model.train()
     optimizer.zero_grad()
+    n_local = int(pcl_in.shape[0])
+    if n_local == 0:
+        # no sequence of this batch landed on this rank: zero gradient, but the collective and the (identical) Adam step
+        # still happen -- skipping them would leave the other ranks blocked in the all-reduce and this replica behind
+        if bucket is None:
+            return float('nan'), float('nan'), float('nan')
+        bucket.all_reduce_mean(weight=0)
+        optimizer.step()
+        return float('nan'), float('nan'), float('nan')
     losses = model(pcl_in, nocs_out, e=e) if e is not None else model(pcl_in, nocs_out)
     loss, cnf_loss, tnocs_loss = training_loss(losses, cnf_loss_weight, tnocs_loss_weight)
     loss.backward()
     if bucket is not None:
-        bucket.all_reduce_mean()
+        bucket.all_reduce_mean(weight=n_local)
     optimizer.step()
     return float(loss.detach()), float(cnf_loss.detach()), float(tnocs_loss.detach())
 
@@ -112,22 +131,36 @@ def run_one_epoch(model, data_loader, device, optimizer, cnf_loss_weight, tnocs_
     list of per-batch losses (train) or the mean loss (val / test)."""
     if mode not in ['train', 'val', 'test']:
         raise ValueError('mode must be train, val or test')
-    out = []
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    out, wsum, nsum = [], 0.0, 0
     for i, data in enumerate(data_loader):
         pcl_in, nocs_out = data[0]
         pcl_in, nocs_out = shard_batch(pcl_in.to(device), nocs_out.to(device))
-        if pcl_in.shape[0] == 0:
-            continue
+        n_local = int(pcl_in.shape[0])
         if mode == 'train':
+            if n_local == 0 and not distributed:
+                continue
             loss, cnf_l, tnocs_l = train_step(model, optimizer, pcl_in, nocs_out, cnf_loss_weight, tnocs_loss_weight, bucket)
         else:
+            if n_local == 0:
+                continue            # evaluation has no collective inside the loop: the reduction happens once, below
             model.eval()
             with torch.no_grad():
                 loss, cnf_l, tnocs_l = (float(v) for v in training_loss(model(pcl_in, nocs_out), cnf_loss_weight, tnocs_loss_weight))
-        out.append(loss)
-        if i % print_stats_every == 0:
-            log('%s epoch %d batch %d/%d: loss %.6f (cnf %.6f, tnocs %.6f)' % (mode, epoch, i, len(data_loader), loss, cnf_l, tnocs_l))
-    return out if mode == 'train' else (float(np.mean(out)) if out else float('nan'))
+            wsum, nsum = wsum + loss * n_local, nsum + n_local
+        if n_local:
+            out.append(loss)
+            if i % print_stats_every == 0:
+                log('%s epoch %d batch %d/%d: loss %.6f (cnf %.6f, tnocs %.6f)' % (mode, epoch, i, len(data_loader), loss, cnf_l, tnocs_l))
+    if mode == 'train':
+        return out
+    if distributed:
+        # validation loss = mean over every sequence of every rank (BEST-checkpoint decisions must agree across ranks)
+        acc = torch.tensor([wsum, float(nsum)], dtype=torch.float64, device=device)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        wsum, nsum = float(acc[0]), int(acc[1])
+        return wsum / nsum if nsum else float('nan')
+    return float(np.mean(out)) if out else float('nan')
 
 
 def train(model, train_loader, val_loader, device, out_dir, num_epochs, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,

@@ -496,12 +496,14 @@ def test_forward_nll(dev, seeded_sd, sd64, model, golden):
     x, sp = dense_sequences(1, 2, 1024)
     e = rnd(23, 2, 1024, 3)
     wr, wt = O.forward_nll(seeded_sd, x, sp, e)
-    recon, tl = model(x.to(dev), sp.to(dev), e=e.to(dev))
+    with torch.no_grad():            # evaluation as the reference's callers run it (test.py:124,141)
+        recon, tl = model(x.to(dev), sp.to(dev), e=e.to(dev))
     record("dense_fwd_tnocs_loss", tl, wt, 2e-5)
     record("dense_fwd_recon_loss", recon, wr, 2e-4)      # NLL ~ 1e1, accumulates ~1e3 f32 ops per point
     x, sp = car_sequences(1, 2, 1024, seed=1234)
     r64, t64 = O.forward_nll(sd64, x.double(), sp.double(), e.double())
-    recon, tl = model(x.to(dev), sp.to(dev), e=e.to(dev))
+    with torch.no_grad():
+        recon, tl = model(x.to(dev), sp.to(dev), e=e.to(dev))
     record_cond("fwd_tnocs_loss_vs_reference_golden", tl, golden["fwd_tnocs_loss"], t64, 1e-5, factor=5.0)
     record_cond("fwd_recon_loss_vs_reference_golden", recon, golden["fwd_recon_loss"], r64, 2e-4, factor=5.0)
 
@@ -633,7 +635,8 @@ def test_decode_options_and_variants(dev, seeded_sd, model, tmp_path):
     pm = CaSPR(pretrain_tnocs=True)
     load_weights(pm, {k: v for k, v in seeded_sd.items() if k.startswith("encoder.")})
     pm = pm.to(dev).eval()
-    (tl,) = pm(xd, sp.to(dev))
+    with torch.no_grad():
+        (tl,) = pm(xd, sp.to(dev))
     _, wt = O.encode(seeded_sd, x)
     record("pretrain_tnocs_loss", tl, (wt - sp).abs(), 2e-5)
     # two stacked CNF blocks (flow.py:68-72): chain [MBN, CNF, CNF, MBN]; checkpoint round trip through torch.save

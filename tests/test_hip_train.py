@@ -584,3 +584,46 @@ def test_full_model_gradients_are_bit_reproducible(seeded_sd, golden):
     a, b = grads(), grads()
     bad = [n for (n, _), u, v in zip(m.named_parameters(), a, b) if not torch.equal(u, v)]
     assert not bad, "gradients differ between two identical passes: %s" % bad[:5]
+
+
+def test_eval_mode_forward_is_differentiable_and_cnf_forward_draws_fresh_noise(seeded_sd, golden):
+    """The reference's forward stays differentiable in eval() (its callers add torch.no_grad() themselves): same loss values
+    as under no_grad, a graph when grad mode is on, no MovingBatchNorm statistics update.  CNF.forward (cnf.py:100) clears
+    the Hutchinson noise of the previous solve instead of re-installing it; ops.cnf_rk4 rejects mismatched e / logp."""
+    from caspr_amd import ops
+    from caspr_amd.models import CaSPR
+    dev = "cuda:0"
+    m = CaSPR(cnf_rk4_steps=2, latent_rk4_steps=1)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    x, sp = torch.from_numpy(golden["train_x"]).to(dev)[:, :, :256].contiguous(), torch.from_numpy(golden["train_sp"]).to(dev)[:, :, :256].contiguous()
+    e = torch.from_numpy(golden["train_e"]).to(dev)[:, :256].contiguous()
+    rm0 = m.point_cnf.chain[0].running_mean.clone()
+    with torch.no_grad():
+        nll0, tl0 = m(x, sp, e=e)
+    assert not nll0.requires_grad
+    nll, tl = m(x, sp, e=e)
+    assert nll.requires_grad and tl.requires_grad
+    rel("evalgrad_nll", nll, nll0, 2e-5)
+    rel("evalgrad_tnocs", tl, tl0, 2e-5)
+    (0.01 * nll.sum(2).mean() + 100.0 * tl[:, :, :, :4].mean()).backward()
+    g = m.encoder.conv3.weight.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    assert m.point_cnf.chain[1].sqrt_end_time.grad is not None
+    assert torch.equal(m.point_cnf.chain[0].running_mean, rm0)          # eval(): frozen statistics
+    # CNF.forward: the noise of the previous solve must not be reused (and a larger x must not read past it)
+    cnf = m.point_cnf.chain[1]
+    ctx = torch.randn(2, m.cnf_args.zdim, device=dev)
+    with torch.no_grad():
+        cnf.odefunc.before_odeint(torch.randn(2, 8, 3, device=dev))
+        xb = torch.randn(2, 64, 3, device=dev)
+        y1, lp1 = cnf(xb, ctx, torch.zeros(2, 64, 1, device=dev))
+        e1 = cnf.odefunc._e
+        assert tuple(e1.shape) == (2, 64, 3)
+        y2, lp2 = cnf(xb, ctx, torch.zeros(2, 64, 1, device=dev))
+        assert not torch.equal(cnf.odefunc._e, e1) and torch.equal(y1, y2) and not torch.equal(lp1, lp2)
+        w = cnf._weights()
+        hyper = ops.conv1x1(w["hyp"], w["hyp_bias"], ctx.view(1, 2, -1))[0]
+        with pytest.raises(ValueError):
+            ops.cnf_rk4(xb, hyper, w["tcol"], w["w0"], w["b0"], w["w1p"], w["b1"], w["w2p"], w["b2"], w["w3"], w["b3"], 0.5, 2, False,
+                        e=torch.randn(2, 8, 3, device=dev), logp=torch.zeros(2, 64, 1, device=dev))

@@ -148,10 +148,27 @@ assert xs.shape[0] == B // world
 loss, _, _ = training_loss(m(xs, ys), 0.01, 100.0)
 loss.backward()
 bucket = GradBucket(m.parameters())
-bucket.all_reduce_mean()
+bucket.all_reduce_mean(weight=xs.shape[0])
 for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
     want = q.grad if q.grad is not None else torch.zeros_like(q)
     assert p.grad is not None and torch.allclose(p.grad, want, atol=1e-6, rtol=1e-5), "gradient of %s differs after the all-reduce" % n
+
+# unequal shards (3 sequences -> 2 + 1) and an EMPTY shard (1 sequence -> 1 + 0): train_step on every rank must neither
+# deadlock nor diverge, and must apply the single-process step on the global-batch mean (train_utils.py:154,163)
+from caspr_amd.train.loop import train_step
+for Bg in (3, 1):
+    one = Tiny(); one.load_state_dict(ref.state_dict())
+    opt1 = torch.optim.Adam(one.parameters(), lr=1e-2)
+    opt1.zero_grad()
+    l1, _, _ = training_loss(one(x[:Bg], y[:Bg]), 0.01, 100.0)
+    l1.backward()
+    opt1.step()
+    mm = Tiny(); mm.load_state_dict(ref.state_dict())
+    optm = torch.optim.Adam(mm.parameters(), lr=1e-2)
+    xs, ys = shard_batch(x[:Bg], y[:Bg])
+    train_step(mm, optm, xs, ys, 0.01, 100.0, bucket=GradBucket(mm.parameters()))
+    for (n, p), (_, q) in zip(mm.named_parameters(), one.named_parameters()):
+        assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), "B=%d rank %d: parameter %s differs from the single-process step" % (Bg, rank, n)
 dist.barrier()
 if rank == 0:
     print("GRAD_OK")
@@ -167,6 +184,46 @@ def test_two_rank_gradient_bucket_gloo(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29534", str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "GRAD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+LAUNCH_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from caspr_amd.utils.launch import ensure_ranks
+from caspr_amd.utils.sharding import max_over_ranks, sum_over_ranks
+n = int(sys.argv[2])
+rank, local_rank, world = ensure_ranks(n, __file__, sys.argv[1:])      # returns only inside the ranks
+assert world == n and "MASTER_PORT" in os.environ
+dist.init_process_group("gloo")
+assert dist.get_world_size() == n and dist.get_rank() == rank
+assert sum_over_ranks(1, torch.device("cpu")) == n and max_over_ranks(rank, torch.device("cpu")) == n - 1
+dist.barrier()
+if rank == 0:
+    print("LAUNCH_OK world=%d" % world)
+dist.destroy_process_group()
+'''
+
+
+def test_plain_invocation_starts_its_own_ranks(tmp_path, monkeypatch):
+    """`python script.py --gpus N` with WORLD_SIZE unset must become N ranks (bench.py / bench_train.py use the same helper);
+    a launcher whose WORLD_SIZE disagrees with --gpus is refused, and so is asking for more ranks than devices."""
+    from caspr_amd.utils.launch import ensure_ranks
+    script = tmp_path / "launch_worker.py"
+    script.write_text(LAUNCH_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(script), ROOT, "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "LAUNCH_OK world=2" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert ensure_ranks(1, "x.py", []) == (0, 0, 1)
+    with pytest.raises(RuntimeError):
+        ensure_ranks(8, "x.py", [], device_count=lambda: 1)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(RuntimeError):
+        ensure_ranks(8, "x.py", [])
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert ensure_ranks(4, "x.py", []) == (3, 3, 4)
 
 
 def test_training_loss_weights():
