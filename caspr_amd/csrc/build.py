@@ -9,7 +9,10 @@ SOURCES = ["point_ops.hip", "gemm.hip", "gemm_bf16x6.hip", "sa_mlp.hip", "ode.hi
 EXTRA = {"point_ops.hip": ["-ffp-contract=off"], "emd.hip": ["-ffp-contract=off"],
          # the 64-piece product loop of the bf16x6 CNF kernel must unroll completely (static register indices)
          "ode_bf16x6.hip": ["-mllvm", "-pragma-unroll-threshold=400000"]}
-OUT = os.path.join(HERE, "libcaspr_hip.so")
+# CASPR_BUILD_DEBUG=1: the flavour with phase-trace hooks and experiment switches (-DCASPR_DEBUG_HOOKS, see common.h), built
+# next to the production library as libcaspr_hip_debug.so with its own objects; tools/*_phase_trace.py load it.
+DEBUG = os.environ.get("CASPR_BUILD_DEBUG", "0") not in ("0", "")
+OUT = os.path.join(HERE, "libcaspr_hip_debug.so" if DEBUG else "libcaspr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -27,10 +30,10 @@ def build(force=False, verbose=False):
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(HERE, s)
-        obj = os.path.join(HERE, s.replace(".hip", ".o"))
+        obj = os.path.join(HERE, s.replace(".hip", ".dbg.o" if DEBUG else ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + FLAGS + (["-DCASPR_DEBUG_HOOKS"] if DEBUG else []) + EXTRA.get(s, []) + ["-c", src, "-o", obj])
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "../../include/caspr_hip.h"
 
@@ -149,3 +152,35 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long x)
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launch hygiene (the C entries carry no state a result could depend on).
+//
+//  * Kernels that need more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute; that is a per-(kernel,
+//    device) setting, so it is done the first time a device launches the kernel, not on every launch.  The only thing
+//    remembered is the bit "this device has opted in" -- a cache of an idempotent driver call.
+//  * Phase traces (s_memtime stamps) and experiment switches read from the environment exist only in a build with
+//    -DCASPR_DEBUG_HOOKS (CASPR_BUILD_DEBUG=1 python caspr_amd/csrc/build.py -> libcaspr_hip_debug.so, used by tools/*_phase_trace.py);
+//    the production library exports no caspr_debug_* symbol, calls getenv nowhere and compiles the stamps out.
+// ---------------------------------------------------------------------------------------------
+struct CasprLdsOptIn {
+    std::atomic<unsigned long long> devices{0};
+};
+static inline hipError_t caspr_lds_opt_in(CasprLdsOptIn &st, const void *kernel, size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (st.devices.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) st.devices.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
+#ifdef CASPR_DEBUG_HOOKS
+#define CASPR_DEBUG_ENV_INT(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#define CASPR_IF_DEBUG(...) __VA_ARGS__
+#else
+#define CASPR_DEBUG_ENV_INT(name) 0
+#define CASPR_IF_DEBUG(...)
+#endif

@@ -216,7 +216,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         const int buf = it & 1;
         const bool more = it + 1 < ntiles;
         const int kt = tile_of(it), ktn = tile_of(more ? it + 1 : it);
+#ifdef CASPR_DEBUG_HOOKS
 #define GEMM_STAMP(i) if (trace && wmt == 3 && wpt == 5 && b == 0 && tid == 0 && it >= 8 && it < 12) trace[(it - 8) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define GEMM_STAMP(i)
+#endif
         GEMM_STAMP(0)
         if (more) load_stage(ktn);             // next tile's global loads stay in flight during this tile's MFMAs
         load_b(b0, buf, 0);
@@ -677,14 +681,19 @@ __global__ __launch_bounds__(256) void conv1x1_big_kernel(const float *__restric
     }
 }
 
-extern "C" int caspr_debug_gemm_occupancy(void)   // debug hook: resident conv1x1_kernel blocks per CU
+#ifdef CASPR_DEBUG_HOOKS
+extern "C" int caspr_debug_gemm_occupancy(void)   // debug build only: resident conv1x1_kernel blocks per CU
 {
     int n = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)conv1x1_kernel<64>, 256, 0);
     return n;
 }
 static unsigned long long *g_gemm_trace = nullptr;
-extern "C" void caspr_debug_set_gemm_trace(unsigned long long *dev_buf) { g_gemm_trace = dev_buf; }   // debug hook
+extern "C" void caspr_debug_set_gemm_trace(unsigned long long *dev_buf) { g_gemm_trace = dev_buf; }   // debug build only
+#define GEMM_TRACE_PTR g_gemm_trace
+#else
+#define GEMM_TRACE_PTR nullptr
+#endif
 
 extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float *bbias, const float *X, int ldx,
                                  const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
@@ -698,18 +707,15 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wp % 16) == 0, "conv1x1: pointers must be 16-byte aligned");
     CASPR_REQUIRE(B <= 65535, "conv1x1: B=%d > 65535", B);
     CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 4 == 0, "conv1x1: in_relu_from=%d must be a non-negative multiple of 4", in_relu_from);
-    static const int force = getenv("CASPR_GEMM_KERNEL") ? atoi(getenv("CASPR_GEMM_KERNEL")) : 0;   // 1 = 128-point tiles, 2 = big (experiments)
+    const int force = CASPR_DEBUG_ENV_INT("CASPR_GEMM_KERNEL");   // debug build only: 1 = 128-point tiles, 2 = big, 7 = streaming (experiments)
     const bool use_big = force == 2;   // measured slower than the 2-blocks-per-CU kernel on every shape of this model (profiles/r01_*)
     if (use_big) {
         const size_t shmem = 2 * 16 * BIG_NT * 4 * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void *)conv1x1_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            if (e != hipSuccess) {
-                caspr_set_error("conv1x1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-                return CASPR_ELAUNCH;
-            }
-            attr_done = true;
+        static CasprLdsOptIn optin;
+        const hipError_t e = caspr_lds_opt_in(optin, (const void *)conv1x1_big_kernel, shmem);
+        if (e != hipSuccess) {
+            caspr_set_error("conv1x1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return CASPR_ELAUNCH;
         }
         dim3 gridb(ceil_div(Cout, BIG_MT), ceil_div(P, BIG_NT), B);
         conv1x1_big_kernel<<<gridb, dim3(256), shmem, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
@@ -717,7 +723,7 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
         CASPR_CHECK_LAUNCH("conv1x1(big)");
         return CASPR_OK;
     }
-    static const size_t lds_pad = getenv("CASPR_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CASPR_GEMM_LDS_PAD")) * 1024 : 0;  // occupancy experiments
+    const size_t lds_pad = (size_t)CASPR_DEBUG_ENV_INT("CASPR_GEMM_LDS_PAD") * 1024;   // occupancy experiments, debug build only
     CASPR_REQUIRE(ceil_div(P, 128) <= 65535, "conv1x1: P=%d rows per batch entry exceed the grid (split the call)", P);
     // default: the streaming kernel wherever a wave's 32 points and the unrolled K loop are filled; the LDS-tiled kernel
     // for short rows-per-batch (coarse levels) and narrow inputs (set-abstraction MLPs).  CASPR_GEMM_KERNEL: 1 / 4 force
@@ -736,11 +742,11 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     if (force == 1 || ceil_div(P, 64) > 65535) {
         dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
         conv1x1_kernel<128><<<grid, dim3(256), lds_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
-                                                                               Y, ldy, P, Cin, Cout, act, g_gemm_trace);
+                                                                               Y, ldy, P, Cin, Cout, act, GEMM_TRACE_PTR);
     } else {
         dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 64), B);
         conv1x1_kernel<64><<<grid, dim3(256), lds_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
-                                                                              Y, ldy, P, Cin, Cout, act, g_gemm_trace);
+                                                                              Y, ldy, P, Cin, Cout, act, GEMM_TRACE_PTR);
     }
     CASPR_CHECK_LAUNCH("conv1x1");
     return CASPR_OK;

@@ -259,15 +259,12 @@ extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, cons
     const int Mt = ceil_div(Cout, X6_TM), Pt = P / X6_TP;
     const long nblk = (long)Mt * Pt * B;
     CASPR_REQUIRE(nblk < (1L << 31), "conv1x1_bf16x6: too many tiles (%ld)", nblk);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
-        hipError_t e2 = hipFuncSetAttribute((const void *)conv1x1_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, X6_LDS);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            caspr_set_error("conv1x1_bf16x6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-            return CASPR_ELAUNCH;
-        }
-        attr_done = true;
+    static CasprLdsOptIn optin_t, optin_f;
+    const hipError_t e1 = caspr_lds_opt_in(optin_t, (const void *)conv1x1_bf16x6_kernel<true>, X6_LDS);
+    const hipError_t e2 = caspr_lds_opt_in(optin_f, (const void *)conv1x1_bf16x6_kernel<false>, X6_LDS);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        caspr_set_error("conv1x1_bf16x6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        return CASPR_ELAUNCH;
     }
     if (in_scale)
         conv1x1_bf16x6_kernel<true><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(

@@ -577,8 +577,12 @@ __global__ __launch_bounds__(CNF_NT, 2) void cnf_rk4_kernel(CnfArgs a)
             // input-layer weights) is recomputed per stage instead of being hoisted out of the 32-stage loop, where
             // ~150 loop-invariant VGPRs were spilled and reloaded with exposed scratch latency in every epilogue.
             asm volatile("" : "+v"(tid));
+#ifdef CASPR_DEBUG_HOOKS
 #define CNF_STAMP(i)                                                                                                   \
     if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid0 == 0 && step == 0) a.trace[stage * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define CNF_STAMP(i)
+#endif
             CNF_STAMP(0)
             const int lane = tid & 63, g = lane >> 4, j = lane & 15;
             const int kq0 = tid & 127, cg0 = tid >> 7;   // input layer: rows 4*kq0 .. +3, column group
@@ -768,9 +772,11 @@ __global__ __launch_bounds__(CNF_NT, 2) void cnf_rk4_kernel(CnfArgs a)
     }
 }
 
+#ifdef CASPR_DEBUG_HOOKS
 static unsigned long long *g_cnf_trace = nullptr;
-// debug hook (not part of include/caspr_hip.h): device buffer of >= 64 u64 receiving per-phase cycle stamps
+// debug build only (not part of include/caspr_hip.h): device buffer of >= 64 u64 receiving per-phase cycle stamps
 extern "C" void caspr_debug_set_cnf_trace(unsigned long long *dev_buf) { g_cnf_trace = dev_buf; }
+#endif
 
 extern "C" int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const float *tcol, const float *w0,
                                  const float *b0, const float *w1p, const float *b1, const float *w2p, const float *b2,
@@ -787,18 +793,20 @@ extern "C" int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh,
     a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.w1p = w1p; a.b1 = b1; a.w2p = w2p; a.b2 = b2;
     a.w3 = w3; a.b3 = b3; a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.e = e; a.logp_in = logp_in; a.logp_out = logp_out;
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
-    a.trace = g_cnf_trace;
-    size_t shmem = ((size_t)(CNF_H / 4) * CNF_NCOL * 4 + 4 * CNF_H + CNF_WAVES * 3 * CNF_NCOL + CNF_NCOL * 4 + 3 * CNF_NCOL + 8) * 4;
-    if (const char *pad = getenv("CASPR_CNF_LDS_PAD")) shmem += (size_t)atoi(pad) * 1024;  // occupancy experiments only
+    a.trace = nullptr;
+    CASPR_IF_DEBUG(a.trace = g_cnf_trace;)
+    const size_t shmem = ((size_t)(CNF_H / 4) * CNF_NCOL * 4 + 4 * CNF_H + CNF_WAVES * 3 * CNF_NCOL + CNF_NCOL * 4 + 3 * CNF_NCOL + 8) * 4
+                         + (size_t)CASPR_DEBUG_ENV_INT("CASPR_CNF_LDS_PAD") * 1024;   // pad: occupancy experiments, debug build only
     hipStream_t st = (hipStream_t)stream;
     hipError_t err;
+    static CasprLdsOptIn optin_div, optin_nodiv;
     if (e) {
         auto kern = cnf_rk4_kernel<true>;
-        err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        err = caspr_lds_opt_in(optin_div, (const void *)kern, shmem);
         if (err == hipSuccess) kern<<<dim3(ceil_div(n, CNF_NCOL / 2), BT), dim3(CNF_NT), shmem, st>>>(a);
     } else {
         auto kern = cnf_rk4_kernel<false>;
-        err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        err = caspr_lds_opt_in(optin_nodiv, (const void *)kern, shmem);
         if (err == hipSuccess) kern<<<dim3(ceil_div(n, CNF_NCOL), BT), dim3(CNF_NT), shmem, st>>>(a);
     }
     if (err != hipSuccess) {

@@ -447,9 +447,10 @@ extern "C" int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int l
     CnfX6Args a;
     a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.b1 = b1; a.b2 = b2; a.w3 = w3; a.b3 = b3;
     a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.w1x = (const unsigned char *)w1x; a.w2x = (const unsigned char *)w2x;
-    a.diag = getenv("CASPR_X6_DIAG") ? atoi(getenv("CASPR_X6_DIAG")) : 0;
+    a.diag = CASPR_DEBUG_ENV_INT("CASPR_X6_DIAG");   // timing experiments, debug build only
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
-    hipError_t err = hipFuncSetAttribute((const void *)cnf_rk4_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
+    static CasprLdsOptIn optin;
+    hipError_t err = caspr_lds_opt_in(optin, (const void *)cnf_rk4_x6_kernel, XC_LDS);
     if (err != hipSuccess) {
         caspr_set_error("cnf_rk4_x6: hipFuncSetAttribute(%d) failed: %s", XC_LDS, hipGetErrorString(err));
         return CASPR_ELAUNCH;

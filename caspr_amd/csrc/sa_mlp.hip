@@ -29,7 +29,11 @@ struct SaArgs {
     unsigned long long *trace;   // debug stamps (NULL in production)
 };
 
+#ifdef CASPR_DEBUG_HOOKS
 #define SAM_STAMP(i) if (a.trace && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = __builtin_amdgcn_s_memtime();
+#else
+#define SAM_STAMP(i)
+#endif
 template <int NS, int NCOL>
 __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
 {
@@ -272,7 +276,11 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     const int b = blockIdx.y;
     const int m0 = (blockIdx.x * 4 + wave) * NCEN;
     if (m0 >= a.M) return;                // wave-uniform; no barriers in this kernel
+#ifdef CASPR_DEBUG_HOOKS
 #define SA_STAMP(i) if (a.trace && blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = __builtin_amdgcn_s_memtime();
+#else
+#define SA_STAMP(i)
+#endif
     SA_STAMP(0)
 
     // ---- per column tile: neighbour row + centre
@@ -460,7 +468,9 @@ static int launch_sa(const SaArgs &a, int B, size_t shmem, hipStream_t st)
 {
     auto kern = sa_mlp_kernel<NS, NCOL>;
     if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        // the opt-in is an upper bound: ask for the device maximum once per (kernel, device) so that later, larger layers need no second call
+        static CasprLdsOptIn optin;
+        const hipError_t e = caspr_lds_opt_in(optin, (const void *)kern, 160 * 1024);
         if (e != hipSuccess) {
             caspr_set_error("sa_mlp_max: hipFuncSetAttribute(%zu) failed: %s", shmem, hipGetErrorString(e));
             return CASPR_ELAUNCH;
@@ -471,8 +481,10 @@ static int launch_sa(const SaArgs &a, int B, size_t shmem, hipStream_t st)
     return CASPR_OK;
 }
 
+#ifdef CASPR_DEBUG_HOOKS
 static unsigned long long *g_sa_trace = nullptr;
-extern "C" void caspr_debug_set_sa_trace(unsigned long long *dev_buf) { g_sa_trace = dev_buf; }   // debug hook
+extern "C" void caspr_debug_set_sa_trace(unsigned long long *dev_buf) { g_sa_trace = dev_buf; }   // debug build only
+#endif
 
 extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
                                     const int32_t *idx, int B, int n, int M, int C, int ns, const float *w1p,
@@ -496,14 +508,15 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
     a.L[1] = {w2p, b2, g2, be2, C2, 2 * ((C1 + 31) / 32)};
     a.L[2] = {w3p, b3, g3, be3, C3, 2 * ((C2 + 31) / 32)};
     a.out = out; a.ldo = ldo; a.out_off = out_off;
-    a.trace = g_sa_trace;
+    a.trace = nullptr;
+    CASPR_IF_DEBUG(a.trace = g_sa_trace;)
     const int rA = a.L[0].kc * 4 > a.L[2].kc * 4 ? a.L[0].kc * 4 : a.L[2].kc * 4;
     const int rB0 = a.L[1].kc * 4, rB1 = C3 / 4;
     a.rowsA = rA > C2 / 4 ? rA : C2 / 4;
     a.rowsB = rB0 > rB1 ? rB0 : rB1;
     if (a.rowsB < C1 / 4) a.rowsB = C1 / 4;
     hipStream_t st = (hipStream_t)stream;
-    static const bool no_small = getenv("CASPR_SA_NO_SMALL") != nullptr;   // experiments: force the LDS kernel
+    const bool no_small = CASPR_DEBUG_ENV_INT("CASPR_SA_NO_SMALL") != 0;   // debug build only: force the LDS kernel
     if (!no_small && ldo % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)out % 16) == 0) {
         const int cpb = 4 * (64 / ns);   // centres per 256-thread block (4 waves x 64 columns)
         dim3 grid(ceil_div(M, cpb), B);

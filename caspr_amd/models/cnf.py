@@ -58,11 +58,17 @@ class CNF(nn.Module):
                 "w1p": ops.PackedWeight(layers[1]._layer.weight.detach().contiguous()), "b1": layers[1]._layer.bias.detach().contiguous(),
                 "w2p": ops.PackedWeight(layers[2]._layer.weight.detach().contiguous()), "b2": layers[2]._layer.bias.detach().contiguous(),
                 "w3": layers[3]._layer.weight.detach().contiguous(), "b3": layers[3]._layer.bias.detach().contiguous(),
-                # opt-in bf16x6 sampling kernel (ops.CNF_BF16X6): three-plane bf16 packs of the hidden layers
-                "w1x": ops.pack_cnf_x6(layers[1]._layer.weight.detach().contiguous()) if ops.CNF_BF16X6 and H == 512 else None,
-                "w2x": ops.pack_cnf_x6(layers[2]._layer.weight.detach().contiguous()) if ops.CNF_BF16X6 and H == 512 else None,
             }
         return self._cache.get("w", srcs, build)
+
+    def _weights_x6(self):
+        """Three-plane bf16 packs of the two hidden layers for the bf16x6 kernel (built on first use)."""
+        layers = self.odefunc.diffeq.layers
+        if layers[0]._layer.out_features != 512:
+            return None, None
+        return self._cache.get("wx6", [layers[1]._layer.weight, layers[2]._layer.weight],
+                               lambda: (ops.pack_cnf_x6(layers[1]._layer.weight.detach().contiguous()),
+                                        ops.pack_cnf_x6(layers[2]._layer.weight.detach().contiguous())))
 
     def end_time(self):
         """T_end = sqrt_end_time^2 (cnf.py:87-90), read back once per parameter version (a D2H sync otherwise
@@ -87,9 +93,10 @@ class CNF(nn.Module):
             if e is None:
                 e = torch.randn_like(x)                                                         # odefunc.py:127-128
             self.odefunc._e = e
+        w1x, w2x = self._weights_x6() if ops.CNF_BF16X6 else (None, None)
         res = ops.cnf_rk4(x.contiguous(), hyper, w["tcol"], w["w0"], w["b0"], w["w1p"], w["b1"], w["w2p"], w["b2"], w["w3"], w["b3"],
                           self.end_time(), self.rk4_steps, reverse, mbn_in, mbn_out, e=e,
-                          logp=None if logpx is None else logpx.contiguous(), w1x=w["w1x"], w2x=w["w2x"])
+                          logp=None if logpx is None else logpx.contiguous(), w1x=w1x, w2x=w2x)
         self.odefunc._num_evals += 4 * self.rk4_steps
         return res
 

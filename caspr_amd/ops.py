@@ -183,15 +183,47 @@ def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale
 
 
 # ---------------------------------------------------------------------------------------------
-# Opt-in: route the large pointwise convs through the bf16x6 kernel (f32-accurate products on the bf16 matrix pipe,
-# csrc/gemm_bf16x6.hip).  Off by default: the headline numbers of bench.py are measured on the f32 MFMA kernels.
-CONV_BF16X6 = os.environ.get("CASPR_CONV_BF16X6", "0") not in ("0", "")
+# Matrix products.  Every contraction of this model is f32 arithmetic; there are two ways to run it on gfx950:
+#   "bf16x6" (default): each f32 operand is split EXACTLY into three bf16 numbers (x = x1 + x2 + x3) and a product is
+#       evaluated as the six partial products a3b1 + a2b2 + a1b3 + a2b1 + a1b2 + a1b1 on the bf16 matrix pipe with f32
+#       accumulation (csrc/gemm_bf16x6.hip, csrc/ode_bf16x6.hip): every partial product is exact, the dropped terms are
+#       below 2^-23 |a||b| -- measured at or below the f32 MFMA kernels' own error against f64 on every test -- at 16x the
+#       per-instruction FLOP rate, i.e. a 2.67x higher ceiling (2500 / 6 = 416.7 f32-equivalent TFLOP/s vs 157.3);
+#   "f32": v_mfma_f32_16x16x4_f32 only (csrc/gemm.hip, csrc/ode.hip), bit-for-bit an ordered fmaf chain.
+# Shapes the bf16x6 kernels do not cover (Cin < 192 or not a multiple of 32, fewer than 128 rows per batch entry, the
+# set-abstraction MLPs, the latent ODE) run on the f32 MFMA kernels in either mode.  CASPR_MATMUL=f32 selects the f32
+# kernels at import; set_matmul_mode() switches at run time (bench.py times both in one process).
+_mode = os.environ.get("CASPR_MATMUL", "bf16x6").strip().lower()
+if _mode not in ("bf16x6", "f32"):
+    raise ValueError("CASPR_MATMUL must be 'bf16x6' or 'f32', got %r" % _mode)
+CONV_BF16X6 = _mode == "bf16x6"      # pointwise convs (conv1x1) on the bf16x6 kernel where the shape allows
+CNF_BF16X6 = _mode == "bf16x6"       # point-CNF solves on the bf16x6 kernel
 _X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstraction / input layers)
 
 
+def set_matmul_mode(mode=None, conv=None, cnf=None):
+    """Select the kernels of the matrix products: mode "bf16x6" | "f32", or conv= / cnf= booleans individually.
+    Returns the previous (conv, cnf) pair.  Packed weights of both kinds are built on first use and cached."""
+    global CONV_BF16X6, CNF_BF16X6
+    prev = (CONV_BF16X6, CNF_BF16X6)
+    if mode is not None:
+        if mode not in ("bf16x6", "f32"):
+            raise ValueError("mode must be 'bf16x6' or 'f32'")
+        CONV_BF16X6 = CNF_BF16X6 = mode == "bf16x6"
+    if conv is not None:
+        CONV_BF16X6 = bool(conv)
+    if cnf is not None:
+        CNF_BF16X6 = bool(cnf)
+    return prev
+
+
+def matmul_mode():
+    return {"conv": "bf16x6" if CONV_BF16X6 else "f32", "cnf": "bf16x6" if CNF_BF16X6 else "f32"}
+
+
 class PackedWeight:
-    """A (Cout, Cin) weight matrix in MFMA A-fragment order (see csrc/common.h); with CASPR_CONV_BF16X6=1 also the
-    three-way bf16 split of csrc/gemm_bf16x6.hip (`x3`) when the shape is supported."""
+    """A (Cout, Cin) weight matrix in MFMA A-fragment order (see csrc/common.h), plus -- built on first use -- the
+    three-way bf16 split of csrc/gemm_bf16x6.hip when the shape is supported (`x3()`)."""
 
     def __init__(self, w2d, col0=0, ncols=None):
         _chk_f32(w2d)
@@ -201,12 +233,18 @@ class PackedWeight:
         self.data = torch.empty(size, device=w2d.device, dtype=torch.float32)
         _lib.check(_lib.load().caspr_pack_weight_f32(_p(w2d), ldw, self.cout, col0, self.cin, _p(self.data), _stream()),
                    "caspr_pack_weight_f32")
-        self.x3 = None
-        if CONV_BF16X6 and self.cin % 32 == 0 and self.cin >= _X6_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128:
+        self.x6_ok = self.cin % 32 == 0 and self.cin >= _X6_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128
+        self._x3 = None
+        self._src = (w2d, ldw, col0) if self.x6_ok else None     # kept for the lazy bf16x3 pack
+
+    def x3(self):
+        if self._x3 is None:
+            w2d, ldw, col0 = self._src
             nbytes = _lib.load().caspr_bf16x3_packed_bytes(self.cout, self.cin)
-            self.x3 = torch.empty(nbytes, device=w2d.device, dtype=torch.uint8)
-            _lib.check(_lib.load().caspr_pack_weight_bf16x3(_p(w2d), ldw, self.cout, col0, self.cin, _p(self.x3), _stream()),
+            self._x3 = torch.empty(nbytes, device=w2d.device, dtype=torch.uint8)
+            _lib.check(_lib.load().caspr_pack_weight_bf16x3(_p(w2d), ldw, self.cout, col0, self.cin, _p(self._x3), _stream()),
                        "caspr_pack_weight_bf16x3")
+        return self._x3
 
 
 def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, act=0, out=None):
@@ -220,8 +258,8 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
     if out is None:
         out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
     ldy = _chk_rows(out)
-    if pw.x3 is not None and P % 128 == 0:
-        _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+    if CONV_BF16X6 and pw.x6_ok and P % 128 == 0:
+        _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
                                                         int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()),
                    "caspr_conv1x1_bf16x6_f32")
         return out
@@ -289,6 +327,35 @@ def _team_workspace(nbytes, device):
     return ws
 
 
+# A team barrier that gives up (its workgroups were not co-resident within the spin bound) poisons the solve's output with
+# NaN and sets an error word in the workspace.  Reading that word right away would put a host synchronisation back into
+# the path, so it is copied to pinned host memory behind the kernel and examined once that copy has completed: at the
+# next solve on the same stream, or when the caller asks (check_deferred_errors, e.g. after a synchronize).
+_team_status = {}
+_LM_WS_STRIDE_WORDS = (256 + (2 * 128 * 16 * 4 + 32 * 4 * 256) * 4) // 4      # LM_WS_STRIDE of csrc/ode.hip, in 32-bit words
+
+
+def _team_raise_if_failed(key, wait=False):
+    st = _team_status.get(key)
+    if st is None:
+        return
+    host, ev = st
+    if wait:
+        ev.synchronize()
+    if ev.query() and int(host.max()) != 0:
+        del _team_status[key]
+        raise _lib.CasprHipError("caspr_latent_rk4_team_f32: a team barrier gave up (the 32 x ceil(B/16) workgroups were not co-resident "
+                                 "within the spin bound); the solve's output was poisoned with NaN.  Set CASPR_LATENT_TEAM=0 to use the "
+                                 "single-workgroup kernel when other streams / processes saturate the GPU")
+
+
+def check_deferred_errors(wait=True):
+    """Raise CasprHipError if an earlier asynchronous kernel reported a failure (today: the latent team kernel's barrier).
+    wait=True blocks until the status words of every outstanding solve have arrived."""
+    for key in list(_team_status):
+        _team_raise_if_failed(key, wait=wait)
+
+
 def latent_rk4(z0, times, steps, wts):
     """Fixed-step RK4 of the latent dynamics (latent_ode_model.py:45-70): z0 (B,D) (rows may be a column
     slice of a wider tensor); wts = [PackedWeight0, b0, PackedWeight1, b1, PackedWeight2, b2, PackedWeight3, b3].  -> (B,Tu,D)."""
@@ -305,18 +372,29 @@ def latent_rk4(z0, times, steps, wts):
     L = _lib.load()
     if LATENT_TEAM and H == 512 and D <= 64 and B <= 64:
         # 32 workgroups per 16 sequences with LDS-resident weights (csrc/ode.hip): the serial chain runs ~3x faster
+        key = (z0.device.index, torch.cuda.current_stream().cuda_stream)
+        capturing = torch.cuda.is_current_stream_capturing()       # hipGraph capture: no event queries, no host copies
+        if not capturing:
+            _team_raise_if_failed(key)                   # status of the previous solve on this stream, if it has arrived
         with timed("latent_rk4"):
             ws = _team_workspace(L.caspr_latent_team_ws_bytes(B), z0.device)
             _lib.check(L.caspr_latent_rk4_team_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *ptrs, _p(out), _p(ws), ws.numel(),
                                                    _stream()), "caspr_latent_rk4_team_f32")
+        if capturing:
+            return out
+        groups = (B + 15) // 16
+        words = ws[:groups * _LM_WS_STRIDE_WORDS * 4].view(torch.int32)[16::_LM_WS_STRIDE_WORDS]      # the error word of each group
+        st = _team_status.get(key)
+        if st is None or st[0].numel() != groups:
+            st = (torch.zeros(groups, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        st[0].copy_(words, non_blocking=True)
+        st[1].record(torch.cuda.current_stream())
+        _team_status[key] = st
         return out
     with timed("latent_rk4"):
         _lib.check(L.caspr_latent_rk4_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *ptrs, _p(out), _stream()), "caspr_latent_rk4_f32")
     return out
 
-
-# Opt-in: the sampling solve of the point CNF on the bf16 matrix pipe (csrc/ode_bf16x6.hip), see DESIGN.md section 3.
-CNF_BF16X6 = os.environ.get("CASPR_CNF_BF16X6", "0") not in ("0", "")
 
 
 def pack_cnf_x6(w):

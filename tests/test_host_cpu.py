@@ -31,6 +31,12 @@ def test_library_exports_every_declared_symbol():
     assert L.caspr_abi_version() == 1
     assert L.caspr_packed_size(1600, 1600) == 100 * 100 * 256
     assert L.caspr_packed_size(4, 518) == 1 * 34 * 256
+    # SURVEY.md 8b "no global state": the production library exports exactly the declared entries -- no caspr_debug_* hook --
+    # and never reads the environment (trace hooks / experiment switches exist only in the CASPR_BUILD_DEBUG flavour)
+    syms = subprocess.run(["nm", "-D", lib.SO_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+    exported = sorted(l.split()[-1] for l in syms if " T caspr_" in l)
+    assert exported == declared, "exported caspr_* symbols differ from include/*.h: %s" % sorted(set(exported) ^ set(declared))
+    assert not [l for l in syms if l.split()[-1].split("@")[0] in ("getenv", "secure_getenv")], "the production library must not read the environment"
 
 
 def test_no_cpu_fallback():

@@ -4,6 +4,8 @@ import ctypes, sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from caspr_amd import lib
+# phase traces / experiment switches live in the debug flavour only: CASPR_BUILD_DEBUG=1 python caspr_amd/csrc/build.py
+lib.SO_PATH = lib.SO_PATH.replace("libcaspr_hip.so", "libcaspr_hip_debug.so")
 from caspr_amd.models import CaSPR
 from caspr_amd.utils.synthetic import seeded_state_dict
 dev = torch.device("cuda:0")
