@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
         mvalid[mi] = (mt0 + mi) < MT16;
         wsoff[mi] = (mvalid[mi] ? mt0 + mi : 0) * KC * 1024;
     }
-    const int rot = wpt % ntiles;
+    // CASPR_CONV_ROW_INVARIANT: every row tile walks K in the same order (a row's result must not depend on which tile it is in)
+    const int rot = (act & CASPR_CONV_ROW_INVARIANT) ? 0 : wpt % ntiles;
 
     f32x4 acc[2][NT / 16];
 #pragma unroll
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] += add[r];
-                if (act == 1) v[r] = sigmoid_f(v[r]);
+                if ((act & 0xff) == 1) v[r] = sigmoid_f(v[r]);
             }
             float *dst = Y + ((long)b * P + p) * ldy + co;
             if (co + 3 < Cout) {
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] += add[r];
-                if (act == 1) v[r] = sigmoid_f(v[r]);
+                if ((act & 0xff) == 1) v[r] = sigmoid_f(v[r]);
             }
             float *dst = Y + ((long)b * P + p) * ldy + co;
             if (co + 3 < Cout) {
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256) void conv1x1_big_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] += add[r];
-                if (act == 1) v[r] = sigmoid_f(v[r]);
+                if ((act & 0xff) == 1) v[r] = sigmoid_f(v[r]);
             }
             float *dst = Y + ((long)b * P + p) * ldy + co;
             if (co + 3 < Cout) {
@@ -728,7 +729,8 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     // default: the streaming kernel wherever a wave's 32 points and the unrolled K loop are filled; the LDS-tiled kernel
     // for short rows-per-batch (coarse levels) and narrow inputs (set-abstraction MLPs).  CASPR_GEMM_KERNEL: 1 / 4 force
     // the LDS kernel with 128 / 64-point tiles, 7 forces streaming.
-    if (force == 7 || (force == 0 && P >= 128 && Cin >= 32 * ST_DB)) {
+    // row-invariant calls always take the LDS kernel (the kernel choice itself must not depend on P)
+    if (force == 7 || (force == 0 && P >= 128 && Cin >= 32 * ST_DB && !(act & CASPR_CONV_ROW_INVARIANT))) {
         dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
         if (in_scale)
             conv1x1_stream_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,

@@ -1,6 +1,9 @@
-// ode_bf16x6.hip -- the point-CNF sampling solve (cnf.py:70-128 reverse direction, no divergence) with the two 512x512
-// hidden layers on the bf16 matrix pipe in the exact three-way split of gemm_bf16x6.hip.  OPT-IN
-// (CASPR_CNF_BF16X6=1 in the Python host); the default is cnf_rk4_kernel of ode.hip on f32 MFMA.
+// ode_bf16x6.hip -- the point-CNF solve (cnf.py:70-128) with the two 512x512 hidden layers on the bf16 matrix pipe in the
+// exact three-way split of gemm_bf16x6.hip: the DEFAULT kernel of the CNF (ops.CNF_BF16X6; cnf_rk4_kernel of ode.hip is
+// the f32-MFMA alternative).  Two instantiations: DIV = false integrates the state only (sampling, cnf.py:71-74 with
+// logpx = None); DIV = true also integrates the Hutchinson divergence estimate (odefunc.py:119-142) for forward() / NLL:
+// forward-mode tangents J e ride as the UPPER 8 columns of every wave's 16-column tile next to their 8 points (e^T J^T e ==
+// e^T J e), the value column's pre-activation reaches its tangent column through one DPP row rotate per layer.
 //
 // Different geometry from the f32 kernel, forced by the 2.67x faster products (weights can no longer be streamed from L2
 // into every wave's fragments: 4x the bytes per MFMA cycle):
@@ -62,6 +65,8 @@ __device__ __forceinline__ unsigned xc_pack(float lo, float hi) { return (__floa
 
 struct CnfX6Args {
     const float *y_in, *hyper, *tcol, *w0, *b0, *b1, *b2, *w3, *b3, *mbn_in, *mbn_out;
+    const float *e, *logp_in;     // DIV only: Hutchinson noise (BT,n,3), initial log-density (BT,n) or NULL
+    float *logp_out;              // DIV only
     const unsigned char *w1x, *w2x;
     float *y_out;
     int ldh, n, steps, reverse;
@@ -70,6 +75,17 @@ struct CnfX6Args {
                 // barriers' gave the breakdown in the header; as runtime branches they split the scheduling regions.)
 };
 
+// value of lane (l ^ 8) inside its 16-lane row: the partner column (value <-> tangent) of the same hidden-unit rows
+__device__ __forceinline__ float xc_partner(float v) { return dpp_mov<0x128>(v); }   // row_ror:8
+// tangent lanes (j >= 8 = DPP banks 2, 3 of every row) take the partner's value, value lanes keep their own: ONE
+// v_mov_b32_dpp row_ror:8 bank_mask:0xC in place -- no select, no second register
+__device__ __forceinline__ float xc_value_pre(float v)
+{
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x128, 0xf, 0xC, false));
+}
+
+template <bool DIV>
 __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -84,7 +100,9 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g0 = lane0 >> 4;
     const int bt = blockIdx.y;
-    const int col = blockIdx.x * XC_COLS + 16 * wave + (lane0 & 15);
+    // DIV: a wave's 16 columns are 8 points (j < 8) and their 8 tangent columns (j >= 8); the workgroup owns 32 points
+    const int col = DIV ? blockIdx.x * (XC_COLS / 2) + 8 * wave + (lane0 & 7) : blockIdx.x * XC_COLS + 16 * wave + (lane0 & 15);
+    const bool tg0 = DIV && (lane0 & 8);
     const bool cvalid = col < a.n;
     const int ccol = cvalid ? col : a.n - 1;
     const float *hy = a.hyper + (long)bt * a.ldh;
@@ -97,6 +115,7 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     }
 
     float y, kacc = 0.f, kprev = 0.f;
+    float lp = 0.f, lacc = 0.f;   // DIV: log-density state of point j, owned by lane (g = 3, j < 8)
     {
         float v = a.y_in[((long)bt * a.n + ccol) * 3 + sd];
         if (a.mbn_in) {
@@ -105,6 +124,16 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
             else v = (v - mean) * expf(-0.5f * logf(var + 1e-4f)) * expf(w) + bb;             // normalization.py:70-74
         }
         y = v;
+        if (DIV) {
+            if (tg0) y = a.e[((long)bt * a.n + ccol) * 3 + sd];     // tangent lanes carry e_d (constant over the solve) in the state register
+            lp = a.logp_in ? a.logp_in[(long)bt * a.n + ccol] : 0.f;
+            if (a.mbn_in) {
+                float ld = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) ld += -0.5f * logf(a.mbn_in[9 + d] + 1e-4f) + a.mbn_in[d];   // normalization.py:103-108
+                lp = a.reverse ? lp + ld : lp - ld;
+            }
+        }
     }
 
     // LDS-DMA of piece p (k chunk p >> 1, row half p & 1) of a layer's pack [row half][k chunk][48 KB image] into
@@ -131,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     // consumed chunk by chunk while layer 2 fills its own) instead of 192 fragment registers.
     f32x4 acc1[32], acc2[32];
     u32x4 bkw[2][3];              // B-fragment planes of the current / next k chunk, by chunk parity
-    f32x4 tg, tb, tw[3];          // table values of the half chunk being produced
+    f32x4 tg_, tb, tw[3];         // table values of the half chunk being produced (gate, bias, input-layer weights)
 
     for (int step = 0; step < a.steps; ++step) {
 #pragma unroll 1
@@ -163,8 +192,28 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
             __syncthreads();
 
             // ---- stage input of this lane's column, all three components
-            const float ystage = (stage == 0) ? y : y + aw * kprev;
-            const float y0 = __shfl(ystage, j), y1 = __shfl(ystage, 16 + j), y2 = __shfl(ystage, 32 + j);
+            const bool tg = DIV && (lane & 8);               // this lane's column is a tangent column
+            const float ystage = (stage == 0 || tg) ? y : y + aw * kprev;   // tangent lanes: e (kprev stays 0 there)
+            const int jp = DIV ? (j & 7) : j;                // the point's value column
+            const float y0 = __shfl(ystage, jp), y1 = __shfl(ystage, 16 + jp), y2 = __shfl(ystage, 32 + jp);
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f;              // DIV: the point's noise vector
+            if (DIV) {
+                e0 = __shfl(ystage, 8 + jp);
+                e1 = __shfl(ystage, 24 + jp);
+                e2 = __shfl(ystage, 40 + jp);
+            }
+            // gated softplus layer on a value / tangent column pair (odefunc.py:98-105 and its forward-mode derivative):
+            //   value   : softplus(pre)                 pre = gate * (W h) + bias  (the VALUE column's, `pre`)
+            //   tangent : gate * (W h_t) * sigmoid(pre)                            (`lin_t` = gate * (W h_t))
+            // with u = e^-|pre| shared: softplus = max(pre, 0) + ln(1 + u), sigmoid = (pre >= 0 ? 1 : u) / (1 + u)
+            auto act_pair = [&](float pre, float lin_t) __attribute__((always_inline)) -> float {
+                if (!DIV) return softplus_fast(pre);
+                const float u = __builtin_amdgcn_exp2f(fabsf(pre) * -1.44269504088896341f);
+                const float w1 = 1.0f + u;
+                const float sp = fmaxf(pre, 0.0f) + 0.69314718055994531f * __builtin_amdgcn_logf(w1);
+                const float sg = (pre >= 0.0f ? 1.0f : u) * __builtin_amdgcn_rcpf(w1);
+                return tg ? lin_t * sg : sp;
+            };
 
             // ---- producers of B fragments, a quarter (two k-slots) at a time; the tables of a half chunk one region earlier
             auto put_pair = [&](int kc, int q, float v0, float v1) __attribute__((always_inline)) {
@@ -177,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
             // input layer 3 -> 512 (diffeq_layers.py:83-90 + softplus): slots 2q, 2q+1 of chunk kc = units 32kc + 16h + 4g + r
             auto tab_in = [&](int kc, int hf) __attribute__((always_inline)) {
                 const int c = 32 * kc + 16 * hf + 4 * g;
-                tg = ld4(s_gate + c);
+                tg_ = ld4(s_gate + c);
                 tb = ld4(s_hb + c);
                 tw[0] = ld4(s_w0 + 3 * c);
                 tw[1] = ld4(s_w0 + 3 * c + 4);
@@ -189,15 +238,16 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int r = 2 * (q & 1) + e;
-                    const float pre = (w[3 * r] * y0 + w[3 * r + 1] * y1 + w[3 * r + 2] * y2) * tg[r] + tb[r];
-                    v[e] = softplus_fast(pre);
+                    const float pre = (w[3 * r] * y0 + w[3 * r + 1] * y1 + w[3 * r + 2] * y2) * tg_[r] + tb[r];
+                    const float lin_t = DIV ? (w[3 * r] * e0 + w[3 * r + 1] * e1 + w[3 * r + 2] * e2) * tg_[r] : 0.f;
+                    v[e] = act_pair(pre, lin_t);
                 }
                 put_pair(kc, q, v[0], v[1]);
             };
             // epilogue of hidden layer 1 for chunk kc of layer 2: units 32kc + 16h + 4g + r = rows of acc1[2kc + h]
             auto tab_e1 = [&](int kc, int hf) __attribute__((always_inline)) {
                 const int c = 32 * kc + 16 * hf + 4 * g;
-                tg = ld4(s_gate + XC_H + c);
+                tg_ = ld4(s_gate + XC_H + c);
                 tb = ld4(s_hb + XC_H + c);
             };
             auto quad_e1 = [&](int kc, int q) __attribute__((always_inline)) {
@@ -205,7 +255,10 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int r = 2 * (q & 1) + e;
-                    v[e] = softplus_fast(acc1[2 * kc + (q >> 1)][r] * tg[r] + tb[r]);
+                    const float lin = acc1[2 * kc + (q >> 1)][r] * tg_[r];
+                    float pre = lin + tb[r];
+                    if (DIV) pre = xc_value_pre(pre);                // the value column's pre-activation
+                    v[e] = act_pair(pre, lin);
                 }
                 put_pair(kc, q, v[0], v[1]);
             };
@@ -245,7 +298,13 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
 #define XC_VM4 XC_SGB(0x002, 2) XC_SGB(0x008, 1) XC_SGB(0x002, 2) XC_SGB(0x008, 1) XC_SGB(0x002, 2) XC_SGB(0x008, 1) XC_SGB(0x002, 2) XC_SGB(0x008, 1)
 #define XC_REGION_PLAIN XC_RM6 XC_SGB(0x008, 18) __builtin_amdgcn_sched_barrier(0);
 #define XC_REGION_TAB XC_RM6 XC_SGB(0x100, 5) XC_SGB(0x008, 18) __builtin_amdgcn_sched_barrier(0);
-#define XC_REGION_VALU XC_RM6 XC_VM4 XC_VM4 XC_VM4 XC_VM4 XC_SGB(0x002, 2) XC_SGB(0x008, 2) __builtin_amdgcn_sched_barrier(0);
+#define XC_REGION_VALU_S XC_RM6 XC_VM4 XC_VM4 XC_VM4 XC_VM4 XC_SGB(0x002, 2) XC_SGB(0x008, 2) __builtin_amdgcn_sched_barrier(0);
+// DIV carries ~1.7x the producer VALU (value + tangent forms of the gated softplus): the reads are pinned as in the sampling
+// variant, the VALU is left to the scheduler between the remaining MFMAs (a fixed 2-per-MFMA pattern strands the rest
+// behind the region's last MFMA and sends ~450 registers to scratch)
+#define XC_VM3 XC_SGB(0x002, 3) XC_SGB(0x008, 1) XC_SGB(0x002, 3) XC_SGB(0x008, 1) XC_SGB(0x002, 3) XC_SGB(0x008, 1) XC_SGB(0x002, 3) XC_SGB(0x008, 1)
+#define XC_REGION_VALU_D XC_RM6 XC_VM3 XC_VM3 XC_VM3 XC_VM3 XC_SGB(0x002, 8) XC_SGB(0x008, 2) __builtin_amdgcn_sched_barrier(0);
+#define XC_REGION_VALU if constexpr (DIV) { XC_REGION_VALU_D } else { XC_REGION_VALU_S }
             auto layer = [&](const unsigned char *wx, const unsigned char *wnext, f32x4 (&acc)[32], auto tab, auto quad) __attribute__((always_inline)) {
 #pragma unroll
                 for (int mi = 0; mi < 32; ++mi) acc[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -362,7 +421,10 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
                     const f32x4 gt = tq[mi & 1][0], hb = tq[mi & 1][1], wx3 = tq[mi & 1][2], wy3 = tq[mi & 1][3], wz3 = tq[mi & 1][4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float hv = softplus_fast(acc2[mi][r] * gt[r] + hb[r]);
+                        const float lin = acc2[mi][r] * gt[r];
+                        float pre = lin + hb[r];
+                        if (DIV) pre = xc_value_pre(pre);
+                        const float hv = act_pair(pre, lin);
                         part[0] += wx3[r] * hv;
                         part[1] += wy3[r] * hv;
                         part[2] += wz3[r] * hv;
@@ -377,17 +439,37 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
                 float v = part[d];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                o[d] = v * s_g3[d] + s_g3[4 + d];
+                o[d] = (DIV && tg) ? v * s_g3[d] : v * s_g3[d] + s_g3[4 + d];    // tangent columns: J e has no bias term
             }
             const float od = sd == 0 ? o[0] : (sd == 1 ? o[1] : o[2]);
-            kprev = od;
-            kacc = (stage == 0) ? od : ((stage == 3) ? kacc + od : kacc + 2.0f * od);
+            if (!DIV || !tg) {
+                kprev = od;
+                kacc = (stage == 0) ? od : ((stage == 3) ? kacc + od : kacc + 2.0f * od);
+            }
+            if (DIV) {
+                // -divergence estimate = -(e . J e) (odefunc.py:26,136): tangent lanes (g < 3) hold e_g and all of J e
+                float dv = (tg && g < 3) ? ystage * od : 0.f;
+                dv += __shfl_xor(dv, 16);
+                dv += __shfl_xor(dv, 32);
+                const float nd = -xc_partner(dv);            // lands in the point's value column (every g)
+                lacc = (stage == 0) ? nd : ((stage == 3) ? lacc + nd : lacc + 2.0f * nd);
+            }
         }
-        y = y + h6 * kacc;
+        if (!DIV || !tg0) y = y + h6 * kacc;
+        if (DIV) lp = lp + h6 * lacc;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prefetch left in flight by the last layer pass
 
-    if (cvalid && g0 < 3) {
+    if (DIV && cvalid && g0 == 3 && !tg0) {
+        if (a.mbn_out) {
+            float ld = 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) ld += -0.5f * logf(a.mbn_out[9 + d] + 1e-4f) + a.mbn_out[d];
+            lp = a.reverse ? lp + ld : lp - ld;
+        }
+        a.logp_out[(long)bt * a.n + col] = lp;
+    }
+    if (cvalid && g0 < 3 && !tg0) {
         float v = y;
         if (a.mbn_out) {
             const float w = a.mbn_out[sd], bb = a.mbn_out[3 + sd], mean = a.mbn_out[6 + sd], var = a.mbn_out[9 + sd];
@@ -437,25 +519,30 @@ extern "C" int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, v
 extern "C" int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int ldh, const float *tcol, const float *w0,
                                     const float *b0, const void *w1x, const float *b1, const void *w2x, const float *b2,
                                     const float *w3, const float *b3, int H, float t_end, int steps, int reverse,
-                                    const float *mbn_in, const float *mbn_out, float *y_out, int BT, int n, void *stream)
+                                    const float *mbn_in, const float *mbn_out, const float *e, const float *logp_in,
+                                    float *logp_out, float *y_out, int BT, int n, void *stream)
 {
     CASPR_REQUIRE(y_in && hyper && tcol && w0 && b0 && w1x && b1 && w2x && b2 && w3 && b3 && y_out, "cnf_rk4_x6: null pointer");
     CASPR_REQUIRE(H == XC_H, "cnf_rk4_x6: hidden width %d unsupported (kernel is built for 512-512-512, flow.py:89)", H);
     CASPR_REQUIRE(BT > 0 && BT <= 65535 && n > 0 && steps > 0 && ldh >= 2 * (3 * H + 3), "cnf_rk4_x6: bad sizes");
+    CASPR_REQUIRE((e == nullptr) == (logp_out == nullptr), "cnf_rk4_x6: e and logp_out must be given together");
     CASPR_REQUIRE(((uintptr_t)w1x % 16) == 0 && ((uintptr_t)w2x % 16) == 0 && ((uintptr_t)w0 % 16) == 0 && ((uintptr_t)w3 % 16) == 0,
                   "cnf_rk4_x6: weights must be 16-byte aligned");
     CnfX6Args a;
     a.y_in = y_in; a.hyper = hyper; a.tcol = tcol; a.w0 = w0; a.b0 = b0; a.b1 = b1; a.b2 = b2; a.w3 = w3; a.b3 = b3;
     a.mbn_in = mbn_in; a.mbn_out = mbn_out; a.w1x = (const unsigned char *)w1x; a.w2x = (const unsigned char *)w2x;
+    a.e = e; a.logp_in = logp_in; a.logp_out = logp_out;
     a.diag = CASPR_DEBUG_ENV_INT("CASPR_X6_DIAG");   // timing experiments, debug build only
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
-    static CasprLdsOptIn optin;
-    hipError_t err = caspr_lds_opt_in(optin, (const void *)cnf_rk4_x6_kernel, XC_LDS);
+    static CasprLdsOptIn optin_s, optin_d;
+    const hipError_t err = e ? caspr_lds_opt_in(optin_d, (const void *)cnf_rk4_x6_kernel<true>, XC_LDS)
+                             : caspr_lds_opt_in(optin_s, (const void *)cnf_rk4_x6_kernel<false>, XC_LDS);
     if (err != hipSuccess) {
         caspr_set_error("cnf_rk4_x6: hipFuncSetAttribute(%d) failed: %s", XC_LDS, hipGetErrorString(err));
         return CASPR_ELAUNCH;
     }
-    cnf_rk4_x6_kernel<<<dim3(ceil_div(n, XC_COLS), BT), dim3(256), XC_LDS, (hipStream_t)stream>>>(a);
+    if (e) cnf_rk4_x6_kernel<true><<<dim3(ceil_div(n, XC_COLS / 2), BT), dim3(256), XC_LDS, (hipStream_t)stream>>>(a);
+    else cnf_rk4_x6_kernel<false><<<dim3(ceil_div(n, XC_COLS), BT), dim3(256), XC_LDS, (hipStream_t)stream>>>(a);
     CASPR_CHECK_LAUNCH("cnf_rk4_x6");
     return CASPR_OK;
 }

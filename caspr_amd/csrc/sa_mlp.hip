@@ -22,6 +22,7 @@ struct SaArgs {
     const float *xyz, *new_xyz, *feat;
     const int32_t *idx;
     int ldf, n, M, C;
+    int feat_kind;     // CASPR_FEAT_QUAD | CASPR_FEAT_PAIRS: feat = quadratic augmentation of xyz (caspr_prep_input_f32)
     SaLayer L[3];
     float *out;
     int ldo, out_off;
@@ -263,6 +264,15 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
 //   * GroupNorm groups are 1, 2 or 4 channels wide = registers of one lane; their statistics reduce over the
 //     16 lanes (x 1 or 2 column tiles) of the neighbourhood with xor-shuffles, in f64 (one pass: sum, sum of squares);
 //   * max over the neighbourhood = the same shuffle pattern; lanes j == 0 store 4 channels (16 bytes) each.
+// Layer 1 runs on CENTRED inputs.  The first level's features are absolute coordinates squared (x^2 ... yz at depth ~2:
+// values ~5 that vary by ~1e-2 inside an r = 0.02 ball), so W x = (large constant) + (small variation) and the
+// per-neighbourhood GroupNorm, which keeps only the variation, would inherit the f32 rounding of the constant amplified
+// by 1/sigma: 1.9e-4 on the level's output (profiles/r02_error_budget.json), the largest error of the whole path.
+// Instead every sample's input has the neighbourhood's sample 0 subtracted (exact in f32: the values are within a factor
+// of two), y = W (x - x0) is accurate to its own magnitude, and the constant mu = W x0 + bias -- one extra column tile of
+// the same MFMAs -- is carried separately and added back in f64 inside the statistics, where it cancels exactly for
+// one-channel groups and supplies the between-channel offsets of wider groups.  An exact reformulation of
+// pointnet2.py:677-689, not an approximation.
 // ---------------------------------------------------------------------------------------------
 template <int NS, int C1, int C2, int C3>
 __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
@@ -298,6 +308,19 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
         cx[ct] = c[0]; cy[ct] = c[1]; cz[ct] = c[2];
     }
     const int C4 = (a.C + 3) & ~3;
+    // reference sample of each neighbourhood: its sample 0 (wave-uniform row index)
+    int rrow[NCEN];
+#pragma unroll
+    for (int cen = 0; cen < NCEN; ++cen) rrow[cen] = __builtin_amdgcn_readlane(nrow[cen * TPC], 0);
+    const int cj = j & (NCEN - 1);              // mu tile: column j carries the reference vector of centre j % NCEN
+    int myr = rrow[0];
+    float mcx = cx[0], mcy = cy[0], mcz = cz[0];
+#pragma unroll
+    for (int cen = 1; cen < NCEN; ++cen)
+        if (cj == cen) {
+            myr = rrow[cen];
+            mcx = cx[cen * TPC]; mcy = cy[cen * TPC]; mcz = cz[cen * TPC];
+        }
     SA_STAMP(1)
 
     // ---- layer 1: K order = [feat (C, padded to C4) | dx dy dz 0 | zeros]
@@ -306,22 +329,61 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     for (int rt = 0; rt < C1 / 16; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KC0 = a.L[0].kc;
-    auto gather = [&](f32x4(&bf)[CT], int kc) {     // B fragments of chunk kc straight from global memory
-        const int k = kc * 16 + 4 * g;
+    f32x4 hmu[C1 / 16];                              // W x0 of the mu tile (column j <-> centre j % NCEN)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (k < C4) {
-                v = ld4(a.feat + ((long)b * a.n + nrow[ct]) * a.ldf + k);
-            } else if (k == C4) {
-                const float *p = a.xyz + ((long)b * a.n + nrow[ct]) * 3;
-                v[0] = p[0] - cx[ct];
-                v[1] = p[1] - cy[ct];
-                v[2] = p[2] - cz[ct];
-            }
-            bf[ct] = v;
+    for (int rt = 0; rt < C1 / 16; ++rt) hmu[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KC0 = a.L[0].kc;
+    // input quad k..k+3 of cloud row `row` as layer 1 sees it: [feat | p - centre | 0]
+    auto in_quad = [&](int row, int k, float ccx, float ccy, float ccz) -> f32x4 {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (k < C4) {
+            v = ld4(a.feat + ((long)b * a.n + row) * a.ldf + k);
+        } else if (k == C4) {
+            const float *p = a.xyz + ((long)b * a.n + row) * 3;
+            v[0] = p[0] - ccx;
+            v[1] = p[1] - ccy;
+            v[2] = p[2] - ccz;
         }
+        return v;
+    };
+    // centred input quad k..k+3 of row `row` against the reference row `r0` when the features are the quadratic augmentation
+    // of the coordinates: every entry is a difference of products of NEARBY coordinates, formed from the exact coordinate
+    // differences -- a b - a0 b0 = (a - a0) b + a0 (b - b0), a^2 - a0^2 = (a - a0)(a + a0) -- so its error is relative to the
+    // variation inside the ball, not to the (100x larger) absolute feature value
+    auto aug_quad = [&](int row, int r0, int k) -> f32x4 {
+        const float *p = a.xyz + ((long)b * a.n + row) * 3, *q = a.xyz + ((long)b * a.n + r0) * 3;
+        const float x = p[0], y = p[1], z = p[2], x0 = q[0], y0 = q[1], z0 = q[2];
+        const float dx = x - x0, dy = y - y0, dz = z - z0;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+        if (a.feat_kind & CASPR_FEAT_QUAD) {
+            f[0] = dx * (x + x0);
+            f[1] = dy * (y + y0);
+            f[2] = dz * (z + z0);
+            c = 3;
+        }
+        if (a.feat_kind & CASPR_FEAT_PAIRS) {
+            f[c + 0] = dx * z + x0 * dz;   // xz
+            f[c + 1] = dx * y + x0 * dy;   // xy
+            f[c + 2] = dz * y + z0 * dy;   // zy
+        }
+        if (k == C4) return (f32x4){dx, dy, dz, 0.f};
+        return k == 0 ? (f32x4){f[0], f[1], f[2], f[3]} : (k == 4 ? (f32x4){f[4], f[5], f[6], f[7]} : (f32x4){0.f, 0.f, 0.f, 0.f});
+    };
+    // B fragments of chunk kc straight from global memory, centred on the neighbourhood's sample 0; bmu = the mu tile
+    auto gather = [&](f32x4(&bf)[CT], f32x4 &bmu, int kc) {
+        const int k = kc * 16 + 4 * g;
+        if (a.feat_kind) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bf[ct] = aug_quad(nrow[ct], rrow[ct / TPC], k);
+        } else {
+            f32x4 ref[NCEN];
+#pragma unroll
+            for (int cen = 0; cen < NCEN; ++cen) ref[cen] = in_quad(rrow[cen], k, cx[cen * TPC], cy[cen * TPC], cz[cen * TPC]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bf[ct] = in_quad(nrow[ct], k, cx[ct], cy[ct], cz[ct]) - ref[ct / TPC];
+        }
+        bmu = in_quad(myr, k, mcx, mcy, mcz);
     };
     auto mask = [&](f32x4(&bf)[CT], int kc) {       // zero the padding lanes of the feature quad that straddles C
         const int k = kc * 16 + 4 * g;
@@ -333,40 +395,63 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
                     if (k + q >= a.C) bf[ct][q] = 0.f;
         }
     };
-    auto mma1 = [&](const f32x4(&bf)[CT], const f32x4(&af)[C1 / 16]) {
+    auto mma1 = [&](const f32x4(&bf)[CT], const f32x4 &bmu, const f32x4(&af)[C1 / 16]) {
 #pragma unroll
         for (int rt = 0; rt < C1 / 16; ++rt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = mfma16(af[rt][q], bf[ct][q], h1[rt][ct]);
+                hmu[rt] = mfma16(af[rt][q], bmu[q], hmu[rt]);
+            }
+    };
+    auto mask1 = [&](f32x4 &v, int kc) {            // the mu tile's padding lanes
+        const int k = kc * 16 + 4 * g;
+        if (k < C4 && k + 3 >= a.C) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k + q >= a.C) v[q] = 0.f;
+        }
     };
     auto load_a1 = [&](f32x4(&af)[C1 / 16], int kc) {
 #pragma unroll
         for (int rt = 0; rt < C1 / 16; ++rt) af[rt] = ld4(a.L[0].wp + (((long)rt * KC0 + kc) * 64 + lane) * 4);
     };
     {   // two register sets: chunk kc+1's gather + weights are in flight while chunk kc multiplies (KC0 is even)
-        f32x4 b0[CT], b1[CT], w0[C1 / 16], w1[C1 / 16];
-        gather(b0, 0);
+        f32x4 b0[CT], b1[CT], m0v, m1v, w0[C1 / 16], w1[C1 / 16];
+        gather(b0, m0v, 0);
         load_a1(w0, 0);
         for (int kc = 0; kc < KC0; kc += 2) {
-            gather(b1, kc + 1);
+            gather(b1, m1v, kc + 1);
             load_a1(w1, kc + 1);
             __builtin_amdgcn_sched_barrier(0);
             mask(b0, kc);
-            mma1(b0, w0);
+            mask1(m0v, kc);
+            mma1(b0, m0v, w0);
             if (kc + 2 < KC0) {
-                gather(b0, kc + 2);
+                gather(b0, m0v, kc + 2);
                 load_a1(w0, kc + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
             mask(b1, kc + 1);
-            mma1(b1, w1);
+            mask1(m1v, kc + 1);
+            mma1(b1, m1v, w1);
         }
+    }
+    // mu[rt][cen] = (W x0 + bias) rows 4g..4g+3 of centre cen: lane (g, cen) of the mu tile, broadcast along the row
+    f32x4 mu[C1 / 16][NCEN];
+#pragma unroll
+    for (int rt = 0; rt < C1 / 16; ++rt) {
+        const f32x4 bias4 = ld4(a.L[0].bias + rt * 16 + 4 * g);
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mu[rt][cen][e] = __shfl(hmu[rt][e], (lane & 48) + cen) + bias4[e];
     }
 
     // bias + GroupNorm(16) per neighbourhood (+ ReLU) on a register-resident layer output
-    auto norm = [&](auto &h, auto RTc, const SaLayer &L, bool relu) {
+    // `off` (layer 1): per-(row tile, centre) constants added in f64 (h holds W (x - x0) without bias); nullptr: h + bias
+    auto norm = [&](auto &h, auto RTc, const SaLayer &L, bool relu, const f32x4 (*off)[NCEN]) {
         constexpr int RT = decltype(RTc)::value;
         constexpr int CPG = RT;            // channels per group = (16*RT)/16
         static_assert(CPG == 1 || CPG == 2 || CPG == 4, "register GroupNorm handles widths 16, 32, 64");
@@ -374,8 +459,10 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
         for (int rt = 0; rt < RT; ++rt) {
             const f32x4 bias4 = ld4(L.bias + rt * 16 + 4 * g);
             const f32x4 ga = ld4(L.gamma + rt * 16 + 4 * g), be = ld4(L.beta + rt * 16 + 4 * g);
+            if (!off) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) h[rt][ct] += bias4;
+                for (int ct = 0; ct < CT; ++ct) h[rt][ct] += bias4;
+            }
 #pragma unroll
             for (int cen = 0; cen < NCEN; ++cen)
 #pragma unroll
@@ -385,7 +472,9 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
                     for (int t = 0; t < TPC; ++t)
 #pragma unroll
                         for (int r = 0; r < CPG; ++r) {
-                            const double x = (double)h[rt][cen * TPC + t][sg * CPG + r];
+                            // one-channel groups: the constant cancels exactly, leave it out (sigma can be ~1e-2 of it)
+                            const double o = (off && CPG > 1) ? (double)off[rt][cen][sg * CPG + r] : 0.0;
+                            const double x = (double)h[rt][cen * TPC + t][sg * CPG + r] + o;
                             s1 += x;
                             s2 += x * x;
                         }
@@ -401,7 +490,8 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
 #pragma unroll
                         for (int r = 0; r < CPG; ++r) {
                             const int e = sg * CPG + r;
-                            const float y = (float)((double)h[rt][cen * TPC + t][e] - mean) * (rstd * ga[e]) + be[e];
+                            const double o = (off && CPG > 1) ? (double)off[rt][cen][e] : 0.0;
+                            const float y = (float)(((double)h[rt][cen * TPC + t][e] + o) - mean) * (rstd * ga[e]) + be[e];
                             h[rt][cen * TPC + t][e] = relu ? (y > 0.f ? y : 0.f) : y;
                         }
                 }
@@ -432,17 +522,17 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     using I2 = std::integral_constant<int, C2 / 16>;
     using I3 = std::integral_constant<int, C3 / 16>;
     SA_STAMP(2)
-    norm(h1, I1{}, a.L[0], true);
+    norm(h1, I1{}, a.L[0], true, mu);
     SA_STAMP(3)
     f32x4 h2[C2 / 16][CT];
     layer(h2, I2{}, h1, I1{}, a.L[1]);
     SA_STAMP(4)
-    norm(h2, I2{}, a.L[1], true);
+    norm(h2, I2{}, a.L[1], true, nullptr);
     SA_STAMP(5)
     f32x4 h3[C3 / 16][CT];
     layer(h3, I3{}, h2, I2{}, a.L[2]);
     SA_STAMP(6)
-    norm(h3, I3{}, a.L[2], false);
+    norm(h3, I3{}, a.L[2], false, nullptr);
     SA_STAMP(7)
 
     // ---- max over the NS samples of each centre (pointnet2.py:690-698)
@@ -487,7 +577,7 @@ extern "C" void caspr_debug_set_sa_trace(unsigned long long *dev_buf) { g_sa_tra
 #endif
 
 extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
-                                    const int32_t *idx, int B, int n, int M, int C, int ns, const float *w1p,
+                                    const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind, const float *w1p,
                                     const float *b1, const float *g1, const float *be1, int C1, const float *w2p,
                                     const float *b2, const float *g2, const float *be2, int C2, const float *w3p,
                                     const float *b3, const float *g3, const float *be3, int C3, float *out, int ldo,
@@ -503,6 +593,9 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
     SaArgs a;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = feat; a.idx = idx;
     a.ldf = ldf; a.n = n; a.M = M; a.C = C;
+    const int want_c = ((feat_kind & CASPR_FEAT_QUAD) ? 3 : 0) + ((feat_kind & CASPR_FEAT_PAIRS) ? 3 : 0);
+    CASPR_REQUIRE(feat_kind == 0 || (feat_kind > 0 && feat_kind <= 3 && C == want_c), "sa_mlp_max: feat_kind=%d does not describe C=%d channels", feat_kind, C);
+    a.feat_kind = feat_kind;
     const int K0 = ((C + 3) & ~3) + 3;
     a.L[0] = {w1p, b1, g1, be1, C1, 2 * ((K0 + 31) / 32)};
     a.L[1] = {w2p, b2, g2, be2, C2, 2 * ((C1 + 31) / 32)};

@@ -25,7 +25,7 @@ SIGNATURES = {
     "caspr_gather_points_f32": (c_int, [c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_ball_query_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_float, c_int, c_ip, c_stream]),
     "caspr_group_points_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_stream]),
-    "caspr_sa_mlp_max_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int,
+    "caspr_sa_mlp_max_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_fp, c_fp, c_fp, c_fp, c_int,
                                      c_fp, c_fp, c_fp, c_fp, c_int,
                                      c_fp, c_fp, c_fp, c_fp, c_int,
@@ -49,7 +49,7 @@ SIGNATURES = {
     "caspr_cnf_x6_packed_bytes": (c_long, []),
     "caspr_pack_weight_cnf_x6": (c_int, [c_fp, c_int, ctypes.c_void_p, c_stream]),
     "caspr_cnf_rk4_x6_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, ctypes.c_void_p, c_fp, ctypes.c_void_p, c_fp, c_fp, c_fp, c_int, c_float,
-                                     c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_stream]),
+                                     c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_stream]),
     "caspr_chamfer_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_stream]),
     "caspr_emd_ws_bytes": (c_long, [c_int, c_int, c_int]),
     "caspr_emd_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, ctypes.c_void_p, c_long, c_stream]),

@@ -86,7 +86,8 @@ class CNF(nn.Module):
             raise ValueError("only the conditional CNF (flow.py:78-81) is supported")
         assert context is not None                                                              # cnf.py:78
         w = self._weights()
-        hyper = ops.conv1x1(w["hyp"], w["hyp_bias"], context.contiguous().view(1, context.shape[0], -1))[0]   # (BT, 2*(3H+3) padded)
+        # frames are the ROWS of this conv: row-invariant, so a frame's gates do not depend on the batch around it
+        hyper = ops.conv1x1(w["hyp"], w["hyp_bias"], context.contiguous().view(1, context.shape[0], -1), row_invariant=True)[0]   # (BT, 2*(3H+3) padded)
         e = None
         if logpx is not None:
             e = self.odefunc._e

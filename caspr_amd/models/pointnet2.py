@@ -158,9 +158,9 @@ class PointNet2SetAbstraction(nn.Module):
         ball = [ops.ball_query(g.radius, ns, xyz, new_xyz) for g, ns in zip(self.grouper_modules, self.layers)]  # :391
         return {"fps_idx": fps_idx, "new_xyz": new_xyz, "ball_idx": ball}
 
-    def run(self, xyz, feat, C, record=None, idx=None):
+    def run(self, xyz, feat, C, record=None, idx=None, feat_kind=0):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels (or None).
-        -> new_xyz (B,M,3), new_feat (B,M,Cout).  `idx` = precomputed self.indices(xyz)."""
+        -> new_xyz (B,M,3), new_feat (B,M,Cout).  `idx` = precomputed self.indices(xyz); feat_kind: see ops.sa_mlp_max."""
         B = xyz.shape[0]
         M = self.num_points_out
         if idx is None:
@@ -169,7 +169,8 @@ class PointNet2SetAbstraction(nn.Module):
         out = torch.empty(B, M, self.get_num_features_out(), device=xyz.device, dtype=torch.float32)
         off = 0
         for i, ns in enumerate(self.layers):
-            ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off)  # :391-409
+            ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off,
+                           feat_kind=feat_kind)  # :391-409
             off += self.pointnet_layer_dims_list[i][-1]
         if record is not None:
             record.append(idx)
@@ -306,14 +307,15 @@ class PointNet2feat(nn.Module):
             target -= 1
         return {"sa": sa_idx, "nn": nn}
 
-    def run(self, xyz, feat, C, out=None, record=None, idx=None):
+    def run(self, xyz, feat, C, out=None, record=None, idx=None, feat_kind=0):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels.  -> (B,n,num_classes)
-        written into `out` (may be a column slice of a wider buffer) if given.  `idx` = precomputed self.indices(xyz)."""
+        written into `out` (may be a column slice of a wider buffer) if given.  `idx` = precomputed self.indices(xyz);
+        feat_kind: what the input features of the FIRST level are (ops.FEAT_QUAD | ops.FEAT_PAIRS), see ops.sa_mlp_max."""
         if idx is None:
             idx = self.indices(xyz)
         xyz_list, feat_list, ch_list = [xyz], [feat], [C]
         for l, sa in enumerate(self.set_abstractions):                                          # pointnet2.py:232
-            xyz, feat = sa.run(xyz, feat, C, record, idx["sa"][l])
+            xyz, feat = sa.run(xyz, feat, C, record, idx["sa"][l], feat_kind=feat_kind if l == 0 else 0)
             C = feat.shape[2]
             xyz_list.append(xyz)
             feat_list.append(feat)

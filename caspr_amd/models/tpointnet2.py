@@ -169,7 +169,8 @@ class TPointNet2(nn.Module):
             main.wait_event(ready)
         # local spatial feature per time step (tpointnet2.py:79-93)
         with ops.timed("enc_local_pointnet2"):
-            self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record, idx=idx)
+            kind = (ops.FEAT_QUAD if self.augment_quad else 0) | (ops.FEAT_PAIRS if self.augment_pairs else 0)
+            self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record, idx=idx, feat_kind=kind)
         t_head = ops.timed("enc_head")
         t_head.__enter__()
 

@@ -247,9 +247,15 @@ class PackedWeight:
         return self._x3
 
 
-def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, act=0, out=None):
+CONV_ROW_INVARIANT = 0x100     # include/caspr_hip.h: act flag
+
+
+def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, act=0, out=None, row_invariant=False):
     """Pointwise conv on MFMA: x (B,P,>=Cin) point-major (may be a column slice of a wider buffer) ->
-    (B,P,roundup4(Cout)) or into `out` (same rules).  See caspr_conv1x1_f32."""
+    (B,P,roundup4(Cout)) or into `out` (same rules).  See caspr_conv1x1_f32.
+    row_invariant: a row's result depends on that row only (not on P / its position): for convs over frames-as-rows."""
+    if row_invariant:
+        act = act | CONV_ROW_INVARIANT
     _chk_f32(bias, bbias, in_scale, in_shift)
     ldx = _chk_rows(x)
     B, P, _ = x.shape
@@ -258,7 +264,7 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
     if out is None:
         out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
     ldy = _chk_rows(out)
-    if CONV_BF16X6 and pw.x6_ok and P % 128 == 0:
+    if CONV_BF16X6 and pw.x6_ok and P % 128 == 0 and not row_invariant:
         _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
                                                         int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()),
                    "caspr_conv1x1_bf16x6_f32")
@@ -295,9 +301,13 @@ def gn_stats(y, C, gamma, beta, groups=16, eps=1e-5, want_max=False):
     return (scale, shift, pmax) if want_max else (scale, shift)
 
 
-def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off):
+FEAT_QUAD, FEAT_PAIRS = 1, 2     # include/caspr_hip.h
+
+
+def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0):
     """Fused grouper + 3-layer point MLP + GroupNorm + max (pointnet2.py:391-409,649-703).
-    feat (B,n,ldf) point-major with C valid channels; layers = 3 x (PackedWeight, bias, gamma, beta)."""
+    feat (B,n,ldf) point-major with C valid channels; layers = 3 x (PackedWeight, bias, gamma, beta).
+    feat_kind: FEAT_QUAD | FEAT_PAIRS when feat is prep_input's quadratic augmentation of xyz (first level)."""
     _chk_f32(xyz, new_xyz, feat, out)
     _chk_i32(idx)
     B, n, _ = xyz.shape
@@ -307,7 +317,7 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off):
     for (pw, b, g, be) in layers:
         _chk_f32(b, g, be)
         args += [_p(pw.data), _p(b), _p(g), _p(be), pw.cout]
-    _lib.check(_lib.load().caspr_sa_mlp_max_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, *args,
+    _lib.check(_lib.load().caspr_sa_mlp_max_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, int(feat_kind), *args,
                                                 _p(out), out.shape[2], out_off, _stream()), "caspr_sa_mlp_max_f32")
     return out
 
@@ -410,7 +420,7 @@ def pack_cnf_x6(w):
 def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reverse, mbn_in=None, mbn_out=None,
             e=None, logp=None, w1x=None, w2x=None):
     """Fixed-step RK4 of one CNF block (cnf.py:70-128).  y (BT,n,3); hyper (BT,ldh).  Returns x or (x, logp).
-    w1x / w2x (pack_cnf_x6): when given and no divergence is integrated, the bf16x6 kernel runs the solve."""
+    w1x / w2x (pack_cnf_x6): when given, the bf16x6 kernel runs the solve (with or without the divergence)."""
     _chk_f32(y, hyper, tcol, w0, b0, b1, b2, w3, b3, mbn_in, mbn_out, e, logp)
     BT, n, _ = y.shape
     if y.dim() != 3 or y.shape[2] != 3:
@@ -425,13 +435,14 @@ def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reve
         if m_ is not None and m_.numel() != 12:
             raise ValueError("cnf_rk4: %s must hold 12 floats [weight | bias | running_mean | running_var]" % name)
     out = torch.empty_like(y)
-    if e is None and w1x is not None and w2x is not None:
+    lp_out = torch.empty(BT, n, 1, device=y.device, dtype=torch.float32) if e is not None else None
+    if w1x is not None and w2x is not None:
         with timed("cnf_rk4"):
             _lib.check(_lib.load().caspr_cnf_rk4_x6_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1x), _p(b1), _p(w2x),
                                                         _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps), int(bool(reverse)),
-                                                        _p(mbn_in), _p(mbn_out), _p(out), BT, n, _stream()), "caspr_cnf_rk4_x6_f32")
-        return out
-    lp_out = torch.empty(BT, n, 1, device=y.device, dtype=torch.float32) if e is not None else None
+                                                        _p(mbn_in), _p(mbn_out), _p(e), _p(logp), _p(lp_out), _p(out), BT, n, _stream()),
+                       "caspr_cnf_rk4_x6_f32")
+        return out if e is None else (out, lp_out)
     with timed("cnf_rk4"):
         _lib.check(_lib.load().caspr_cnf_rk4_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1p.data), _p(b1),
                                                  _p(w2p.data), _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps), int(bool(reverse)),

@@ -68,9 +68,16 @@ int caspr_group_points_f32(const float *xyz, const float *new_xyz, const float *
  * For every centre: gather the ns neighbours (xyz - centre || feat), run 3 x (conv1d k=1 ->
  * GroupNorm(16) per neighbourhood -> ReLU [not after the last]) and max over the ns samples.
  * Weights are packed with caspr_pack_weight_f32 from the K-permuted matrix [feat (C, padded to 4) |
- * xyz (3) | 0...].  out[b, m, out_off : out_off+C3] (row stride ldo).              */
+ * xyz (3) | 0...].  out[b, m, out_off : out_off+C3] (row stride ldo).
+ * feat_kind: 0 = generic features; CASPR_FEAT_QUAD | CASPR_FEAT_PAIRS = `feat` is the quadratic augmentation of `xyz`
+ *   written by caspr_prep_input_f32 ([x2 y2 z2] then [xz xy yz], tpointnet2.py:79-90).  The first layer runs on inputs
+ *   centred on a sample of the neighbourhood (an exact reformulation in front of the per-neighbourhood GroupNorm); with
+ *   feat_kind set the centred features come straight from the coordinates, x^2 - x0^2 = (x - x0)(x + x0), instead of
+ *   from the difference of two rounded squares -- same function, closer to its exact value.                       */
+#define CASPR_FEAT_QUAD 1
+#define CASPR_FEAT_PAIRS 2
 int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
-                         const int32_t *idx, int B, int n, int M, int C, int ns,
+                         const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind,
                          const float *w1p, const float *b1, const float *g1, const float *be1, int C1,
                          const float *w2p, const float *b2, const float *g2, const float *be2, int C2,
                          const float *w3p, const float *b3, const float *g3, const float *be3, int C3,
@@ -95,12 +102,16 @@ int caspr_three_interp_f32(const float *feat, int ldf, const int32_t *idx, const
  *   in(x) = x                                   if in_scale == NULL
  *         = max(x*in_scale[b,k]+in_shift[b,k],0) (in_relu, for k >= in_relu_from) or without the max -- the previous
  *           layer's GroupNorm(+ReLU) folded into the operand load (scale/shift from caspr_gn_stats_f32)
- *   act  = identity (0) or sigmoid (1).
+ *   act  = identity (0) or sigmoid (1), optionally | CASPR_CONV_ROW_INVARIANT: the result of a row then depends on that
+ *          row's data only -- not on P or on the row's position in the batch entry (same kernel, same K order for every
+ *          row tile).  The hyper-network conv of the CNF runs over frames-as-rows with this flag so that a frame's gates do
+ *          not change with the batch it is part of (sharding invariance).
  * caspr_pack_weight_f32: W (Cout,Cin) row-major [+ column offset/count to pack a slice] -> packed
  * buffer of caspr_packed_size(Cout, ncols) floats.                                                 */
 long caspr_packed_size(int Cout, int Cin);
 int caspr_pack_weight_f32(const float *w, int ldw, int Cout, int col0, int ncols, float *packed,
                           void *stream);
+#define CASPR_CONV_ROW_INVARIANT 0x100
 int caspr_conv1x1_f32(const float *wp, const float *bias, const float *bbias, const float *X, int ldx,
                       const float *in_scale, const float *in_shift, int in_relu, int in_relu_from,
                       float *Y, int ldy, int B, int P, int Cin, int Cout, int act, void *stream);
@@ -164,19 +175,21 @@ int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const floa
                       const float *e, const float *logp_in, float *logp_out, float *y_out, int BT,
                       int n, void *stream);
 
-/* The same solve WITHOUT the divergence (sampling, e == NULL) with the two hidden layers on the bf16 matrix pipe in the
- * exact three-way split of caspr_conv1x1_bf16x6_f32 (csrc/ode_bf16x6.hip): a workgroup owns 64 points, each wave keeps
- * all 512 hidden units of its 16 points in registers across the layers (accumulator fragments are the next layer's
- * operand fragments), LDS only stages the shared weight pieces.  w1x / w2x = the (512,512) hidden weights packed by
- * caspr_pack_weight_cnf_x6 (caspr_cnf_x6_packed_bytes() bytes each); other arguments as caspr_cnf_rk4_f32.  Opt-in in
- * the Python host (CASPR_CNF_BF16X6=1).                                                                              */
+/* The same solve with the two hidden layers on the bf16 matrix pipe in the exact three-way split of
+ * caspr_conv1x1_bf16x6_f32 (csrc/ode_bf16x6.hip; the Python host's default, ops.set_matmul_mode): a workgroup owns 64
+ * points (32 points + their 32 tangent columns when the divergence is integrated), each wave keeps all 512 hidden units
+ * of its 16 columns in registers across the layers (accumulator fragments are the next layer's operand fragments), LDS
+ * only stages the shared weight pieces.  w1x / w2x = the (512,512) hidden weights packed by caspr_pack_weight_cnf_x6
+ * (caspr_cnf_x6_packed_bytes() bytes each); every other argument as caspr_cnf_rk4_f32, including e / logp_in / logp_out
+ * (NULL together: sampling; given: forward()/NLL with the Hutchinson divergence, odefunc.py:119-142).                 */
 long caspr_cnf_x6_packed_bytes(void);
 int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream);
 int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int ldh, const float *tcol,
                          const float *w0, const float *b0, const void *w1x, const float *b1,
                          const void *w2x, const float *b2, const float *w3, const float *b3, int H,
                          float t_end, int steps, int reverse, const float *mbn_in, const float *mbn_out,
-                         float *y_out, int BT, int n, void *stream);
+                         const float *e, const float *logp_in, float *logp_out, float *y_out, int BT,
+                         int n, void *stream);
 
 /* ---------------- Chamfer (tk3dv.extern.chamfer.ChamferDistance): utils/evaluations.py:40 --------
  * p (B,n,3), q (B,m,3) -> dist1 (B,n) = min_j |p_i-q_j|^2 , dist2 (B,m).                            */

@@ -398,23 +398,33 @@ def test_cnf_sample_bf16x6(dev, seeded_sd, model, n, steps):
     exact("cnf_sample_bf16x6_repeat", again, got)
 
 
-def test_cnf_forward_with_divergence(dev, seeded_sd, model):
-    BT, n = 2, 96
+@pytest.mark.parametrize("mode,n", [("bf16x6", 96), ("bf16x6", 100), ("bf16x6", 1024), ("f32", 96), ("f32", 37)])
+def test_cnf_forward_with_divergence(dev, seeded_sd, model, mode, n):
+    """forward()/NLL direction with the Hutchinson divergence (odefunc.py:119-142, injected noise) on both kernels: the
+    bf16x6 kernel's divergence variant (tangents as the upper 8 columns of every wave) and the f32-MFMA kernel."""
+    from caspr_amd import ops
+    BT = 2
     c, x, e = rnd(41, BT, 1600), rnd(42, BT, n, 3, scale=0.5), rnd(43, BT, n, 3)
-    wy, wlp = O.point_cnf(seeded_sd, x, c, torch.zeros(BT, n, 1), False, "rk4", 8, e)
-    gy, glp = model.point_cnf(x.to(dev), c.to(dev), torch.zeros(BT, n, 1, device=dev), e=e.to(dev))
-    record("cnf_fwd_y", gy, wy, 1e-5)
-    record("cnf_fwd_logp", glp, wlp, 1e-4)
-    # sampling ignores the divergence: xyz of the with-div kernel == xyz of the plain kernel (same direction)
-    gy2 = model.point_cnf(x.to(dev), c.to(dev), reverse=False)
-    record("cnf_fwd_y_nodiv_vs_div", gy2, gy, 1e-6)
-    # flow then inverse flow returns to the start (fixed-step RK4 is reversible to O(h^5))
-    back = model.point_cnf(gy2, c.to(dev), reverse=True)
-    record("cnf_roundtrip", back, x, 2e-4)
+    lp0 = rnd(44, BT, n, 1)
+    wy, wlp = O.point_cnf(seeded_sd, x, c, lp0, False, "rk4", 8, e)
+    prev = ops.set_matmul_mode(cnf=(mode == "bf16x6"))
+    try:
+        gy, glp = model.point_cnf(x.to(dev), c.to(dev), lp0.to(dev), e=e.to(dev))
+        record("cnf_fwd_y_%s_n%d" % (mode, n), gy, wy, 1e-5)
+        record("cnf_fwd_logp_%s_n%d" % (mode, n), glp, wlp, 1e-4)
+        # sampling ignores the divergence: xyz of the with-div kernel == xyz of the plain kernel (same direction)
+        gy2 = model.point_cnf(x.to(dev), c.to(dev), reverse=False)
+        record("cnf_fwd_y_nodiv_vs_div_%s_n%d" % (mode, n), gy2, gy, 1e-6)
+        # flow then inverse flow returns to the start (fixed-step RK4 is reversible to O(h^5)); with the log-density too
+        back, lpb = model.point_cnf(gy, c.to(dev), glp, reverse=True, e=e.to(dev))
+        record("cnf_roundtrip_%s_n%d" % (mode, n), back, x, 2e-4)
+        record("cnf_roundtrip_logp_%s_n%d" % (mode, n), lpb, lp0, 2e-4)
+        again = model.point_cnf(x.to(dev), c.to(dev), lp0.to(dev), e=e.to(dev))
+        exact("cnf_fwd_repeat_%s_n%d" % (mode, n), again[1], glp)
+    finally:
+        ops.set_matmul_mode(cnf=prev[1])
 
 
-# ---------------------------------------------------------------------------------------------
-# end to end
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def sd64(seeded_sd):
@@ -436,10 +446,11 @@ def test_encode_parity_dense(dev, seeded_sd, sd64, model):
         exact("dense_fps_l%d" % l, rec[l]["fps_idx"], inter[l]["fps_idx"])
         for s in range(2):
             exact("dense_ball_l%d_s%d" % (l, s), rec[l]["ball_idx"][s], inter[l]["ball_idx"][s])
-    record("dense_tnocs", gt, tnocs, 2e-5)
-    record_cond("dense_tnocs_vs_f64", gt, tnocs, t64, 1e-5, factor=1.0)
-    record("dense_z0", gz0, z0, 1e-4)   # max over T*N of a 1600-wide feature, |z0| ~ 5: 2e-5 relative
-    record_cond("dense_z0_vs_f64", gz0, z0, z64, 1e-5, factor=3.0)
+    record("dense_tnocs", gt, tnocs, 1e-5)
+    record("dense_tnocs_hip_vs_f64", gt, t64, 3e-6)
+    record("dense_z0_hip_vs_f64", gz0, z64, 1e-5)
+    record("dense_z0", gz0, z0, 1e-4)   # direct: the f32 oracle's own error on this 1600-wide max feature is 7.5e-5 (|z0| ~ 4)
+    record_cond("dense_z0_vs_f64", gz0, z0, z64, 1e-5, factor=1.0)
 
 
 def test_encode_parity_cars(dev, seeded_sd, sd64, model):
@@ -480,15 +491,19 @@ def _reconstruct_dense_vs_oracle(dev, seeded_sd, model, mode):
     _, _, x64, t64 = O.reconstruct(sd64, x.double(), ybase.double(), timestamps=sp[0, :, 0, 3].double())
     _, glp, gx, gt = model.reconstruct(x.to(dev), num_points=512, timestamps=sp[0, :, 0, 3].to(dev), y=ybase.to(dev))
     tag = "" if mode == "bf16x6" else "_f32mfma"
-    record("dense_recon_tnocs" + tag, gt, wt, 2e-5)
-    record("dense_recon_x" + tag, gx, wx, 2e-5)
-    record_cond("dense_recon_tnocs_vs_f64" + tag, gt, wt, t64, 1e-5, factor=1.0)
-    record_cond("dense_recon_x_vs_f64" + tag, gx, wx, x64, 1e-5, factor=1.0)
+    # north_star as written: within 1e-5 of the (f32) reference restatement.  What is left of that difference is the f32
+    # oracle's own distance from the f64 evaluation (7-8e-6 on this input); the HIP path itself sits within 4e-6 of f64.
+    record("dense_recon_tnocs" + tag, gt, wt, 1e-5)
+    record("dense_recon_x" + tag, gx, wx, 1e-5)
+    record("dense_recon_tnocs_hip_vs_f64" + tag, gt, t64, 3e-6)
+    record("dense_recon_x_hip_vs_f64" + tag, gx, x64, 4e-6)
     record("dense_recon_logp_y" + tag, glp, wlp, 1e-5)
     from caspr_amd import ops
     gt_pts = sp[0, :, :512, :3].contiguous()
     d1, d2 = ops.chamfer_distance(gx.view(3, 512, 3).contiguous(), gt_pts.to(dev))
-    record("dense_recon_chamfer_l2" + tag, d1.mean(dim=1) + d2.mean(dim=1), O.chamfer_l2(wx.view(3, 512, 3), gt_pts), 1e-5)
+    cd = d1.mean(dim=1) + d2.mean(dim=1)
+    record("dense_recon_chamfer_l2_hip_vs_f64" + tag, cd, O.chamfer_l2(x64.view(3, 512, 3).float(), gt_pts), 1e-5)
+    record("dense_recon_chamfer_l2" + tag, cd, O.chamfer_l2(wx.view(3, 512, 3), gt_pts), 2e-5)   # the f32 oracle's samples are 7e-6 off themselves
 
 
 def test_reconstruct_vs_reference_golden(dev, seeded_sd, sd64, model, golden):
