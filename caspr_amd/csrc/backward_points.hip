@@ -47,7 +47,7 @@ extern "C" int caspr_three_interp_bwd_f32(const float *dOut, int ldo, const int3
 __global__ __launch_bounds__(256) void group_rows_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                          const float *__restrict__ feat, int ldf,
                                                          const int32_t *__restrict__ idx, int n, int M, int C, int ns,
-                                                         float *__restrict__ G, int ldg, long rows)
+                                                         int centred, int feat_kind, float *__restrict__ G, int ldg, long rows)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -58,10 +58,34 @@ __global__ __launch_bounds__(256) void group_rows_kernel(const float *__restrict
     const float *px = xyz + (b * n + i) * 3, *pc = new_xyz + bj * 3;
     const float *f = feat ? feat + (b * n + i) * ldf : nullptr;
     float *o = G + row * ldg;
+    if (!centred) {
+        for (int c = lane; c < ldg; c += 64) {
+            float v = 0.f;
+            if (c < 3) v = px[c] - pc[c];
+            else if (c - 3 < C) v = f[c - 3];
+            o[c] = v;
+        }
+        return;
+    }
+    // centred on the neighbourhood's sample 0 (see caspr_group_rows_f32 / sa_small_kernel in sa_mlp.hip)
+    const int i0 = idx[bj * ns];
+    const float *q = xyz + (b * n + i0) * 3;
+    const float *f0 = feat ? feat + (b * n + i0) * ldf : nullptr;
+    const float x = px[0], y = px[1], z = px[2], x0 = q[0], y0 = q[1], z0 = q[2];
+    const float dx = x - x0, dy = y - y0, dz = z - z0;
     for (int c = lane; c < ldg; c += 64) {
         float v = 0.f;
-        if (c < 3) v = px[c] - pc[c];
-        else if (c - 3 < C) v = f[c - 3];
+        if (c < 3) v = c == 0 ? dx : (c == 1 ? dy : dz);
+        else if (c - 3 < C) {
+            const int k = c - 3;
+            if (feat_kind) {
+                const int kq = (feat_kind & CASPR_FEAT_QUAD) ? k : k + 3;    // position in [x2 y2 z2 xz xy zy]
+                v = kq == 0 ? dx * (x + x0) : kq == 1 ? dy * (y + y0) : kq == 2 ? dz * (z + z0)
+                  : kq == 3 ? dx * z + x0 * dz : kq == 4 ? dx * y + x0 * dy : dz * y + z0 * dy;
+            } else {
+                v = f[k] - f0[k];
+            }
+        }
         o[c] = v;
     }
 }
@@ -81,14 +105,16 @@ __global__ __launch_bounds__(256) void group_rows_bwd_kernel(const float *__rest
 }
 
 extern "C" int caspr_group_rows_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
-                                    const int32_t *idx, int B, int n, int M, int C, int ns, float *G, int ldg,
-                                    void *stream)
+                                    const int32_t *idx, int B, int n, int M, int C, int ns, int centred, int feat_kind,
+                                    float *G, int ldg, void *stream)
 {
     CASPR_REQUIRE(xyz && new_xyz && idx && G && B > 0 && n > 0 && M > 0 && ns > 0 && C >= 0, "group_rows: bad arguments");
+    const int want_c = ((feat_kind & CASPR_FEAT_QUAD) ? 3 : 0) + ((feat_kind & CASPR_FEAT_PAIRS) ? 3 : 0);
+    CASPR_REQUIRE(feat_kind == 0 || (centred && feat_kind > 0 && feat_kind <= 3 && C == want_c), "group_rows: feat_kind=%d needs centred rows and C=%d", feat_kind, want_c);
     CASPR_REQUIRE((C == 0 || (feat && ldf >= C)) && ldg >= 3 + C, "group_rows: feat/ldf/ldg inconsistent with C=%d", C);
     const long rows = (long)B * M * ns;
     group_rows_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(xyz, new_xyz, feat, ldf, idx, n, M, C,
-                                                                                               ns, G, ldg, rows);
+                                                                                               ns, centred, feat_kind, G, ldg, rows);
     CASPR_CHECK_LAUNCH("group_rows");
     return CASPR_OK;
 }

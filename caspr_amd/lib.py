@@ -67,7 +67,7 @@ SIGNATURES = {
     "caspr_colsum_ws_bytes": (c_long, [c_long, c_int, c_int]),
     "caspr_colsum_batched_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_three_interp_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
-    "caspr_group_rows_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
+    "caspr_group_rows_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_group_rows_bwd_f32": (c_int, [c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_segment_sum_f32": (c_int, [c_fp, c_int, c_int, c_ip, c_ip, c_fp, c_long, c_int, c_fp, c_int, c_int, c_stream]),
     "caspr_gn_rows_f32": (c_int, [c_fp, c_int, c_long, c_int, c_int, c_fp, c_fp, c_float, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_ip,

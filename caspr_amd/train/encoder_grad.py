@@ -90,9 +90,13 @@ def _conv_gn_bwd(packs, grads, rec, da, relu=True, dmax=None, amax=None, need_dx
 # ---------------------------------------------------------------------------------------------
 # one scale of a set-abstraction level on neighbourhood rows
 # ---------------------------------------------------------------------------------------------
-def _sa_scale_fwd(packs, pn, xyz, new_xyz, feat, C, idx, out, off, need_input_grad=True):
+def _sa_scale_fwd(packs, pn, xyz, new_xyz, feat, C, idx, out, off, need_input_grad=True, feat_kind=0):
     ns = idx.shape[2]
-    cur = T.group_rows(xyz, new_xyz, feat, C, idx)
+    # First level, 16-channel scale (one channel per GroupNorm group): the conv runs on rows centred on the neighbourhood's
+    # sample 0 -- the constant it drops cancels in the normalisation, forward and backward, and the result no longer
+    # carries the rounding of a constant 100x larger than what the GroupNorm keeps (see csrc/sa_mlp.hip, sa_small_kernel)
+    centred = feat_kind != 0 and not need_input_grad and pn.conv_layers[0].out_channels == 16
+    cur = T.group_rows(xyz, new_xyz, feat, C, idx, centred=centred, feat_kind=feat_kind if centred else 0)
     recs = []
     n_layers = len(pn.conv_layers)
     for l, (conv, gn) in enumerate(zip(pn.conv_layers, pn.bn_layers)):
@@ -154,6 +158,7 @@ def encoder_forward(enc, x):
     X1 = torch.empty(B, P, L + S, device=dev, dtype=torch.float32)
     xyz, feat = ops.prep_input(x, enc.augment_quad, enc.augment_pairs)
     C0 = (3 if enc.augment_quad else 0) + (3 if enc.augment_pairs else 0)
+    feat_kind0 = (ops.FEAT_QUAD if enc.augment_quad else 0) | (ops.FEAT_PAIRS if enc.augment_pairs else 0)
     if C0 == 0:
         feat = None
     pn2 = enc.local_extract
@@ -177,7 +182,8 @@ def encoder_forward(enc, x):
         off, scales = 0, []
         for i in range(len(sa.layers)):
             scales.append(_sa_scale_fwd(packs, sa.pointnet_modules[i], xyz_list[-1], new_xyz, feat_list[-1], ch_list[-1], d["ball_idx"][i], out, off,
-                                        need_input_grad=l > 0))   # level 0 reads the input coordinates' features: no gradient
+                                        need_input_grad=l > 0,    # level 0 reads the input coordinates' features: no gradient
+                                        feat_kind=feat_kind0 if l == 0 else 0))
             off += sa.pointnet_layer_dims_list[i][-1]
         tape.sa.append(scales)
         xyz_list.append(new_xyz)

@@ -67,10 +67,15 @@ int caspr_three_interp_bwd_f32(const float *dOut, int ldo, const int32_t *idx, c
 /* Training layout of the grouper (Kaolin PointNet2GroupingLayer, call site pointnet2.py:391): one row
  * per (b, centre j, sample s): G[(b*M+j)*ns+s] = [xyz[b,i]-new_xyz[b,j] | feat[b,i,0:C] | 0 pad],
  * i = idx[b,j,s]; channel order = the reference's (xyz first).  Backward scatters the feature columns
- * back: dFeat[b,i,c] += dG[row,3+c] (float atomics).                                                */
+ * back: dFeat[b,i,c] += dG[row,3+c] (float atomics).
+ * centred != 0: every row has the row of its neighbourhood's sample 0 subtracted (exact in front of a conv whose
+ *   GroupNorm groups are single channels: the per-neighbourhood constant W x0 + b cancels in the normalisation, and
+ *   the weight gradient sum_s dy_s x_s is unchanged because sum_s dy_s = 0 there); with feat_kind = CASPR_FEAT_QUAD |
+ *   CASPR_FEAT_PAIRS (feat = caspr_prep_input_f32's augmentation of xyz) the centred features are formed from the
+ *   coordinate differences as in caspr_sa_mlp_max_f32.  Used for the first level's 16-channel scale.           */
 int caspr_group_rows_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
-                         const int32_t *idx, int B, int n, int M, int C, int ns, float *G, int ldg,
-                         void *stream);
+                         const int32_t *idx, int B, int n, int M, int C, int ns, int centred, int feat_kind,
+                         float *G, int ldg, void *stream);
 int caspr_group_rows_bwd_f32(const float *dG, int ldg, const int32_t *idx, int B, int n, int M, int C,
                              int ns, float *dFeat, int ldf, void *stream);
 

@@ -272,10 +272,9 @@ def test_encoder_backward_matches_oracle_autograd(B, T, N):
     # is itself 2e-4 (head) to 2e-2 (set abstraction) away from f64 autograd in the relative L2 norm, with the same
     # layer-by-layer growth.  Criteria:
     #   * exact where no selection is upstream: the loss value and conv3's gradient (first in the backward chain);
-    #   * wiring: per parameter the MEDIAN elementwise error stays below 1.5e-2 of the largest entry and the L2 error below
-    #     0.05 + 2x the f32 oracle's -- a mis-wired block (wrong operand, missing term, transposed index) is O(1) in both;
-    #   * accuracy class: the whole-gradient L2 error is below 0.05 (4x the measured one-ulp input-perturbation floor)
-    #     and within 10x of the f32 oracle's own error against f64.
+    #   * wiring: per parameter the MEDIAN elementwise error stays below 1e-2 of the largest entry and the L2 error below
+    #     0.01 + 1.5x the f32 oracle's -- a mis-wired block (wrong operand, missing term, transposed index) is O(1) in both;
+    #   * accuracy class: the whole-gradient L2 error is below 0.01 and within 1.5x of the f32 oracle's own error against f64.
     e_gpu, e_ref, n, num_g, num_r, den, bad = [], [], 0, 0.0, 0.0, 0.0, []
     for name, p in m.named_parameters():
         want = sd6[name].grad
@@ -299,7 +298,7 @@ def test_encoder_backward_matches_oracle_autograd(B, T, N):
         den += float(want.norm()) ** 2
         n += 1
         assert np.isfinite(dg)
-        if not (med <= 1.5e-2 and dg / nrm <= 0.05 + 2 * dr / nrm):
+        if not (med <= 1.0e-2 and dg / nrm <= 0.01 + 1.5 * dr / nrm):
             bad.append("%s: median elementwise err %.3e (of max), L2 err %.3e" % (name, med, dg / nrm))
     rel("enc_flush" + tag, torch.zeros(1), torch.zeros(1), 1.0)   # writes the report file
     assert not bad, "\n".join(bad)
@@ -309,10 +308,13 @@ def test_encoder_backward_matches_oracle_autograd(B, T, N):
                                         "median_oracle32": float(np.median(e_ref)), "max_hip": float(np.max(e_gpu)),
                                         "max_oracle32": float(np.max(e_ref))}
     rel("enc_grad_conv3" + tag, m.encoder.conv3.weight.grad, sd6["encoder.conv3.weight"].grad, 1e-4)
-    # measured: HIP 2.3e-2, f32 oracle 6.8e-3, input-perturbation noise floor 1.3e-2 (tools/grad_noise_probe.py).  The f32
-    # oracle's own figure depends on the host's thread count (summation order), so the bound is absolute with the ratio kept
-    # as a looser second condition.
-    assert tot_g <= 0.05 and tot_g <= 10 * tot_r + 1e-5, "whole-gradient L2 error %.3e vs the f32 oracle's %.3e" % (tot_g, tot_r)
+    # Round 1 measured HIP 2.3e-2 against the f32 oracle's 6.8e-3 and called the difference selection noise.  The round-2
+    # error budget (tests/test_error_budget.py) found the cause: the first set-abstraction level's forward error (a large
+    # constant in front of a per-neighbourhood GroupNorm) flipped ReLU / max selections all the way up the network.  With
+    # that level's 16-channel scale on centred rows (train/encoder_grad.py, csrc/backward_points.hip) the whole-gradient
+    # error is 2.7e-3 .. 3.3e-3: HALF to a QUARTER of the f32 CPU autograd's own distance from f64 (6.9e-3 .. 1.1e-2).
+    # Bound: no worse than 1.5x the f32 oracle's error and below 1e-2 in absolute terms.
+    assert tot_g <= 0.01 and tot_g <= 1.5 * tot_r + 1e-5, "whole-gradient L2 error %.3e vs the f32 oracle's %.3e" % (tot_g, tot_r)
 
 
 def test_pretrain_step_matches_reference_golden(golden, seeded_sd):
