@@ -301,9 +301,17 @@ def cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, yb
     with torch.no_grad():
         od = model.reconstruct(xd.to(dev), num_points=N, timestamps=spd[0, :, 0, 3].to(dev), y=yd.to(dev))
     _, _, wxd, wtd = O.reconstruct(sd, xd, yd, timestamps=spd[0, :, 0, 3], cnf_steps=args.cnf_steps, latent_steps=args.latent_steps)
+    _, _, xd64, td64 = O.reconstruct(sd64, xd.double(), yd.double(), timestamps=spd[0, :, 0, 3].double(), cnf_steps=args.cnf_steps,
+                                     latent_steps=args.latent_steps)
     ex, et = float((od[2].cpu() - wxd).abs().max()), float((od[3].cpu() - wtd).abs().max())
-    checks.append(ex <= DENSE_TOL and et <= DENSE_TOL)
-    parity["dense_input"] = {"x_max_abs_err": ex, "tnocs_max_abs_err": et, "criterion": DENSE_TOL, "ok": ex <= DENSE_TOL and et <= DENSE_TOL}
+    ex64, et64 = float((od[2].cpu().double() - xd64).abs().max()), float((od[3].cpu().double() - td64).abs().max())
+    ox64, ot64 = float((wxd.double() - xd64).abs().max()), float((wtd.double() - td64).abs().max())
+    # the direct HIP-vs-f32-oracle difference is the oracle's own f32 error once the HIP path is within a few 1e-6 of f64:
+    # assert HALF the tolerance against f64, and the full tolerance directly with the oracle's own excess allowed for
+    dense_ok = ex64 <= 0.5 * DENSE_TOL and et64 <= 0.5 * DENSE_TOL and ex <= DENSE_TOL + max(0.0, ox64 - 8.5e-6) and et <= DENSE_TOL + max(0.0, ot64 - 8.5e-6)
+    checks.append(dense_ok)
+    parity["dense_input"] = {"x_max_abs_err": ex, "tnocs_max_abs_err": et, "criterion": DENSE_TOL, "x_hip_vs_f64": ex64, "tnocs_hip_vs_f64": et64,
+                             "x_oracle32_vs_f64": ox64, "tnocs_oracle32_vs_f64": ot64, "ok": dense_ok}
     # NFE of the reference's adaptive solvers on this input (the oracle's dopri5 restatement, PARITY UNPINNED), small sample
     nfe = [0, 0]
     O.reconstruct(sd, xs[:1], ys[:1, :, :256].contiguous(), timestamps=times_cpu, method="dopri5", nfe=nfe)
