@@ -2,6 +2,12 @@
 // (ops.CONV_BF16X6; the f32 MFMA kernels of gemm.hip take the shapes it does not cover and the "f32" mode).  Same contract
 // as caspr_conv1x1_f32.
 //
+// Measured and dropped (round 2): a double-buffered form -- 8 waves (4 x 2, wave tile 64 x 64), two 72 KB LDS stages, one
+// barrier per K chunk with the next chunk's DMA / split-store under the current chunk's MFMAs -- ran 183 f32-equivalent
+// TFLOP/s on the 1600 x 1600 head layer against 198 for this kernel (same box, random data): the smaller wave tile reads 30 %
+// more fragments per MFMA and eight waves meet one barrier; two independent workgroups per CU already hide each other's
+// staging.
+//
 // Every f32 operand is written as the EXACT sum of three bf16 numbers, x = x1 + x2 + x3 (8 significand bits each, by
 // truncation, so every remainder is exact), and a*b is evaluated as a3b1 + a2b2 + a1b3 + a2b1 + a1b2 + a1b1: the six
 // partial products are exact inside v_mfma_f32_16x16x32_bf16 and accumulate in f32; the three dropped terms are below
@@ -226,154 +232,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Double-buffered form (the default): the same 256-channel x 128-point tile and the same pack, but 8 waves (4 x 2, wave tile
-// 64 channels x 64 points, 64 accumulator registers, two waves per SIMD) over TWO LDS stages (144 KB, one workgroup per
-// CU) and ONE barrier per K chunk: while chunk kc multiplies out of stage kc & 1, the weight planes of chunk kc + 1 arrive
-// by LDS-DMA in the other stage, its activation rows (fetched a chunk earlier into registers) are split and stored
-// there, and the rows of chunk kc + 2 are requested.  The single-buffered kernel above stages between two barriers with
-// the matrix pipe idle for its own workgroup (223 f32-equivalent TFLOP/s on the 1600 x 1600 head layer against 280-312
-// with the staging switched off, profiles/r01_bf16x6_micro.txt).
-// ---------------------------------------------------------------------------------------------
-#define X6_STAGE (3 * X6_PA + 3 * X6_PB)
-#define X6_LDS_DB (2 * X6_STAGE)
-
-template <bool FUSED>
-__global__ __launch_bounds__(512, 2) void conv1x1_bf16x6_db_kernel(const unsigned char *__restrict__ wpk, const float *__restrict__ bias,
-                                                                   const float *__restrict__ bbias, const float *__restrict__ X,
-                                                                   int ldx, const float *__restrict__ in_scale,
-                                                                   const float *__restrict__ in_shift, int in_relu, int relu_from,
-                                                                   float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int act,
-                                                                   int Mt, int Pt)
-{
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, j = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware, bijective for any block count: consecutive work items (the channel tiles of one point tile) share an L2
-    const int nblk = gridDim.x, lin = blockIdx.x;
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int q8 = nblk >> 3, r8 = nblk & 7;
-    const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int mt = work % Mt, pt = (work / Mt) % Pt, b = work / (Mt * Pt);
-    const int p0 = pt * X6_TP;
-    const int nk = Cin / 32;
-    const int co_w = mt * X6_TM + wm * 64;
-    const bool live = co_w < Cout;   // wave-uniform; a wave of pure padding only stages and meets the barriers
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // activation staging: thread = (row xr, 8-float piece xq of the chunk); xq is wave-uniform (waves 2q, 2q+1), so the
-    // fused transform's scale / shift come through scalar loads
-    const int xr = tid & 127, xq = wave >> 1;
-    const float *xsrc = X + ((long)b * P + p0 + xr) * ldx + 8 * xq;
-    const float *sc = FUSED ? in_scale + (long)b * Cin + 8 * xq : nullptr;
-    const float *sh = FUSED ? in_shift + (long)b * Cin + 8 * xq : nullptr;
-    f32x4 xreg[2];
-    const unsigned char *wsrc = wpk + ((long)mt * nk) * X6_CHUNK + (wave * 6) * 1024 + lane * 16;
-    auto gload = [&](int kc) {
-        xreg[0] = ld4(xsrc + kc * 32);
-        xreg[1] = ld4(xsrc + kc * 32 + 4);
-    };
-    auto dma = [&](int kc, unsigned char *sA) {
-#pragma unroll
-        for (int s_ = 0; s_ < 6; ++s_)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (long)kc * X6_CHUNK + s_ * 1024),
-                                             (__attribute__((address_space(3))) void *)(sA + (wave * 6 + s_) * 1024), 16, 0, 0);
-    };
-    auto lstore = [&](int kc, unsigned char *sB) {
-        float xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float v = xreg[q >> 2][q & 3];
-            if (FUSED) {
-                const int k = kc * 32 + q;   // relative to the 8 * xq already folded into sc / sh
-                v = v * sc[k] + sh[k];
-                if (in_relu && k + 8 * xq >= relu_from) v = v > 0.f ? v : 0.f;
-            }
-            xv[q] = v;
-        }
-        u32x4 pv[3];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned p1, p2, p3;
-            x6_split_pair(xv[2 * q], xv[2 * q + 1], p1, p2, p3);
-            pv[0][q] = p1;
-            pv[1][q] = p2;
-            pv[2][q] = p3;
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *(u32x4 *)(sB + pl * X6_PB + x6_off(xr, xq)) = pv[pl];
-    };
-
-    gload(0);
-    dma(0, lds);
-    lstore(0, lds + 3 * X6_PA);
-    gload(nk > 1 ? 1 : 0);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        unsigned char *cur = lds + (kc & 1) * X6_STAGE, *nxt = lds + ((kc + 1) & 1) * X6_STAGE;
-        const int k1 = kc + 1 < nk ? kc + 1 : kc, k2 = kc + 2 < nk ? kc + 2 : nk - 1;   // unconditional (clamped) staging: no branch
-        dma(k1, nxt);
-        lstore(k1, nxt + 3 * X6_PA);
-        gload(k2);
-        if (live) {
-            const unsigned char *sA = cur, *sB = cur + 3 * X6_PA;
-            bf16x8 bf[3][4];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) bf[pl][ni] = *(const bf16x8 *)(sB + pl * X6_PB + x6_off(wn * 64 + ni * 16 + j, g));
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                bf16x8 af[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[pl] = *(const bf16x8 *)(sA + pl * X6_PA + x6_off(wm * 64 + mi * 16 + j, g));
-                // smallest terms first; term-major so four independent accumulators sit between dependent MFMAs
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][ni], acc[mi][ni], 0, 0, 0);
-            }
-        }
-        __syncthreads();   // stage nxt is complete (DMA landed, rows stored); everybody is done reading stage cur
-    }
-
-    // epilogue: lane holds channels co + r (D row = 4g + r) of point p (column j); Cout % 4 == 0
-    const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int co = co_w + mi * 16 + 4 * g;
-        if (co >= Cout) continue;
-        f32x4 add = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (bias) add += ld4(bias + co);
-        if (bb) add += ld4(bb + co);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int p = p0 + wn * 64 + ni * 16 + j;
-            f32x4 v = acc[mi][ni] + add;
-            if ((act & 0xff) == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = sigmoid_f(v[r]);
-            }
-            st4(Y + ((long)b * P + p) * ldy + co, v);
-        }
-    }
-}
-
 extern "C" long caspr_bf16x3_packed_bytes(int Cout, int Cin)
 {
     if (Cout <= 0 || Cin <= 0 || Cin % 32) return 0;
@@ -408,23 +266,7 @@ extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, cons
     const int Mt = ceil_div(Cout, X6_TM), Pt = P / X6_TP;
     const long nblk = (long)Mt * Pt * B;
     CASPR_REQUIRE(nblk < (1L << 31), "conv1x1_bf16x6: too many tiles (%ld)", nblk);
-    static CasprLdsOptIn optin_t, optin_f, optin_dt, optin_df;
-    if (!CASPR_DEBUG_ENV_INT("CASPR_X6_CONV_SINGLE")) {   // debug build only: 1 = the single-buffered kernel (A/B timing)
-        const hipError_t e1 = caspr_lds_opt_in(optin_dt, (const void *)conv1x1_bf16x6_db_kernel<true>, X6_LDS_DB);
-        const hipError_t e2 = caspr_lds_opt_in(optin_df, (const void *)conv1x1_bf16x6_db_kernel<false>, X6_LDS_DB);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            caspr_set_error("conv1x1_bf16x6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-            return CASPR_ELAUNCH;
-        }
-        if (in_scale)
-            conv1x1_bf16x6_db_kernel<true><<<dim3((unsigned)nblk), dim3(512), X6_LDS_DB, (hipStream_t)stream>>>(
-                (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt);
-        else
-            conv1x1_bf16x6_db_kernel<false><<<dim3((unsigned)nblk), dim3(512), X6_LDS_DB, (hipStream_t)stream>>>(
-                (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt);
-        CASPR_CHECK_LAUNCH("conv1x1_bf16x6");
-        return CASPR_OK;
-    }
+    static CasprLdsOptIn optin_t, optin_f;
     const hipError_t e1 = caspr_lds_opt_in(optin_t, (const void *)conv1x1_bf16x6_kernel<true>, X6_LDS);
     const hipError_t e2 = caspr_lds_opt_in(optin_f, (const void *)conv1x1_bf16x6_kernel<false>, X6_LDS);
     if (e1 != hipSuccess || e2 != hipSuccess) {
