@@ -1002,9 +1002,9 @@ extern "C" int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int l
     a.diag = CASPR_DEBUG_ENV_INT("CASPR_X6_DIAG");   // timing experiments, debug build only
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
     static CasprLdsOptIn optin_s, optin_d, optin_w;
-    // sampling: the 128-point kernel unless the frame would leave most of its last 128-point workgroup idle (debug build:
-    // CASPR_X6_NARROW=1 forces the 64-point kernel for A/B timing)
-    const bool wide = !e && (n % XW_PTS == 0 || n % XW_PTS > XC_COLS || n > 4 * XW_PTS) && !CASPR_DEBUG_ENV_INT("CASPR_X6_NARROW");
+    // The 128-point kernel is an experiment (53.5 ms against this kernel's 50.5 at cfg-2, see its header and DESIGN.md): only
+    // the debug build can select it (CASPR_X6_WIDE=1), for tools/cnf_x6w_trace.py
+    const bool wide = !e && CASPR_DEBUG_ENV_INT("CASPR_X6_WIDE") != 0;
     const hipError_t err = e ? caspr_lds_opt_in(optin_d, (const void *)cnf_rk4_x6_kernel<true>, XC_LDS)
                              : (wide ? caspr_lds_opt_in(optin_w, (const void *)cnf_rk4_x6w_kernel, XW_LDS)
                                      : caspr_lds_opt_in(optin_s, (const void *)cnf_rk4_x6_kernel<false>, XC_LDS));

@@ -22,10 +22,10 @@ def run(k=3):
         b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / k
 for rep in range(2):
-    os.environ["CASPR_X6_NARROW"] = "0"; tw = run()
-    os.environ["CASPR_X6_NARROW"] = "1"; tn = run()
+    os.environ["CASPR_X6_WIDE"] = "1"; tw = run()
+    os.environ["CASPR_X6_WIDE"] = "0"; tn = run()
     print("wide %.2f ms   narrow %.2f ms (includes the hyper conv)" % (tw, tn))
-os.environ["CASPR_X6_NARROW"] = "0"
+os.environ["CASPR_X6_WIDE"] = "1"
 buf = torch.zeros(288, dtype=torch.int64, device=dev)
 so.caspr_debug_set_x6_trace(ctypes.c_void_p(buf.data_ptr()))
 with torch.no_grad():
