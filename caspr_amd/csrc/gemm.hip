@@ -497,191 +497,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// conv1x1, large-problem variant: ONE wave per SIMD (the CNF kernel's lesson, profiles/r01_*): 256 threads,
-// block tile 128 (co) x 256 (points), wave tile 64 x 128 = 4 x 8 MFMA tiles (128 accumulator VGPRs), K tile 64
-// in a double-buffered 2 x 64 KiB LDS B-tile.  Per 16-k chunk a wave issues 4 weight-fragment loads (L2) and 8
-// activation-fragment reads (LDS) for 128 MFMAs; both are prefetched one chunk ahead into a second register
-// set, and the next K tile's global loads are issued two chunks before they are written to LDS.
-// ---------------------------------------------------------------------------------------------
-#define BIG_MT 128
-#define BIG_NT 256
-#define BIG_KT 64
-
-__global__ __launch_bounds__(256) void conv1x1_big_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
-                                                          const float *__restrict__ bbias, const float *__restrict__ X,
-                                                          int ldx, const float *__restrict__ in_scale,
-                                                          const float *__restrict__ in_shift, int in_relu,
-                                                          int relu_from, float *__restrict__ Y, int ldy, int P, int Cin,
-                                                          int Cout, int act)
-{
-    extern __shared__ __attribute__((aligned(16))) float sBig[];   // [2][16 kq][256 col][4]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int g = lane >> 4, j = lane & 15;
-    const int b = blockIdx.z;
-    const int p0 = blockIdx.y * BIG_NT;
-    const int co0 = blockIdx.x * BIG_MT;
-    const int KC = 2 * ((Cin + 31) / 32);          // 16-k chunks in the packed stream (even)
-    const int MT16 = (Cout + 15) / 16;
-    const int ntiles = (KC + 3) / 4;               // K tiles of 4 chunks (the last one may hold 2)
-
-    const float *Xb = X + (long)b * P * ldx;
-    const float *sc = in_scale ? in_scale + (long)b * Cin : nullptr;
-    const float *sh = in_scale ? in_shift + (long)b * Cin : nullptr;
-
-    const int mt0 = (co0 >> 4) + wm * 4;
-    int nvalid = MT16 - mt0;                       // valid 16-row tiles of this wave (wave-uniform)
-    nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
-    const float *wbase = wp + ((long)(nvalid > 0 ? mt0 : 0) * KC) * 256 + lane * 4;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // staging: float4 f = tid + 256*i (i < 16) -> kq = f & 15, col = f >> 4 ; two groups of 8
-    f32x4 stage[8];
-    auto load_stage = [&](int kt, int grp) {   // issue only; see the small kernel
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = tid + 256 * (grp * 8 + i);
-            const int kq = f & 15, col = f >> 4;
-            const int k = kt * BIG_KT + kq * 4;
-            const int p = p0 + col;
-            const bool ok = p < P && k < Cin;
-            stage[i] = ld4(Xb + (ok ? ((long)p * ldx + k) : 0));
-        }
-    };
-    auto store_stage = [&](int buf, int kt, int grp) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = tid + 256 * (grp * 8 + i);
-            const int kq = f & 15, col = f >> 4;
-            const int k = kt * BIG_KT + kq * 4;
-            const int p = p0 + col;
-            f32x4 v = stage[i];
-            if (p < P && k < Cin) {
-                if (sc) {
-                    const f32x4 s4 = ld4(sc + k), t4 = ld4(sh + k);
-                    v = v * s4 + t4;
-                    if (in_relu && k >= relu_from) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (k + q >= Cin) v[q] = 0.f;
-            } else {
-                v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            st4(&sBig[buf * (16 * BIG_NT * 4) + btile_off(kq, col, BIG_NT)], v);
-        }
-    };
-    f32x4 a0[4], a1[4], b0[8], b1[8];
-    auto load_a = [&](f32x4(&a)[4], int kc) {
-        const int kk = kc < KC ? kc : KC - 1;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a[mi] = ld4(wbase + ((long)(mi < nvalid ? mi : 0) * KC + kk) * 256);
-    };
-    auto load_b = [&](f32x4(&bf)[8], int buf, int c) {
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni)
-            bf[ni] = ld4(&sBig[buf * (16 * BIG_NT * 4) + btile_off(c * 4 + g, wn * 128 + ni * 16 + j, BIG_NT)]);
-    };
-    auto mma = [&](const f32x4(&a)[4], const f32x4(&bf)[8]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = mfma16(a[mi][q], bf[ni][q], acc[mi][ni]);
-    };
-
-    load_stage(0, 0);
-    store_stage(0, 0, 0);
-    load_stage(0, 1);
-    store_stage(0, 0, 1);
-    load_a(a0, 0);
-    __syncthreads();
-
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < ntiles;
-        const int kc = kt * 4;
-        const bool four = kc + 2 < KC;             // this tile holds 4 chunks (else 2)
-        load_b(b0, buf, 0);
-        // chunk 0
-        load_a(a1, kc + 1);
-        load_b(b1, buf, 1);
-        if (more) load_stage(kt + 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (nvalid > 0) mma(a0, b0);
-        // chunk 1
-        load_a(a0, kc + 2);
-        if (four) load_b(b0, buf, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (nvalid > 0) mma(a1, b1);
-        if (more) store_stage(buf ^ 1, kt + 1, 0);
-        if (four) {
-            // chunk 2
-            load_a(a1, kc + 3);
-            load_b(b1, buf, 3);
-            if (more) load_stage(kt + 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (nvalid > 0) mma(a0, b0);
-            // chunk 3
-            load_a(a0, kc + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            if (nvalid > 0) mma(a1, b1);
-            if (more) store_stage(buf ^ 1, kt + 1, 1);
-        } else if (more) {
-            load_stage(kt + 1, 1);
-            store_stage(buf ^ 1, kt + 1, 1);
-        }
-        if (more) __syncthreads();
-    }
-
-    const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        if (mi >= nvalid) continue;
-        const int co = co0 + wm * 64 + mi * 16 + 4 * g;
-        float add[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = 0.f;
-            if (co + r < Cout) {
-                if (bias) v += bias[co + r];
-                if (bb) v += bb[co + r];
-            }
-            add[r] = v;
-        }
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) {
-            const int p = p0 + wn * 128 + ni * 16 + j;
-            if (p >= P) continue;
-            f32x4 v = acc[mi][ni];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] += add[r];
-                if ((act & 0xff) == 1) v[r] = sigmoid_f(v[r]);
-            }
-            float *dst = Y + ((long)b * P + p) * ldy + co;
-            if (co + 3 < Cout) {
-                st4(dst, v);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co + r < Cout) dst[r] = v[r];
-            }
-        }
-    }
-}
-
 #ifdef CASPR_DEBUG_HOOKS
 extern "C" int caspr_debug_gemm_occupancy(void)   // debug build only: resident conv1x1_kernel blocks per CU
 {
@@ -708,22 +523,7 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wp % 16) == 0, "conv1x1: pointers must be 16-byte aligned");
     CASPR_REQUIRE(B <= 65535, "conv1x1: B=%d > 65535", B);
     CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 4 == 0, "conv1x1: in_relu_from=%d must be a non-negative multiple of 4", in_relu_from);
-    const int force = CASPR_DEBUG_ENV_INT("CASPR_GEMM_KERNEL");   // debug build only: 1 = 128-point tiles, 2 = big, 7 = streaming (experiments)
-    const bool use_big = force == 2;   // measured slower than the 2-blocks-per-CU kernel on every shape of this model (profiles/r01_*)
-    if (use_big) {
-        const size_t shmem = 2 * 16 * BIG_NT * 4 * sizeof(float);
-        static CasprLdsOptIn optin;
-        const hipError_t e = caspr_lds_opt_in(optin, (const void *)conv1x1_big_kernel, shmem);
-        if (e != hipSuccess) {
-            caspr_set_error("conv1x1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return CASPR_ELAUNCH;
-        }
-        dim3 gridb(ceil_div(Cout, BIG_MT), ceil_div(P, BIG_NT), B);
-        conv1x1_big_kernel<<<gridb, dim3(256), shmem, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
-                                                                              in_relu_from, Y, ldy, P, Cin, Cout, act);
-        CASPR_CHECK_LAUNCH("conv1x1(big)");
-        return CASPR_OK;
-    }
+    const int force = CASPR_DEBUG_ENV_INT("CASPR_GEMM_KERNEL");   // debug build only: 1 = 128-point tiles, 7 = streaming (experiments)
     const size_t lds_pad = (size_t)CASPR_DEBUG_ENV_INT("CASPR_GEMM_LDS_PAD") * 1024;   // occupancy experiments, debug build only
     CASPR_REQUIRE(ceil_div(P, 128) <= 65535, "conv1x1: P=%d rows per batch entry exceed the grid (split the call)", P);
     // default: the streaming kernel wherever a wave's 32 points and the unrolled K loop are filled; the LDS-tiled kernel

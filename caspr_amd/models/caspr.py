@@ -10,8 +10,6 @@ Training: in train() mode with grad enabled `forward` is differentiable end to e
 with a HIP backward (caspr_amd/train/encoder_grad.py), the latent ODE and the CNF through the discrete RK4 map with
 every matrix product on the HIP kernels (caspr_amd/train/flow_grad.py).
 """
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -111,9 +109,9 @@ class CaSPR(nn.Module):
         log_px = log_py - delta_log_py
         return (-log_px).view((B, T, -1))
 
-    def encode(self, x, _pre=None):
+    def encode(self, x):
         """caspr.py:148-155."""
-        return self.encoder(x) if _pre is None else self.encoder(x, pre=_pre)
+        return self.encoder(x)
 
     def aggregate_and_solve_latent(self, z0, time_tensor):
         """caspr.py:157-183: unique sorted times -> latent ODE -> map back -> concat the static feature.
@@ -177,64 +175,20 @@ class CaSPR(nn.Module):
 
     def reconstruct(self, x, num_points=1024, constant_in_time=False, timestamps=None, max_timestamp=5.0,
                     truncate_std=None, sample_contours=None, y=None):
-        """caspr.py:269-308 -> (y, logp_y, x, tnocs_pred).
-
-        Sequences are independent on this path, so a batch of >= 2 * `pipeline_min_chunk` sequences can be
-        run as two halves (opt-in, see `pipeline_min_chunk`): the latent ODE of one half -- a serial chain of tiny evaluations that occupies ONE compute
-        unit for ~4 ms -- runs on a side stream underneath the encoder / CNF kernels of the other half.  Same kernels,
-        same per-sequence arithmetic, identical results; only the schedule changes."""
+        """caspr.py:269-308 -> (y, logp_y, x, tnocs_pred).  `y` (B,T,num_points,3) optionally supplies the base samples."""
         with torch.no_grad():
             B, T, N, _ = x.size()
             if timestamps is None:
                 all_times = x[:, :, 0, 3] / max_timestamp
             else:
                 all_times = timestamps.view((1, -1)).repeat((B, 1)).to(x)
-            chunks = [(0, B)]
-            if x.is_cuda and B >= 2 * self.pipeline_min_chunk:
-                chunks = [(0, B // 2), (B // 2, B)]
-            if len(chunks) == 1:
-                z0, tnocs_pred = self.encode(x)
-                with ops.timed("latent"):
-                    z = self.aggregate_and_solve_latent(z0, all_times)
-                with ops.timed("decode"):
-                    y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y)
-                return y, logp_y, x, tnocs_pred
-            # the base samples are drawn for the whole batch at once (same CPU-generator consumption as the reference)
-            Tz = all_times.shape[1]
-            y_all = self._base_samples(B, Tz, num_points, constant_in_time, truncate_std, sample_contours, y, x)
-            y_all = y_all.view(B, Tz, num_points, -1)
-            main = torch.cuda.current_stream()
-            side = self._latent_stream(x.device)
-            enc, lat = [], []
-            handle = self.encoder.launch_indices(x)     # FPS / ball-query / three-NN chain of ALL frames, once, on its side stream
-            for lo, hi in chunks:
-                z0, tn = self.encode(x[lo:hi], _pre=handle.chunk(lo, hi))
-                done = torch.cuda.Event()
-                done.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(done)
-                    with ops.timed("latent"):
-                        z = self.aggregate_and_solve_latent(z0, all_times[lo:hi])
-                    ready = torch.cuda.Event()
-                    ready.record(side)
-                z0.record_stream(side)
-                z.record_stream(main)
-                enc.append(tn)
-                lat.append((z, ready))
-            outs = []
-            for (lo, hi), (z, ready) in zip(chunks, lat):
-                main.wait_event(ready)
-                with ops.timed("decode"):
-                    outs.append(self.decode(z, num_points, y=y_all[lo:hi]))
-            y_out = torch.cat([o[0] for o in outs], dim=0)
-            logp_y = torch.cat([o[1] for o in outs], dim=0)
-            x_out = torch.cat([o[2] for o in outs], dim=0)
-            tnocs_pred = None if enc[0] is None else torch.cat(enc, dim=0)
-            return y_out, logp_y, x_out, tnocs_pred
+            z0, tnocs_pred = self.encode(x)
+            with ops.timed("latent"):
+                z = self.aggregate_and_solve_latent(z0, all_times)
+            with ops.timed("decode"):
+                y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y)
+            return y, logp_y, x, tnocs_pred
 
-    # Two-half schedule: off by default.  Measured at cfg-2 (B=16): 130.1 ms/step with it (min chunk 4) vs 131.1 without --
-    # the ~3.9 ms latent ODE disappears under the other half, but the half-size encoder / CNF launches lose 2.6 ms to
-    # their tails and the dominant kernel drops from 0.863 to 0.856 of the MFMA peak.  CASPR_PIPELINE_MIN_CHUNK=4 turns it on.
     def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16), num_points=512, timestamps=None, max_timestamp=5.0):
         """Pick the CNF's fixed RK4 step count the way an adaptive solver picks its step: by an error estimate on the
         actual weights and input.  Decodes the first sequence of `x` with S and 2S steps (same base samples) for each
@@ -261,13 +215,3 @@ class CaSPR(nn.Module):
             b.rk4_steps = chosen
         self.cnf_args.rk4_steps = chosen
         return chosen, diffs
-
-    pipeline_min_chunk = int(os.environ.get("CASPR_PIPELINE_MIN_CHUNK", str(1 << 30)))
-
-    def _latent_stream(self, device):
-        key = (device.type, device.index)
-        if not hasattr(self, "_lat_streams"):
-            self._lat_streams = {}
-        if key not in self._lat_streams:
-            self._lat_streams[key] = torch.cuda.Stream(device=device)
-        return self._lat_streams[key]

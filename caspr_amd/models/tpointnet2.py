@@ -28,27 +28,6 @@ def _tensors(obj):
             yield from _tensors(v)
 
 
-def _slice_tree(obj, lo, hi):
-    if torch.is_tensor(obj):
-        return obj[lo:hi]
-    if isinstance(obj, dict):
-        return {k: _slice_tree(v, lo, hi) for k, v in obj.items()}
-    if isinstance(obj, (list, tuple)):
-        return type(obj)(_slice_tree(v, lo, hi) for v in obj)
-    return obj
-
-
-class _IndexHandle:
-    """Index tensors of a whole batch (leading dimension = frames), sliceable by sequence range."""
-
-    def __init__(self, xyz, feat, idx, done, T):
-        self.xyz, self.feat, self.idx, self.done, self.T = xyz, feat, idx, done, T
-
-    def chunk(self, lo, hi):
-        a, b = lo * self.T, hi * self.T
-        return self.xyz[a:b], self.feat[a:b], _slice_tree(self.idx, a, b), self.done
-
-
 class TPointNet2(nn.Module):
     def __init__(self, radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], local_feat_size=512, out_feat_size=1600,
                  augment_quad=True, augment_pairs=True, tnocs_point_size=4, regress_tnocs=True):
@@ -109,27 +88,8 @@ class TPointNet2(nn.Module):
                                  lambda: ops.PackedWeight(self.conv3.weight.detach()[:, :, 0].contiguous()))
         return p1, p2, p3
 
-    def launch_indices(self, x):
-        """Start the index chain of the local branch (FPS / ball query / three-NN of every level: functions of the
-        coordinates only) for x (B,T,N,4) on the side stream.  Returns a handle for forward(x_chunk, pre=handle.chunk(lo, hi)):
-        a caller that runs the batch in several pieces (CaSPR.reconstruct) pays the chain's latency once."""
-        B, T, N, _ = x.size()
-        x = x.contiguous().float()
-        xyz, feat = ops.prep_input(x, self.augment_quad, self.augment_pairs)
-        main = torch.cuda.current_stream()
-        side = self._side_stream(x.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            idx = self.local_extract.indices(xyz)
-            done = torch.cuda.Event()
-            done.record(side)
-        for t_ in _tensors(idx):
-            t_.record_stream(main)
-        return _IndexHandle(xyz, feat, idx, done, T)
-
-    def forward(self, x, pre=None):
-        """x (B,T,N,4) -> z0 (B, out_feat_size), tnocs (B,T,N,4) | None   (tpointnet2.py:70-115).
-        pre: optional index handle from launch_indices (inference only)."""
+    def forward(self, x):
+        """x (B,T,N,4) -> z0 (B, out_feat_size), tnocs (B,T,N,4) | None   (tpointnet2.py:70-115)."""
         if not x.is_cuda:
             raise ValueError("caspr_amd.TPointNet2 runs on the GPU only (HIP kernels); got a %s tensor" % x.device)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -147,26 +107,19 @@ class TPointNet2(nn.Module):
         # underneath the MFMA-bound global PointNet below.
         C = (3 if self.augment_quad else 0) + (3 if self.augment_pairs else 0)
         main = torch.cuda.current_stream()
-        if pre is None:
-            xyz, feat = ops.prep_input(x, self.augment_quad, self.augment_pairs)
-            side = self._side_stream(x.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                idx = self.local_extract.indices(xyz)
-            ready = None
-        else:
-            xyz, feat, idx, ready = pre
+        xyz, feat = ops.prep_input(x, self.augment_quad, self.augment_pairs)
+        side = self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            idx = self.local_extract.indices(xyz)
         if C == 0:
             feat = None
         # global spatio-temporal feature (tpointnet2.py:75-76)
         with ops.timed("enc_global_pointnet"):
             pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
-        if ready is None:
-            main.wait_stream(side)
-            for t_ in _tensors(idx):
-                t_.record_stream(main)
-        else:
-            main.wait_event(ready)
+        main.wait_stream(side)
+        for t_ in _tensors(idx):
+            t_.record_stream(main)
         # local spatial feature per time step (tpointnet2.py:79-93)
         with ops.timed("enc_local_pointnet2"):
             kind = (ops.FEAT_QUAD if self.augment_quad else 0) | (ops.FEAT_PAIRS if self.augment_pairs else 0)
