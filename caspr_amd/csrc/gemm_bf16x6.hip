@@ -2,7 +2,12 @@
 // (ops.CONV_BF16X6; the f32 MFMA kernels of gemm.hip take the shapes it does not cover and the "f32" mode).  Same contract
 // as caspr_conv1x1_f32.
 //
-// Measured and dropped (round 2): a double-buffered form -- 8 waves (4 x 2, wave tile 64 x 64), two 72 KB LDS stages, one
+// Measured and dropped (round 2, tools/conv_x6_trace.py; DESIGN.md section 3 has the per-phase cycle counts): (a) one workgroup
+// per CU with both operands double-buffered and every transfer inside the product stream (5,700 cycles per 192 MFMAs: a single
+// wave per SIMD pays each LDS-DMA issue and each VALU instruction beyond the MFMA shadow in its own stream); (b) the same with
+// eight waves / 256 points and one activation buffer (9,000 cycles per 2 x 192 MFMAs per SIMD); (c) a ping-pong of two four-wave
+// groups, one multiplying while the other stages: the staging wave's ~250 VALU instructions get about ONE issue slot per MFMA of
+// its partner (4,000 cycles, s_setprio makes no difference), so the phases do not shorten.  (d) a double-buffered form -- 8 waves (4 x 2, wave tile 64 x 64), two 72 KB LDS stages, one
 // barrier per K chunk with the next chunk's DMA / split-store under the current chunk's MFMAs -- ran 183 f32-equivalent
 // TFLOP/s on the 1600 x 1600 head layer against 198 for this kernel (same box, random data): the smaller wave tile reads 30 %
 // more fragments per MFMA and eight waves meet one barrier; two independent workgroups per CU already hide each other's
@@ -25,6 +30,7 @@
 // window (swz = 0,3,2,1 per row QUAD, as in ode_bf16x6.hip, is conflict-free for the reads only: 21 % of this
 // kernel's LDS cycles were store conflicts, profiles/r01_bf16x6_optin_pmc_summary.txt).
 #include "common.h"
+#include <type_traits>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -92,14 +98,25 @@ __global__ void pack_weight_bf16x3_kernel(const float *__restrict__ w, int ldw, 
     }
 }
 
-template <bool FUSED>
+// STATS: the GroupNorm that follows the conv (conv -> GroupNorm -> ReLU is the model's building block) gets its statistics
+// from the accumulators instead of a second pass over the output: every workgroup tile leaves, per output channel, the sum,
+// the sum of squares, the max and the min over its 128 points (f32; one float4 per (batch entry, point tile, channel) in
+// `part`), conv_gn_finalize_kernel folds them in f64 in a fixed order.  Y may then be NULL (only the statistics are wanted:
+// the global PointNet's last layer, whose output is max-pooled).
+template <bool FUSED, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned char *__restrict__ wpk, const float *__restrict__ bias,
                                                                 const float *__restrict__ bbias, const float *__restrict__ X,
                                                                 int ldx, const float *__restrict__ in_scale,
                                                                 const float *__restrict__ in_shift, int in_relu, int relu_from,
                                                                 float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int act,
-                                                                int Mt, int Pt)
+                                                                int Mt, int Pt, f32x4 *__restrict__ part, unsigned long long *trace)
 {
+    // debug build (tools/conv_x6_trace.py): s_memtime stamps of workgroup 0, thread 0, five per K chunk
+#ifdef CASPR_DEBUG_HOOKS
+#define X6_STAMP(i) if (trace && blockIdx.x == 0 && threadIdx.x == 0 && (i) < 160) trace[i] = __builtin_amdgcn_s_memtime();
+#else
+#define X6_STAMP(i)
+#endif
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char *sA = lds;
     unsigned char *sB = lds + 3 * X6_PA;
@@ -118,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     // the last channel tile may be mostly padding (zero rows in the pack): a wave without real channels skips the products
     const int co_w = mt * X6_TM + wm * 128;
     const bool live = co_w < Cout;   // wave-uniform; a dead wave only stages and meets the barriers
+    const bool half = co_w + 64 >= Cout;   // at most four of the wave's eight row tiles hold real channels (1600 = 6 x 256 + 64)
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -175,43 +193,74 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     dma(0);
     lstore(0);
     __syncthreads();
+    // the K loop, for a wave with NMI live row tiles (two whole copies: a branch inside the loop sends registers to scratch)
+    auto kloop = [&](auto nmi) __attribute__((always_inline)) {
     for (int kc = 0; kc < nk; ++kc) {
         const int kn = kc + 1 < nk ? kc + 1 : kc;   // unconditional re-load at the end (a branch here sends registers to scratch)
+        X6_STAMP(5 * kc)
         gload(kn);
         if (live) {
-            bf16x8 bf[3][4];
+            constexpr int NMI = decltype(nmi)::value;
+            // B fragments of the chunk, then the row tiles: the three A-fragment reads of tile mi+1 are issued between the first
+            // MFMAs of tile mi (two fragment sets; sched_group_barrier pins the pattern, hipcc on its own puts every read right in
+            // front of its use and the wave sits out the LDS latency eight times per chunk)
+            bf16x8 bf[3][4], af[2][3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) bf[pl][ni] = *(const bf16x8 *)(sB + pl * X6_PB + x6_off(wn * 64 + ni * 16 + j, g));
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                bf16x8 af[3];
+            for (int pl = 0; pl < 3; ++pl) af[0][pl] = *(const bf16x8 *)(sA + pl * X6_PA + x6_off(wm * 128 + j, g));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[pl] = *(const bf16x8 *)(sA + pl * X6_PA + x6_off(wm * 128 + mi * 16 + j, g));
+            for (int mi = 0; mi < NMI; ++mi) {
+                const bf16x8 (&a)[3] = af[mi & 1];
+                if (mi + 1 < NMI) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) af[(mi + 1) & 1][pl] = *(const bf16x8 *)(sA + pl * X6_PA + x6_off(wm * 128 + (mi + 1) * 16 + j, g));
+                }
                 // smallest terms first; term-major so four independent accumulators sit between dependent MFMAs
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bf[0][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bf[1][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[2][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bf[0][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[1][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bf[0][ni], acc[mi][ni], 0, 0, 0);
+                if (mi + 1 < NMI) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 21, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        X6_STAMP(5 * kc + 1)
         __syncthreads();
+        X6_STAMP(5 * kc + 2)
         dma(kn);
         lstore(kn);
+        X6_STAMP(5 * kc + 3)
         __syncthreads();
+        X6_STAMP(5 * kc + 4)
     }
+    };
+    if (half) kloop(std::integral_constant<int, 4>());
+    else kloop(std::integral_constant<int, 8>());
 
     // epilogue: lane holds channels co + r (D row = 4g + r) of point p (column j); Cout % 4 == 0
     const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
+    f32x4 *sp = (f32x4 *)lds;   // STATS: [2 point halves][256 channels] {sum, sum of squares, max, min}; the K loop ends on a barrier
+    if (STATS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of the loop's last (repeated) stage targets the same LDS
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int co = co_w + mi * 16 + 4 * g;
@@ -219,15 +268,108 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
         f32x4 add = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (bias) add += ld4(bias + co);
         if (bb) add += ld4(bb + co);
+        f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f}, q4 = s4;
+        f32x4 mx = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int p = p0 + wn * 64 + ni * 16 + j;
             f32x4 v = acc[mi][ni] + add;
+            if (STATS) {
+                s4 += v;
+                q4 += v * v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mx[r] = fmaxf(mx[r], v[r]);
+                    mn[r] = fminf(mn[r], v[r]);
+                }
+            }
             if ((act & 0xff) == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = sigmoid_f(v[r]);
             }
-            st4(Y + ((long)b * P + p) * ldy + co, v);
+            if (!STATS || Y) st4(Y + ((long)b * P + p) * ldy + co, v);
+        }
+        if (STATS) {
+            // over the tile's 16 columns: four DPP steps inside the 16-lane row
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s4[r] = row_allreduce_add<16>(s4[r]);
+                q4[r] = row_allreduce_add<16>(q4[r]);
+                mx[r] = row_allreduce_max<16>(mx[r]);
+                mn[r] = -row_allreduce_max<16>(-mn[r]);
+            }
+            if (j < 4) {
+                const float ss = j == 0 ? s4[0] : (j == 1 ? s4[1] : (j == 2 ? s4[2] : s4[3]));
+                const float qq = j == 0 ? q4[0] : (j == 1 ? q4[1] : (j == 2 ? q4[2] : q4[3]));
+                const float m1 = j == 0 ? mx[0] : (j == 1 ? mx[1] : (j == 2 ? mx[2] : mx[3]));
+                const float m0 = j == 0 ? mn[0] : (j == 1 ? mn[1] : (j == 2 ? mn[2] : mn[3]));
+                sp[wn * X6_TM + wm * 128 + mi * 16 + 4 * g + j] = (f32x4){ss, qq, m1, m0};
+            }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        const int co = mt * X6_TM + tid;
+        if (co < Cout) {
+            const f32x4 a0 = sp[tid], a1 = sp[X6_TM + tid];
+            part[((long)b * Pt + pt) * Cout + co] = (f32x4){a0[0] + a1[0], a0[1] + a1[1], fmaxf(a0[2], a1[2]), fminf(a0[3], a1[3])};
+        }
+    }
+}
+
+// Folds the per-tile statistics of a STATS conv: one workgroup per (group, batch entry) sums the tiles' channel sums in f64
+// (a thread's elements and the tree over threads are fixed by (P, C, G) only: a batch entry's result does not depend on the
+// batch it sits in), then emits what caspr_gn_stats_f32 does: scale / shift per (b, c), optionally the max over points of the
+// normalised output (from the channel's raw max or min, by the sign of its scale) and the moments.
+__global__ __launch_bounds__(256) void conv_gn_finalize_kernel(const f32x4 *__restrict__ part, int PT, int P, int C, int G,
+                                                               const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                               float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ pmax,
+                                                               float *__restrict__ mean_out, float *__restrict__ rstd_out)
+{
+    __shared__ double s_sum[256], s_sq[256];
+    const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, tid = threadIdx.x;
+    const f32x4 *base = part + (long)b * PT * C + g * cpg;
+    double sum = 0.0, sq = 0.0;
+    const int total = PT * cpg;
+    for (int e = tid; e < total; e += 256) {
+        const int pt = e / cpg, cc = e - pt * cpg;
+        const f32x4 v = base[(long)pt * C + cc];
+        sum += (double)v[0];
+        sq += (double)v[1];
+    }
+    s_sum[tid] = sum;
+    s_sq[tid] = sq;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) {
+            s_sum[tid] += s_sum[tid + off];
+            s_sq[tid] += s_sq[tid + off];
+        }
+        __syncthreads();
+    }
+    const double cnt = (double)P * cpg;
+    const double mean = s_sum[0] / cnt;
+    double var = s_sq[0] / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    if (mean_out && tid == 0) {
+        mean_out[b * G + g] = (float)mean;
+        rstd_out[b * G + g] = (float)rstd;
+    }
+    for (int cc = tid; cc < cpg; cc += 256) {
+        const int c = g * cpg + cc;
+        const float sc = (float)((double)gamma[c] * rstd);
+        const float sf = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+        scale[(long)b * C + c] = sc;
+        shift[(long)b * C + c] = sf;
+        if (pmax) {
+            float m1 = -INFINITY, m0 = INFINITY;
+            for (int pt = 0; pt < PT; ++pt) {
+                const f32x4 v = base[(long)pt * C + cc];
+                m1 = fmaxf(m1, v[2]);
+                m0 = fminf(m0, v[3]);
+            }
+            pmax[(long)b * C + c] = (sc >= 0.f ? m1 : m0) * sc + sf;
         }
     }
 }
@@ -249,15 +391,20 @@ extern "C" int caspr_pack_weight_bf16x3(const float *w, int ldw, int Cout, int c
     return CASPR_OK;
 }
 
-extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
-                                        const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
-                                        int ldy, int B, int P, int Cin, int Cout, int act, void *stream)
+#ifdef CASPR_DEBUG_HOOKS
+static unsigned long long *g_conv_x6_trace = nullptr;
+extern "C" void caspr_debug_set_conv_x6_trace(unsigned long long *dev_buf) { g_conv_x6_trace = dev_buf; }   // debug build only: >= 160 u64
+#endif
+
+static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx, const float *in_scale,
+                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout,
+                          int act, f32x4 *part, void *stream)
 {
-    CASPR_REQUIRE(wpk && X && Y && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1_bf16x6: bad arguments");
+    CASPR_REQUIRE(wpk && X && (Y || part) && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1_bf16x6: bad arguments");
     CASPR_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && P % X6_TP == 0,
                   "conv1x1_bf16x6: needs Cin %% 32 == 0, Cout %% 4 == 0 and P %% 128 == 0 (Cin=%d Cout=%d P=%d); use caspr_conv1x1_f32", Cin, Cout, P);
     CASPR_REQUIRE(ldx % 4 == 0 && ldx >= Cin, "conv1x1_bf16x6: ldx=%d must be a multiple of 4 and >= Cin=%d", ldx, Cin);
-    CASPR_REQUIRE(ldy % 4 == 0 && ldy >= Cout, "conv1x1_bf16x6: ldy=%d must be a multiple of 4 and >= Cout=%d", ldy, Cout);
+    CASPR_REQUIRE(!Y || (ldy % 4 == 0 && ldy >= Cout), "conv1x1_bf16x6: ldy=%d must be a multiple of 4 and >= Cout=%d", ldy, Cout);
     CASPR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_bf16x6: in_scale/in_shift must be given together");
     CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wpk % 16) == 0, "conv1x1_bf16x6: pointers must be 16-byte aligned");
     CASPR_REQUIRE((bias == nullptr || ((uintptr_t)bias % 16) == 0) && (bbias == nullptr || ((uintptr_t)bbias % 16) == 0),
@@ -266,19 +413,60 @@ extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, cons
     const int Mt = ceil_div(Cout, X6_TM), Pt = P / X6_TP;
     const long nblk = (long)Mt * Pt * B;
     CASPR_REQUIRE(nblk < (1L << 31), "conv1x1_bf16x6: too many tiles (%ld)", nblk);
-    static CasprLdsOptIn optin_t, optin_f;
-    const hipError_t e1 = caspr_lds_opt_in(optin_t, (const void *)conv1x1_bf16x6_kernel<true>, X6_LDS);
-    const hipError_t e2 = caspr_lds_opt_in(optin_f, (const void *)conv1x1_bf16x6_kernel<false>, X6_LDS);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-        caspr_set_error("conv1x1_bf16x6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    unsigned long long *trace = nullptr;
+    CASPR_IF_DEBUG(trace = g_conv_x6_trace;)
+    static CasprLdsOptIn optin[4];
+    const void *kern[4] = {(const void *)conv1x1_bf16x6_kernel<false, false>, (const void *)conv1x1_bf16x6_kernel<true, false>,
+                           (const void *)conv1x1_bf16x6_kernel<false, true>, (const void *)conv1x1_bf16x6_kernel<true, true>};
+    const int which = (in_scale ? 1 : 0) + (part ? 2 : 0);
+    const hipError_t e1 = caspr_lds_opt_in(optin[which], kern[which], X6_LDS);
+    if (e1 != hipSuccess) {
+        caspr_set_error("conv1x1_bf16x6: hipFuncSetAttribute failed: %s", hipGetErrorString(e1));
         return CASPR_ELAUNCH;
     }
-    if (in_scale)
-        conv1x1_bf16x6_kernel<true><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(
-            (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt);
-    else
-        conv1x1_bf16x6_kernel<false><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(
-            (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt);
+#define X6_LAUNCH(F, S)                                                                                                          \
+    conv1x1_bf16x6_kernel<F, S><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(                                \
+        (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt, part, trace)
+    if (which == 0) X6_LAUNCH(false, false);
+    else if (which == 1) X6_LAUNCH(true, false);
+    else if (which == 2) X6_LAUNCH(false, true);
+    else X6_LAUNCH(true, true);
+#undef X6_LAUNCH
     CASPR_CHECK_LAUNCH("conv1x1_bf16x6");
+    return CASPR_OK;
+}
+
+extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
+                                        const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
+                                        int ldy, int B, int P, int Cin, int Cout, int act, void *stream)
+{
+    CASPR_REQUIRE(Y, "conv1x1_bf16x6: Y is NULL");
+    return conv_x6_launch(wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, act, nullptr, stream);
+}
+
+extern "C" long caspr_conv_gn_ws_bytes(int B, int P, int Cout)
+{
+    if (B <= 0 || P <= 0 || Cout <= 0 || P % X6_TP) return 0;
+    return (long)B * (P / X6_TP) * Cout * 16;
+}
+
+extern "C" int caspr_conv1x1_gn_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
+                                           const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
+                                           int ldy, int B, int P, int Cin, int Cout, int G, const float *gamma, const float *beta,
+                                           float eps, float *scale, float *shift, float *pmax, float *mean, float *rstd, void *ws,
+                                           long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(gamma && beta && scale && shift && ws && G > 0, "conv1x1_gn_bf16x6: bad arguments");
+    CASPR_REQUIRE(Cout % G == 0, "conv1x1_gn_bf16x6: Cout=%d is not a multiple of the %d groups", Cout, G);
+    CASPR_REQUIRE((mean == nullptr) == (rstd == nullptr), "conv1x1_gn_bf16x6: mean / rstd must be given together");
+    CASPR_REQUIRE(B <= 65535, "conv1x1_gn_bf16x6: B too large");
+    CASPR_REQUIRE(P % X6_TP == 0 && ws_bytes >= caspr_conv_gn_ws_bytes(B, P, Cout) && ((uintptr_t)ws % 16) == 0,
+                  "conv1x1_gn_bf16x6: workspace too small or misaligned (%ld < %ld)", ws_bytes, caspr_conv_gn_ws_bytes(B, P, Cout));
+    const int rc = conv_x6_launch(wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, 0,
+                                  (f32x4 *)ws, stream);
+    if (rc != CASPR_OK) return rc;
+    conv_gn_finalize_kernel<<<dim3(G, B), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, P / X6_TP, P, Cout, G, gamma, beta, eps,
+                                                                               scale, shift, pmax, mean, rstd);
+    CASPR_CHECK_LAUNCH("conv1x1_gn_bf16x6");
     return CASPR_OK;
 }

@@ -38,6 +38,9 @@ SIGNATURES = {
     "caspr_bf16x3_packed_bytes": (c_long, [c_int, c_int]),
     "caspr_pack_weight_bf16x3": (c_int, [c_fp, c_int, c_int, c_int, c_int, ctypes.c_void_p, c_stream]),
     "caspr_conv1x1_bf16x6_f32": (c_int, [ctypes.c_void_p, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_stream]),
+    "caspr_conv_gn_ws_bytes": (c_long, [c_int, c_int, c_int]),
+    "caspr_conv1x1_gn_bf16x6_f32": (c_int, [ctypes.c_void_p, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_fp, c_int, c_int, c_int, c_int, c_int,
+                                            c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_gn_ws_bytes": (c_long, [c_int, c_int, c_int, c_int]),
     "caspr_gn_stats_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_latent_rk4_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_stream]),

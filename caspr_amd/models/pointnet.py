@@ -38,8 +38,9 @@ class PointNetfeat(nn.Module):
         s1, t1 = ops.gn_stats(y1, c1.out_channels, self.bn1.weight, self.bn1.bias)
         y2 = ops.conv1x1(self._packed("conv2"), c2.bias, y1, in_scale=s1, in_shift=t1, in_relu=True)  # :39
         s2, t2 = ops.gn_stats(y2, c2.out_channels, self.bn2.weight, self.bn2.bias)
-        y3 = ops.conv1x1(self._packed("conv3"), c3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True)  # :40
-        _, _, gmax = ops.gn_stats(y3, c3.out_channels, self.bn3.weight, self.bn3.bias, want_max=True)  # :41-42
+        # conv3 -> bn3 -> max over points (:40-42): only the pooled maximum is used, so the 1024-channel output is not stored
+        _, _, _, gmax = ops.conv1x1_gn(self._packed("conv3"), c3.bias, y2, self.bn3.weight, self.bn3.bias, want_max=True, write=False,
+                                       in_scale=s2, in_shift=t2, in_relu=True)
         return Lazy(y1, c1.out_channels, s1, t1, True), gmax
 
     def forward(self, x):

@@ -158,6 +158,13 @@ class PointNet2SetAbstraction(nn.Module):
         ball = [ops.ball_query(g.radius, ns, xyz, new_xyz) for g, ns in zip(self.grouper_modules, self.layers)]  # :391
         return {"fps_idx": fps_idx, "new_xyz": new_xyz, "ball_idx": ball}
 
+    @staticmethod
+    def _await(idx):
+        """When the indices were computed on another stream (PointNet2feat.indices(events=True)), wait for THIS level's."""
+        ev = idx.get("ready")
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def run(self, xyz, feat, C, record=None, idx=None, feat_kind=0):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels (or None).
         -> new_xyz (B,M,3), new_feat (B,M,Cout).  `idx` = precomputed self.indices(xyz); feat_kind: see ops.sa_mlp_max."""
@@ -165,6 +172,7 @@ class PointNet2SetAbstraction(nn.Module):
         M = self.num_points_out
         if idx is None:
             idx = self.indices(xyz)
+        self._await(idx)
         new_xyz = idx["new_xyz"]
         out = torch.empty(B, M, self.get_num_features_out(), device=xyz.device, dtype=torch.float32)
         off = 0
@@ -208,22 +216,33 @@ class PointNet2FeaturePropagator(nn.Module):
     def get_num_features_out(self):
         return self.layer_dims[-1]
 
-    def _packed(self, i):
+    def _packed(self, i, cin_pad=None):
+        """cin_pad: the conv's input width padded with zero columns (a multiple of 32, for the bf16x6 kernel)."""
         conv = self.unit_pointnet[i]
-        return self._cache.get(i, [conv.weight], lambda: ops.PackedWeight(conv.weight.detach()[:, :, 0].contiguous()))
+
+        def build():
+            w = conv.weight.detach()[:, :, 0]
+            if cin_pad is not None and cin_pad > w.shape[1]:
+                w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[1]))
+            return ops.PackedWeight(w.contiguous())
+        return self._cache.get((i, cin_pad), [conv.weight], build)
 
     def run(self, xyz, xyz_prev, feat, C, prev: Lazy, nn=None):
         """Point-major core.  feat (B,n,ldf) skip features with C valid channels (or None); prev = Lazy
         features of the coarser level; nn = precomputed ops.three_nn(xyz, xyz_prev, with_weights=True).  -> Lazy (B,n,Cout)."""
         _, idx, w = nn if nn is not None else ops.three_nn(xyz, xyz_prev, with_weights=True)    # pointnet2.py:514-518
+        # an input width the bf16x6 conv cannot take (518 at the finest level) is padded with zero columns to a multiple of 32
+        cin = prev.channels + C
+        pad = ops.CONV_BF16X6 and cin % 32 != 0 and cin >= 192 and idx.shape[1] % 128 == 0
         x = ops.three_interpolate(prev.raw, idx, w, skip=feat, skip_channels=C, in_scale=prev.scale,
-                                  in_shift=prev.shift, in_relu=prev.relu, C=prev.channels)      # :519-523
-        cur = Lazy(x, prev.channels + C)
+                                  in_shift=prev.shift, in_relu=prev.relu, C=prev.channels, align=32 if pad else 4)   # :519-523
+        cur = Lazy(x, cin)
         n_layers = len(self.layer_dims)
         for l in range(n_layers):                                                               # :525
             conv, gn = self.unit_pointnet[3 * l], self.unit_pointnet[3 * l + 1]
-            y = ops.conv1x1(self._packed(3 * l), conv.bias, cur.raw, in_scale=cur.scale, in_shift=cur.shift, in_relu=cur.relu)
-            s, t = ops.gn_stats(y, conv.out_channels, gn.weight, gn.bias)
+            pw = self._packed(3 * l, x.shape[2]) if (pad and l == 0) else self._packed(3 * l)
+            y, s, t = ops.conv1x1_gn(pw, conv.bias, cur.raw, gn.weight, gn.bias, in_scale=cur.scale, in_shift=cur.shift,
+                                     in_relu=cur.relu)
             cur = Lazy(y, conv.out_channels, s, t, True)
         return cur
 
@@ -291,13 +310,18 @@ class PointNet2feat(nn.Module):
         conv = self.final_layers[i]
         return self._cache.get(i, [conv.weight], lambda: ops.PackedWeight(conv.weight.detach()[:, :, 0].contiguous()))
 
-    def indices(self, xyz):
+    def indices(self, xyz, events=False):
         """Every index tensor of the level stack -- FPS, ball queries, three-NN + weights -- depends on the
         coordinates only.  Computing them up front lets the caller run this latency-bound chain (1,872 dependent
-        FPS rounds per frame, one small workgroup per frame) on a side stream under the MFMA-bound kernels."""
+        FPS rounds per frame, one small workgroup per frame) on a side stream under the MFMA-bound kernels.
+        events=True (called on that side stream): every level's dict carries a "ready" event, so the consumer starts a level's
+        set abstraction as soon as ITS indices exist while the chain continues underneath (run() waits per level)."""
         sa_idx, xyz_list = [], [xyz]
         for sa in self.set_abstractions:
             d = sa.indices(xyz_list[-1])
+            if events:
+                d["ready"] = torch.cuda.Event()
+                d["ready"].record()
             sa_idx.append(d)
             xyz_list.append(d["new_xyz"])
         nn = []
@@ -305,7 +329,11 @@ class PointNet2feat(nn.Module):
         for _ in self.feature_propagators:
             nn.append(ops.three_nn(xyz_list[target], xyz_list[target + 1], with_weights=True))
             target -= 1
-        return {"sa": sa_idx, "nn": nn}
+        out = {"sa": sa_idx, "nn": nn}
+        if events:
+            out["nn_ready"] = torch.cuda.Event()
+            out["nn_ready"].record()
+        return out
 
     def run(self, xyz, feat, C, out=None, record=None, idx=None, feat_kind=0):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels.  -> (B,n,num_classes)
@@ -322,12 +350,14 @@ class PointNet2feat(nn.Module):
             ch_list.append(C)
         prev = Lazy(feat_list[-1], ch_list[-1])
         target = -2
+        if idx.get("nn_ready") is not None:
+            torch.cuda.current_stream().wait_event(idx["nn_ready"])
         for l, fp in enumerate(self.feature_propagators):                                       # :238-245
             prev = fp.run(xyz_list[target], xyz_list[target + 1], feat_list[target], ch_list[target], prev, idx["nn"][l])
             target -= 1
         c0, gn, c3 = self.final_layers[0], self.final_layers[1], self.final_layers[3]
-        y = ops.conv1x1(self._packed_final(0), c0.bias, prev.raw, in_scale=prev.scale, in_shift=prev.shift, in_relu=prev.relu)
-        s, t = ops.gn_stats(y, c0.out_channels, gn.weight, gn.bias)
+        y, s, t = ops.conv1x1_gn(self._packed_final(0), c0.bias, prev.raw, gn.weight, gn.bias, in_scale=prev.scale, in_shift=prev.shift,
+                                 in_relu=prev.relu)
         return ops.conv1x1(self._packed_final(3), c3.bias, y, in_scale=s, in_shift=t, in_relu=True, out=out)  # :247
 
     def forward(self, points):

@@ -111,13 +111,13 @@ class TPointNet2(nn.Module):
         side = self._side_stream(x.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            idx = self.local_extract.indices(xyz)
+            idx = self.local_extract.indices(xyz, events=True)
         if C == 0:
             feat = None
         # global spatio-temporal feature (tpointnet2.py:75-76)
         with ops.timed("enc_global_pointnet"):
             pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
-        main.wait_stream(side)
+        # no join here: local_extract.run waits for each level's indices where it uses them
         for t_ in _tensors(idx):
             t_.record_stream(main)
         # local spatial feature per time step (tpointnet2.py:79-93)
@@ -133,12 +133,11 @@ class TPointNet2(nn.Module):
         ones = torch.ones(B, L, device=x.device, dtype=torch.float32)
         in_scale = torch.cat([ones, pf.scale], dim=1).contiguous()
         in_shift = torch.cat([torch.zeros_like(ones), pf.shift], dim=1).contiguous()
-        y1 = ops.conv1x1(w_pt, None, X1, bbias=bbias.view(B, -1), in_scale=in_scale, in_shift=in_shift,
-                         in_relu=True, in_relu_from=L)
-        s1, t1 = ops.gn_stats(y1, self.conv1.out_channels, self.bn1.weight, self.bn1.bias)
-        y2 = ops.conv1x1(p2, self.conv2.bias, y1, in_scale=s1, in_shift=t1, in_relu=True)     # :99-100
+        y1, s1, t1 = ops.conv1x1_gn(w_pt, None, X1, self.bn1.weight, self.bn1.bias, bbias=bbias.view(B, -1), in_scale=in_scale,
+                                    in_shift=in_shift, in_relu=True, in_relu_from=L)
+        y2, s2, t2, z0 = ops.conv1x1_gn(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, want_max=True,
+                                        in_scale=s1, in_shift=t1, in_relu=True)               # :99-100, 111
         del y1
-        s2, t2, z0 = ops.gn_stats(y2, self.conv2.out_channels, self.bn2.weight, self.bn2.bias, want_max=True)  # :100,111
         tnocs_regression = None
         if self.regress_tnocs:
             t = ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1)  # :105-106

@@ -163,9 +163,9 @@ def three_nn(unknown, known, with_weights=False):
     return (dist, idx, w) if with_weights else (dist, idx)
 
 
-def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale=None, in_shift=None, in_relu=False, C=None):
-    """Point-major `three_interpolate` (+ concat of skip features): feat (B,m,>=C) -> (B,n,roundup4(C+C2))
-    (pointnet2.py:519-523).  in_scale/in_shift (B,C): feat is read as relu(feat*scale+shift)."""
+def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale=None, in_shift=None, in_relu=False, C=None, align=4):
+    """Point-major `three_interpolate` (+ concat of skip features): feat (B,m,>=C) -> (B,n,roundup(C+C2, align))
+    (pointnet2.py:519-523), columns past C+C2 zero.  in_scale/in_shift (B,C): feat is read as relu(feat*scale+shift)."""
     _chk_f32(weight, in_scale, in_shift)
     _chk_i32(idx)
     ldf = _chk_rows(feat)
@@ -174,7 +174,9 @@ def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale
     C = feat.shape[2] if C is None else C
     n = idx.shape[1]
     C2 = 0 if skip is None else (skip.shape[2] if skip_channels is None else skip_channels)
-    ldo = (C + C2 + 3) // 4 * 4
+    if align % 4:
+        raise ValueError("three_interpolate: align must be a multiple of 4")
+    ldo = (C + C2 + align - 1) // align * align
     out = torch.empty(B, n, ldo, device=feat.device, dtype=torch.float32)
     _lib.check(_lib.load().caspr_three_interp_f32(_p(feat), ldf, _p(idx), _p(weight), _p(in_scale), _p(in_shift), int(in_relu),
                                                   _p(skip), lds, B, m, n, C, C2, _p(out), ldo, _stream()),
@@ -199,6 +201,7 @@ if _mode not in ("bf16x6", "f32"):
 CONV_BF16X6 = _mode == "bf16x6"      # pointwise convs (conv1x1) on the bf16x6 kernel where the shape allows
 CNF_BF16X6 = _mode == "bf16x6"       # point-CNF solves on the bf16x6 kernel
 _X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstraction / input layers)
+_X6_GN_MIN_CIN = 128  # conv + GroupNorm statistics in one pass (conv1x1_gn): pays from a smaller width (no second pass over the output)
 
 
 def set_matmul_mode(mode=None, conv=None, cnf=None):
@@ -234,8 +237,9 @@ class PackedWeight:
         _lib.check(_lib.load().caspr_pack_weight_f32(_p(w2d), ldw, self.cout, col0, self.cin, _p(self.data), _stream()),
                    "caspr_pack_weight_f32")
         self.x6_ok = self.cin % 32 == 0 and self.cin >= _X6_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128
+        self.x6_gn_ok = self.cin % 32 == 0 and self.cin >= _X6_GN_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128
         self._x3 = None
-        self._src = (w2d, ldw, col0) if self.x6_ok else None     # kept for the lazy bf16x3 pack
+        self._src = (w2d, ldw, col0) if self.x6_gn_ok else None     # kept for the lazy bf16x3 pack
 
     def x3(self):
         if self._x3 is None:
@@ -299,6 +303,48 @@ def gn_stats(y, C, gamma, beta, groups=16, eps=1e-5, want_max=False):
     _lib.check(_lib.load().caspr_gn_stats_f32(_p(y), ldy, B, P, C, groups, _p(gamma), _p(beta), float(eps), _p(scale), _p(shift), _p(pmax),
                                               _p(ws), ws.numel(), _stream()), "caspr_gn_stats_f32")
     return (scale, shift, pmax) if want_max else (scale, shift)
+
+
+def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, want_moments=False, write=True, bbias=None,
+               in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, out=None):
+    """conv1x1 followed by the statistics of the GroupNorm on its output (the model's conv -> GroupNorm -> ReLU block):
+    -> (y | None, scale (B,C), shift (B,C)[, mean (B,G), rstd (B,G)][, pmax (B,C)]).  On the bf16x6 path the statistics come
+    out of the conv's epilogue (caspr_conv1x1_gn_bf16x6_f32) and `write=False` skips the output altogether; otherwise this is
+    conv1x1 + gn_stats (`write` is then ignored: y is returned)."""
+    _chk_f32(bias, bbias, in_scale, in_shift, gamma, beta)
+    B, P, _ = x.shape
+    C = pw.cout
+    if not (CONV_BF16X6 and pw.x6_gn_ok and P % 128 == 0 and C % groups == 0):
+        y = conv1x1(pw, bias, x, bbias=bbias, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, in_relu_from=in_relu_from, out=out)
+        if want_moments:
+            from . import train_ops
+            return (y,) + tuple(train_ops.gn_stats_train(y, C, gamma, beta, groups, eps, want_max))
+        return (y,) + tuple(gn_stats(y, C, gamma, beta, groups, eps, want_max))
+    ldx = _chk_rows(x)
+    if x.shape[2] < pw.cin and ldx < (pw.cin + 3) // 4 * 4:
+        raise ValueError("conv1x1_gn: input rows hold %d channels, weight needs %d" % (x.shape[2], pw.cin))
+    dev = x.device
+    y = None
+    if write or out is not None:
+        y = out if out is not None else torch.empty(B, P, (C + 3) // 4 * 4, device=dev, dtype=torch.float32)
+    ldy = _chk_rows(y) if y is not None else 0
+    scale = torch.empty(B, C, device=dev, dtype=torch.float32)
+    shift = torch.empty(B, C, device=dev, dtype=torch.float32)
+    mean = torch.empty(B, groups, device=dev, dtype=torch.float32) if want_moments else None
+    rstd = torch.empty(B, groups, device=dev, dtype=torch.float32) if want_moments else None
+    pmax = torch.empty(B, C, device=dev, dtype=torch.float32) if want_max else None
+    L = _lib.load()
+    ws = _workspace(L.caspr_conv_gn_ws_bytes(B, P, C), dev)
+    _lib.check(L.caspr_conv1x1_gn_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                             int(in_relu_from), _p(y), ldy, B, P, pw.cin, C, groups, _p(gamma), _p(beta), float(eps),
+                                             _p(scale), _p(shift), _p(pmax), _p(mean), _p(rstd), _p(ws), ws.numel(), _stream()),
+               "caspr_conv1x1_gn_bf16x6_f32")
+    res = (y, scale, shift)
+    if want_moments:
+        res += (mean, rstd)
+    if want_max:
+        res += (pmax,)
+    return res
 
 
 FEAT_QUAD, FEAT_PAIRS = 1, 2     # include/caspr_hip.h

@@ -64,10 +64,11 @@ class _Grads:
 # conv -> GroupNorm(16) -> ReLU over whole clouds (statistics per batch entry over all its points)
 # ---------------------------------------------------------------------------------------------
 def _conv_gn_fwd(packs, conv, gn, cur, want_max=False, out=None, bbias=None, pw=None, bias="conv", in_relu_from=0):
-    y = ops.conv1x1(pw if pw is not None else packs.fwd(conv), conv.bias if bias == "conv" else None, cur.raw, bbias=bbias,
-                    in_scale=cur.scale, in_shift=cur.shift, in_relu=cur.relu, in_relu_from=in_relu_from, out=out)
     C = conv.out_channels
-    st = T.gn_stats_train(y, C, gn.weight, gn.bias, want_max=want_max)
+    res = ops.conv1x1_gn(pw if pw is not None else packs.fwd(conv), conv.bias if bias == "conv" else None, cur.raw, gn.weight, gn.bias,
+                         want_max=want_max, want_moments=True, bbias=bbias, in_scale=cur.scale, in_shift=cur.shift, in_relu=cur.relu,
+                         in_relu_from=in_relu_from, out=out)
+    y, st = res[0], res[1:]
     rec = {"x": cur, "y": y, "mean": st[2], "rstd": st[3], "conv": conv, "gn": gn, "scale": st[0], "shift": st[1]}
     return Lazy(y, C, st[0], st[1], True), rec, (st[4] if want_max else None)
 

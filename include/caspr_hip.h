@@ -122,12 +122,26 @@ int caspr_conv1x1_f32(const float *wp, const float *bias, const float *bbias, co
  * 1.5-1.8x the rate of the f32 MFMA kernels.  Same argument meaning as caspr_conv1x1_f32; restricted to Cin % 32 == 0,
  * Cout % 4 == 0, P % 128 == 0 and ldx >= Cin (CASPR_EINVAL otherwise: the caller falls back to caspr_conv1x1_f32).
  * wpk = the weight split and packed once by caspr_pack_weight_bf16x3 into caspr_bf16x3_packed_bytes(Cout, Cin)
- * bytes (0 if the shape is not supported).  Opt-in in the Python host (CASPR_CONV_BF16X6=1).                       */
+ * bytes (0 if the shape is not supported).  The Python host's default where the shape allows (ops.set_matmul_mode). */
 long caspr_bf16x3_packed_bytes(int Cout, int Cin);
 int caspr_pack_weight_bf16x3(const float *w, int ldw, int Cout, int col0, int ncols, void *packed, void *stream);
 int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
                              const float *in_scale, const float *in_shift, int in_relu, int in_relu_from,
                              float *Y, int ldy, int B, int P, int Cin, int Cout, int act, void *stream);
+
+/* conv -> GroupNorm statistics in one pass (the model's conv -> GroupNorm -> ReLU blocks: pointnet.py:37-42,
+ * pointnet2.py:575-590 / 247, tpointnet2.py:96-111): caspr_conv1x1_bf16x6_f32 (act = 0) whose epilogue also leaves, per
+ * (batch entry, 128-point tile, output channel), the f32 sum / sum of squares / max / min of the tile's outputs in ws; a
+ * second small kernel folds them in f64 in a fixed order into what caspr_gn_stats_f32 returns for Y: scale, shift (B,Cout),
+ * optionally pmax (B,Cout) and the moments mean / rstd (B,G) (NULL: not wanted).  The 2 x |Y| read pass of caspr_gn_stats_f32
+ * disappears; Y itself may be NULL when only the statistics are needed (pointnet.py:41-42: the output is max-pooled).
+ * ws: caspr_conv_gn_ws_bytes(B, P, Cout) bytes, 16-byte aligned.  Same shape restrictions as caspr_conv1x1_bf16x6_f32.  */
+long caspr_conv_gn_ws_bytes(int B, int P, int Cout);
+int caspr_conv1x1_gn_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
+                                const float *in_scale, const float *in_shift, int in_relu, int in_relu_from,
+                                float *Y, int ldy, int B, int P, int Cin, int Cout, int G, const float *gamma,
+                                const float *beta, float eps, float *scale, float *shift, float *pmax, float *mean,
+                                float *rstd, void *ws, long ws_bytes, void *stream);
 
 /* GroupNorm statistics of Y (B,P,C) (nn.GroupNorm(G,C), biased variance, eps):
  *   scale[b,c] = gamma[c]*rstd[b,g(c)] ; shift[b,c] = beta[c] - mean[b,g(c)]*scale[b,c]

@@ -316,6 +316,55 @@ def test_gn_stats(ops, dev, B, P_, C):
     record("gn_max_C%d" % C, pm, want.max(dim=1)[0], 5e-6)
 
 
+@pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 256, 512, 512), (1, 2560, 1600, 1600), (3, 384, 128, 1024), (2, 128, 544, 512), (1, 200, 512, 512)])
+def test_conv1x1_gn_fused(ops, dev, B, P_, Cin, Cout):
+    """conv -> GroupNorm statistics in one pass (caspr_conv1x1_gn_bf16x6_f32): the statistics taken from the conv's
+    accumulators (f32 per 128-point tile, f64 across tiles) against an f64 GroupNorm of the f64 conv, at gn_stats' tolerance;
+    against the two-pass form (conv1x1 + gn_stats) directly; with and without storing the output; moments for training."""
+    from caspr_amd import train_ops as T
+    w = rnd(1, Cout, Cin, scale=1.0 / np.sqrt(Cin))
+    b, bb = rnd(2, Cout, scale=0.3), rnd(3, B, Cout, scale=0.1)
+    x = rnd(Cin + Cout, B, P_, Cin)
+    sc_in, sh_in = rnd(4, B, Cin).abs() + 0.5, rnd(5, B, Cin)
+    gamma, beta = rnd(6, Cout) * 0.2 + 1.0, rnd(7, Cout) * 0.1
+    gamma[::7] *= -1.0
+    pw = ops.PackedWeight(w.to(dev))
+    xin = torch.relu(x * sc_in.unsqueeze(1) + sh_in.unsqueeze(1))
+    y64 = xin.double() @ w.double().t() + b.double() + bb.double().unsqueeze(1)
+    want = F.group_norm(y64.transpose(1, 2), 16, gamma.double(), beta.double(), 1e-5).transpose(1, 2)
+    kw = dict(bbias=bb.to(dev), in_scale=sc_in.to(dev), in_shift=sh_in.to(dev), in_relu=True)
+    y, sc, sh, mean, rstd, pm = ops.conv1x1_gn(pw, b.to(dev), x.to(dev), gamma.to(dev), beta.to(dev), want_max=True, want_moments=True, **kw)
+    tol_y = 2e-6 * max(1.0, float(y64.abs().max()))
+    record("conv_gn_y_%dx%d" % (Cin, Cout), y[:, :, :Cout], y64, tol_y)
+    got = y64.to(dev) * sc.double().unsqueeze(1) + sh.double().unsqueeze(1)        # the statistics alone, applied to the exact output
+    record("conv_gn_apply_%dx%d" % (Cin, Cout), got, want, 5e-6)
+    record("conv_gn_max_%dx%d" % (Cin, Cout), pm, want.max(dim=1)[0], 5e-6 + 2 * tol_y)
+    m64 = y64.view(B, P_, 16, Cout // 16).transpose(1, 2).reshape(B, 16, -1)
+    record("conv_gn_mean", mean, m64.mean(dim=2), 2e-6)
+    record("conv_gn_rstd", rstd, 1.0 / torch.sqrt(m64.var(dim=2, unbiased=False) + 1e-5), 5e-6 * float((1.0 / torch.sqrt(m64.var(dim=2, unbiased=False) + 1e-5)).max()))
+    # two-pass form on the same conv output
+    y2 = ops.conv1x1(pw, b.to(dev), x.to(dev), **kw)
+    if pw.x6_ok and P_ % 128 == 0:
+        exact("conv_gn_y_same_kernel", y, y2)       # (narrower inputs: conv1x1 alone prefers the f32 kernel)
+    sc2, sh2, mean2, rstd2, pm2 = T.gn_stats_train(y2, Cout, gamma.to(dev), beta.to(dev), want_max=True)
+    record("conv_gn_scale_vs_two_pass", sc, sc2, 2e-6 * float(sc2.abs().max()))
+    record("conv_gn_shift_vs_two_pass", sh, sh2, 2e-6 * max(1.0, float(sh2.abs().max())))
+    # statistics only: no output
+    res = ops.conv1x1_gn(pw, b.to(dev), x.to(dev), gamma.to(dev), beta.to(dev), want_max=True, write=False, **kw)
+    if P_ % 128 == 0:
+        assert res[0] is None
+        exact("conv_gn_nowrite_scale", res[1], sc)
+        exact("conv_gn_nowrite_shift", res[2], sh)
+        exact("conv_gn_nowrite_max", res[3], pm)
+        # a batch entry's statistics do not depend on the batch around it
+        r1 = ops.conv1x1_gn(pw, b.to(dev), x[B - 1:].to(dev).contiguous(), gamma.to(dev), beta.to(dev), want_max=True, bbias=bb[B - 1:].to(dev).contiguous(),
+                            in_scale=sc_in[B - 1:].to(dev).contiguous(), in_shift=sh_in[B - 1:].to(dev).contiguous(), in_relu=True)
+        exact("conv_gn_batch_invariance_scale", r1[1], sc[B - 1:])
+        exact("conv_gn_batch_invariance_max", r1[3], pm[B - 1:])
+    else:
+        assert res[0] is not None       # unsupported row count: conv1x1 + gn_stats
+
+
 # ---------------------------------------------------------------------------------------------
 # fused set-abstraction scale
 # ---------------------------------------------------------------------------------------------
