@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     const float *sc = FUSED ? in_scale + (long)b * Cin + 16 * xh : nullptr;
     const float *sh = FUSED ? in_shift + (long)b * Cin + 16 * xh : nullptr;
     f32x4 xreg[4];
-    const unsigned char *wsrc = wpk + ((long)mt * nk) * X6_CHUNK + (wave * 12) * 1024 + lane * 16;
+    const unsigned char *wsrc = wpk + ((long)mt * nk) * X6_CHUNK + (wave * 12) * 1024;   // wave-uniform; the lane's 16 bytes ride as a
+    const unsigned wlane = lane * 16;                                                    // 32-bit offset (no 64-bit add per transfer)
     auto gload = [&](int kc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) xreg[q] = ld4(xsrc + kc * 32 + 4 * q);
@@ -158,20 +159,34 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     auto dma = [&](int kc) {
 #pragma unroll
         for (int s = 0; s < 12; ++s)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (long)kc * X6_CHUNK + s * 1024),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (long)kc * X6_CHUNK + s * 1024 + wlane),
                                              (__attribute__((address_space(3))) void *)(sA + (wave * 12 + s) * 1024), 16, 0, 0);
+    };
+    // The weight piece goes through registers between the two barriers of a chunk (12 x 16 B per thread: the fragment registers are
+    // free then): an LDS-DMA instruction costs its wave ~125 cycles of issue even on an otherwise idle CU (12 per piece: 1,500 of a
+    // lone workgroup's 2,360-cycle stage, tools/conv_x6_trace.py), a plain 16-byte load ~17, and the piece is back (L2) before the
+    // activation split is done.  The very first piece still comes by DMA (nothing to overlap it with).
+    u32x4 wreg[12];
+    auto wload = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s) wreg[s] = *(const u32x4 *)(wsrc + (long)kc * X6_CHUNK + s * 1024 + wlane);
+    };
+    auto wstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s) *(u32x4 *)(sA + (wave * 12 + s) * 1024 + wlane) = wreg[s];
     };
     auto lstore = [&](int kc) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
             float xv[8];
+            // the ReLU switches on at a multiple of 8 channels (checked by the host): one wave-uniform lower bound per piece
+            const float lo = (FUSED && in_relu && kc * 32 + 16 * xh + 8 * pc >= relu_from) ? 0.f : -INFINITY;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float v = xreg[2 * pc + (q >> 2)][q & 3];
                 if (FUSED) {
                     const int k = kc * 32 + 8 * pc + q;   // relative to the 16 * xh already folded into sc / sh
-                    v = v * sc[k] + sh[k];
-                    if (in_relu && k + 16 * xh >= relu_from) v = v > 0.f ? v : 0.f;
+                    v = fmaxf(v * sc[k] + sh[k], lo);
                 }
                 xv[q] = v;
             }
@@ -247,8 +262,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
         X6_STAMP(5 * kc + 1)
         __syncthreads();
         X6_STAMP(5 * kc + 2)
-        dma(kn);
+        wload(kn);
         lstore(kn);
+        wstore();
         X6_STAMP(5 * kc + 3)
         __syncthreads();
         X6_STAMP(5 * kc + 4)
@@ -409,7 +425,7 @@ static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias
     CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wpk % 16) == 0, "conv1x1_bf16x6: pointers must be 16-byte aligned");
     CASPR_REQUIRE((bias == nullptr || ((uintptr_t)bias % 16) == 0) && (bbias == nullptr || ((uintptr_t)bbias % 16) == 0),
                   "conv1x1_bf16x6: bias pointers must be 16-byte aligned");
-    CASPR_REQUIRE(in_relu_from >= 0, "conv1x1_bf16x6: in_relu_from=%d must be non-negative", in_relu_from);
+    CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 8 == 0, "conv1x1_bf16x6: in_relu_from=%d must be a non-negative multiple of 8", in_relu_from);
     const int Mt = ceil_div(Cout, X6_TM), Pt = P / X6_TP;
     const long nblk = (long)Mt * Pt * B;
     CASPR_REQUIRE(nblk < (1L << 31), "conv1x1_bf16x6: too many tiles (%ld)", nblk);

@@ -268,7 +268,7 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
     if out is None:
         out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
     ldy = _chk_rows(out)
-    if CONV_BF16X6 and pw.x6_ok and P % 128 == 0 and not row_invariant:
+    if CONV_BF16X6 and pw.x6_ok and P % 128 == 0 and not row_invariant and in_relu_from % 8 == 0:
         _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
                                                         int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()),
                    "caspr_conv1x1_bf16x6_f32")
@@ -314,7 +314,7 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
     _chk_f32(bias, bbias, in_scale, in_shift, gamma, beta)
     B, P, _ = x.shape
     C = pw.cout
-    if not (CONV_BF16X6 and pw.x6_gn_ok and P % 128 == 0 and C % groups == 0):
+    if not (CONV_BF16X6 and pw.x6_gn_ok and P % 128 == 0 and C % groups == 0 and in_relu_from % 8 == 0):
         y = conv1x1(pw, bias, x, bbias=bbias, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, in_relu_from=in_relu_from, out=out)
         if want_moments:
             from . import train_ops
