@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float *__restrict__ 
 #define ST_DA 3   // weight fragment sets in flight (chunks); ST_DB must be a multiple of ST_DA and even
 #endif
 
-template <bool FUSED>
+// NMI = row tiles of 16 output channels per wave: 8, or 1 for convs with up to 16 outputs (the T-NOCS regression 1600 -> 4,
+// tpointnet2.py:105: with the 128-row tile 7/8 of its MFMAs multiplied padding and the layer ran at 1.9 TB/s of its 2.1 GB input)
+template <bool FUSED, int NMI>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
                                                                 const float *__restrict__ bbias, const float *__restrict__ X,
                                                                 int ldx, const float *__restrict__ in_scale,
@@ -341,9 +343,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
     const int mt0 = co0 >> 4;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, MT16 * KC * 1024, 0x00020000);
     const int wvoff = lane * 16;
-    int wsoff[8];
+    int wsoff[NMI];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) wsoff[mi] = ((mt0 + mi) < MT16 ? mt0 + mi : 0) * KC * 1024;
+    for (int mi = 0; mi < NMI; ++mi) wsoff[mi] = ((mt0 + mi) < MT16 ? mt0 + mi : 0) * KC * 1024;
     // activation rows of this lane (two column tiles); rows past P read row P-1 (finite data, columns never stored)
     const float *xrow[2];
 #pragma unroll
@@ -352,16 +354,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
         xrow[ni] = X + ((long)b * P + (p < P ? p : P - 1)) * ldx + 4 * g;
     }
 
-    f32x4 acc[8][2];
+    f32x4 acc[NMI][2];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 af[ST_DA][8], bfr[ST_DB][2];
+    f32x4 af[ST_DA][NMI], bfr[ST_DB][2];
     auto load_a = [&](int set, int kc) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < NMI; ++mi)
             af[set][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff[mi] + kc * 1024, 0));
     };
     // Whole chunks (all 16 k below Cin) run in an unconditional, ST_DB-times unrolled loop; the ragged end (a partial
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
+            for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16(af[aset][mi][q], bfr[bset][ni][q], acc[mi][ni]);
     };
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
                 fix_b(d, kc);
                 if (ST_TOUCH_A) {
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) af[d % ST_DA][mi] = af[d % ST_DA][mi] * opaque_one;
+                    for (int mi = 0; mi < NMI; ++mi) af[d % ST_DA][mi] = af[d % ST_DA][mi] * opaque_one;
                 }
                 mma(d % ST_DA, d);
             }
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
     // epilogue: lane holds co = co0 + mi*16 + 4g + r for point p0 + ni*16 + j
     const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
+    for (int mi = 0; mi < NMI; ++mi) {
         if (mt0 + mi >= MT16) continue;
         const int co = co0 + mi * 16 + 4 * g;
         float add[4];
@@ -532,12 +534,16 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     // row-invariant calls always take the LDS kernel (the kernel choice itself must not depend on P)
     if (force == 7 || (force == 0 && P >= 128 && Cin >= 32 * ST_DB && !(act & CASPR_CONV_ROW_INVARIANT))) {
         dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
-        if (in_scale)
-            conv1x1_stream_kernel<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
-                                                                                     in_relu_from, Y, ldy, P, Cin, Cout, act);
-        else
-            conv1x1_stream_kernel<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu,
-                                                                                      in_relu_from, Y, ldy, P, Cin, Cout, act);
+#define ST_LAUNCH(F, N) conv1x1_stream_kernel<F, N><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, \
+                                                                                    in_relu_from, Y, ldy, P, Cin, Cout, act)
+        if (Cout <= 16) {
+            if (in_scale) ST_LAUNCH(true, 1);
+            else ST_LAUNCH(false, 1);
+        } else {
+            if (in_scale) ST_LAUNCH(true, 8);
+            else ST_LAUNCH(false, 8);
+        }
+#undef ST_LAUNCH
         CASPR_CHECK_LAUNCH("conv1x1(stream)");
         return CASPR_OK;
     }

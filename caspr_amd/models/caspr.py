@@ -182,9 +182,14 @@ class CaSPR(nn.Module):
                 all_times = x[:, :, 0, 3] / max_timestamp
             else:
                 all_times = timestamps.view((1, -1)).repeat((B, 1)).to(x)
-            z0, tnocs_pred = self.encode(x)
+            # the T-NOCS regression of the encoder's last layer runs on a side stream underneath the latent solve (32 workgroups,
+            # latency-bound); joined before the flow starts
+            defer = x.is_cuda and not self._differentiable(x)
+            z0, tnocs_pred = self.encoder(x, defer_tnocs=True) if defer else self.encode(x)
             with ops.timed("latent"):
                 z = self.aggregate_and_solve_latent(z0, all_times)
+            if defer:
+                self.encoder.join()
             with ops.timed("decode"):
                 y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y)
             return y, logp_y, x, tnocs_pred

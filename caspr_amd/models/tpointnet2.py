@@ -88,8 +88,18 @@ class TPointNet2(nn.Module):
                                  lambda: ops.PackedWeight(self.conv3.weight.detach()[:, :, 0].contiguous()))
         return p1, p2, p3
 
-    def forward(self, x):
-        """x (B,T,N,4) -> z0 (B, out_feat_size), tnocs (B,T,N,4) | None   (tpointnet2.py:70-115)."""
+    def join(self):
+        """Make the current stream wait for a T-NOCS regression that forward(x, defer_tnocs=True) left running on the side
+        stream.  No-op when nothing is pending."""
+        ev = getattr(self, "_tnocs_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._tnocs_ready = None
+
+    def forward(self, x, defer_tnocs=False):
+        """x (B,T,N,4) -> z0 (B, out_feat_size), tnocs (B,T,N,4) | None   (tpointnet2.py:70-115).
+        defer_tnocs: the T-NOCS regression (:105-106; nothing downstream of z0 needs it) is issued on the side stream and
+        the caller continues with z0 on the current one; the caller must call join() before anything reads tnocs."""
         if not x.is_cuda:
             raise ValueError("caspr_amd.TPointNet2 runs on the GPU only (HIP kernels); got a %s tensor" % x.device)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -139,7 +149,17 @@ class TPointNet2(nn.Module):
                                         in_scale=s1, in_shift=t1, in_relu=True)               # :99-100, 111
         del y1
         tnocs_regression = None
-        if self.regress_tnocs:
+        if self.regress_tnocs and defer_tnocs and self.record is None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                t = ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1)  # :105-106
+                self._tnocs_ready = torch.cuda.Event()
+                self._tnocs_ready.record()
+            for t_ in (y2, s2, t2):
+                t_.record_stream(side)          # main-stream allocations the side stream still reads
+            t.record_stream(main)
+            tnocs_regression = t[:, :, :self.tnocs_point_size].reshape(B, T, N, self.tnocs_point_size)
+        elif self.regress_tnocs:
             t = ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1)  # :105-106
             tnocs_regression = t[:, :, :self.tnocs_point_size].reshape(B, T, N, self.tnocs_point_size)
         t_head.__exit__()
