@@ -155,6 +155,204 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient with the products on the bf16 matrix pipe in the exact three-way split of gemm_bf16x6.hip (both
+// operands are activations here, so both are split on the way to LDS).  Same tile (128 x 128, 2 x 2 waves of 64 x 64, 32
+// rows per stage), same slab decomposition and fixed-order reduction.
+//   A bf16 MFMA operand wants, per lane, 8 consecutive CONTRACTION indices (rows r) of one channel -- the row-major [row][channel]
+//   data the wrong way round.  The LDS image is therefore kept row-major, as 16-channel subtiles [32 rows][16 channels] of
+//   bf16 (1 KB + 32 B pad each, three planes per operand), and read with ds_read_b64_tr_b16: a 16-lane group reads a 4-row x
+//   16-channel block and every lane receives the 4 rows of ITS channel.  Lane group g takes rows 4g..4g+3 and 16+4g..16+4g+3 as
+//   its 8 contraction slots -- the same permutation of the 32 rows for both operands, which is all a contraction needs -- so
+//   every read is 512 contiguous bytes (conflict-free), and the 8-byte stores of the staging pass (4 channels of one row) hit 64
+//   distinct banks per 32 lanes thanks to the 32-byte pad between subtiles.
+// ---------------------------------------------------------------------------------------------
+typedef short wg6_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wg6_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wg6_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wg6_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wg6_f32x2 __attribute__((ext_vector_type(2)));
+#define WG6_SUB (32 * 32 + 32)          // bytes of a [32][16] bf16 subtile + pad
+
+// x0, x1 -> their entries of the three planes (exact: round-to-nearest conversion, exact remainders; see gemm_bf16x6.hip)
+__device__ __forceinline__ void wg6_split_pair(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    wg6_f32x2 v = {x0, x1};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg6_bf16x2));
+    wg6_f32x2 h = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+    v = v - h;
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg6_bf16x2));
+    h = (wg6_f32x2){__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
+    v = v - h;
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg6_bf16x2));
+}
+
+// NW = 4: the 128 x 128 tile of the f32 kernel (2 x 2 waves of 64 x 64, two workgroups per CU); NW = 8: 256 x 256 (2 x 4 waves of
+// 128 x 64, one workgroup per CU): every staged element then meets 256 instead of 128 channels of the other operand -- half the
+// split arithmetic and half the re-reads of dY and X per product -- at the price of more padding on widths like 1600 (7 x 256).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv1x1_wgrad_bf16x6_kernel(const float *__restrict__ dY, int lddy,
+                                                                      const float *__restrict__ X, int ldx,
+                                                                      const float *__restrict__ in_scale,
+                                                                      const float *__restrict__ in_shift, int in_relu,
+                                                                      int relu_from, long R, int P, int Cin, int Cout,
+                                                                      long rows_per_slab, float *__restrict__ part,
+                                                                      float *__restrict__ bpart)
+{
+    constexpr int NT = 64 * NW, T = 32 * NW;          // threads; tile edge (channels of either operand)
+    constexpr int MI = NW == 4 ? 4 : 8;                // row tiles per wave
+    constexpr int PLANE = (T / 16) * WG6_SUB, OPER = 3 * PLANE;
+    constexpr int CQ = T / 4, LD = T + 16;             // float4 per staged row; row stride of the bias scratch
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * OPER];
+    unsigned char *sA = lds, *sB = lds + OPER;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
+    const int g = lane >> 4, j = lane & 15;
+    const int co0 = blockIdx.x * T, k0 = blockIdx.y * T;
+    const int slab = blockIdx.z;
+    const long r_beg = (long)slab * rows_per_slab;
+    const long r_end = (r_beg + rows_per_slab) < R ? (r_beg + rows_per_slab) : R;
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 va[4], vb[4];
+    f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_stage = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + NT * i;
+            const int row = f / CQ, c = (f % CQ) * 4;
+            const long r = r0 + row;
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r < r_end) {
+                if (co0 + c < Cout) a = ld4(dY + r * lddy + co0 + c);   // lddy >= roundup4(Cout)
+                if (k0 + c < Cin) b = ld4(X + r * ldx + k0 + c);
+            }
+            va[i] = a;
+            vb[i] = b;
+        }
+    };
+    const bool full_cols = co0 + T <= Cout && k0 + T <= Cin;
+    auto put = [&](unsigned char *base, int row, int c, const f32x4 &v) __attribute__((always_inline)) {
+        unsigned a1, a2, a3, b1, b2, b3;
+        wg6_split_pair(v[0], v[1], a1, a2, a3);
+        wg6_split_pair(v[2], v[3], b1, b2, b3);
+        unsigned char *dst = base + (c >> 4) * WG6_SUB + row * 32 + (c & 15) * 2;
+        *(wg6_u32x2 *)(dst) = (wg6_u32x2){a1, b1};
+        *(wg6_u32x2 *)(dst + PLANE) = (wg6_u32x2){a2, b2};
+        *(wg6_u32x2 *)(dst + 2 * PLANE) = (wg6_u32x2){a3, b3};
+    };
+    auto store_stage = [&](long r0) {   // masking, the fused input transform and the split run here, when the data has arrived
+        const bool interior = full_cols && r0 + WG_ROWS <= r_end;   // block-uniform
+        long bi0 = 0;
+        int rem0 = 0;
+        if (in_scale) {
+            bi0 = r0 / P;
+            rem0 = (int)(r0 - bi0 * P);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + NT * i;
+            const int row = f / CQ, c = (f % CQ) * 4;
+            const long r = r0 + row;
+            f32x4 a = va[i], b = vb[i];
+            const int k = k0 + c;
+            if (in_scale && (interior || (r < r_end && k < Cin))) {
+                long bi = bi0;
+                int pr = rem0 + row;
+                while (pr >= P) { pr -= P; ++bi; }
+                const f32x4 s4 = ld4(in_scale + bi * Cin + k), t4 = ld4(in_shift + bi * Cin + k);
+                b = b * s4 + t4;
+                if (in_relu && k >= relu_from) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = b[q] > 0.f ? b[q] : 0.f;
+                }
+            }
+            if (!interior) {
+                if (r < r_end) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (co0 + c + q >= Cout) a[q] = 0.f;
+                        if (k + q >= Cin) b[q] = 0.f;
+                    }
+                } else {
+                    a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    b = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            bsum = bsum + a;
+            put(sA, row, c, a);
+            put(sB, row, c, b);
+        }
+    };
+    // fragment of subtile `sub` of an operand plane: lane (g, i) supplies the address of 4 channels of row 4g + (i >> 2) (then
+    // 16 + ...), and receives rows 4g .. 4g+3 (16+4g ..) of channel i
+    auto frag = [&](const unsigned char *plane, int sub) __attribute__((always_inline)) -> wg6_bf16x8 {
+        const unsigned char *p = plane + sub * WG6_SUB + (4 * g + (j >> 2)) * 32 + (j & 3) * 8;
+        const wg6_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg6_s16x4 *)(p));
+        const wg6_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg6_s16x4 *)(p + 16 * 32));
+        return (wg6_bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    load_stage(r_beg);
+    for (long r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
+        __syncthreads();   // previous stage fully consumed
+        store_stage(r0);
+        __syncthreads();
+        if (r0 + WG_ROWS < r_end) load_stage(r0 + WG_ROWS);
+        __builtin_amdgcn_sched_barrier(0);
+        wg6_bf16x8 bfr[3][4];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bfr[pl][ni] = frag(sB + pl * PLANE, wn * 4 + ni);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            wg6_bf16x8 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[pl] = frag(sA + pl * PLANE, wm * MI + mi);
+            // smallest terms first (plane 0 = leading part)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bfr[0][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[1][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[2][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[0][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[1][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[0][ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (bpart && blockIdx.y == 0) {
+        float *sF = (float *)lds;
+        __syncthreads();
+        st4(&sF[(tid / CQ) * LD + (tid % CQ) * 4], bsum);
+        __syncthreads();
+        if (tid < T && co0 + tid < Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < 8; ++ph) t += sF[ph * LD + tid];
+            bpart[(long)slab * Cout + co0 + tid] = t;
+        }
+    }
+    float *pp = part + (long)slab * Cout * Cin;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (16 * MI) + mi * 16 + 4 * g + r, k = k0 + wn * 64 + ni * 16 + j;
+                if (co < Cout && k < Cin) pp[(long)co * Cin + k] = acc[mi][ni][r];
+            }
+}
+
 // out[i] (+)= sum_s part[s][i]  in a fixed order.  Few slabs: one thread per element walks them (coalesced over i).
 // Many slabs (small weights of the set-abstraction MLPs, up to 4096 slabs): 32 lanes per element each take every 32nd
 // slab, then a fixed xor-shuffle tree -- a single thread walking thousands of slabs was a 0.6 ms latency chain.
@@ -206,10 +404,24 @@ extern "C" long caspr_wgrad_ws_bytes(long R, int Cin, int Cout)
     return (long)pick_slabs(R, Cin, Cout) * ((long)Cout * Cin + Cout) * 4 + 256;
 }
 
-extern "C" int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X, int ldx, const float *in_scale,
-                                       const float *in_shift, int in_relu, int in_relu_from, int B, int P, int Cin,
-                                       int Cout, float *dW, float *dbias, int accumulate, void *ws, long ws_bytes,
-                                       void *stream)
+static void wgrad_launch(int kind, dim3 grid, hipStream_t st, const float *dY, int lddy, const float *X, int ldx, const float *in_scale,
+                         const float *in_shift, int in_relu, int in_relu_from, long R, int P, int Cin, int Cout, long rps, float *part,
+                         float *bpart)
+{
+    if (kind == 2)
+        conv1x1_wgrad_bf16x6_kernel<8><<<grid, dim3(512), 0, st>>>(dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin, Cout, rps,
+                                                                   part, bpart);
+    else if (kind == 1)
+        conv1x1_wgrad_bf16x6_kernel<4><<<grid, dim3(256), 0, st>>>(dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin, Cout, rps,
+                                                                   part, bpart);
+    else
+        conv1x1_wgrad_kernel<<<grid, dim3(256), 0, st>>>(dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin, Cout, rps, part,
+                                                         bpart);
+}
+
+static int wgrad_impl(bool bf16x6, const float *dY, int lddy, const float *X, int ldx, const float *in_scale, const float *in_shift, int in_relu,
+                      int in_relu_from, int B, int P, int Cin, int Cout, float *dW, float *dbias, int accumulate, void *ws, long ws_bytes,
+                      void *stream)
 {
     CASPR_REQUIRE(dY && X && dW && ws && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1_wgrad: bad arguments");
     CASPR_REQUIRE(lddy % 4 == 0 && lddy >= ((Cout + 3) & ~3) && ldx % 4 == 0 && ldx >= ((Cin + 3) & ~3),
@@ -222,8 +434,19 @@ extern "C" int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X
     const long rps = ((R + S - 1) / S + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)ws;
-    conv1x1_wgrad_kernel<<<dim3(ceil_div(Cout, WG_T), ceil_div(Cin, WG_T), S), dim3(256), 0, st>>>(
-        dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin, Cout, rps, part, dbias ? part + (long)S * ((long)Cout * Cin) : nullptr);
+    // bf16x6: the 256 x 256 tile where both widths fill it reasonably (padded area at most 20 % above the 128-tile's), else 128 x 128
+    int kind = 0, T = WG_T;
+    if (bf16x6) {
+        const double a128 = (double)ceil_div(Cout, 128) * ceil_div(Cin, 128) * 128.0 * 128.0;
+        const double a256 = (double)ceil_div(Cout, 256) * ceil_div(Cin, 256) * 256.0 * 256.0;
+        kind = (Cout >= 256 && Cin >= 256 && a256 <= 1.2 * a128) ? 2 : 1;
+        const int force = CASPR_DEBUG_ENV_INT("CASPR_WGRAD_TILE");   // debug build: 128 / 256
+        if (force == 128) kind = 1;
+        if (force == 256) kind = 2;
+        T = kind == 2 ? 256 : 128;
+    }
+    wgrad_launch(kind, dim3(ceil_div(Cout, T), ceil_div(Cin, T), S), st, dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin,
+                 Cout, rps, part, dbias ? part + (long)S * ((long)Cout * Cin) : nullptr);
     const long n = (long)Cout * Cin;
     launch_slab_reduce(part, n, S, accumulate, dW, st);
     if (dbias) {
@@ -232,6 +455,23 @@ extern "C" int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X
     }
     CASPR_CHECK_LAUNCH("conv1x1_wgrad");
     return CASPR_OK;
+}
+
+extern "C" int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X, int ldx, const float *in_scale,
+                                       const float *in_shift, int in_relu, int in_relu_from, int B, int P, int Cin,
+                                       int Cout, float *dW, float *dbias, int accumulate, void *ws, long ws_bytes,
+                                       void *stream)
+{
+    return wgrad_impl(false, dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, B, P, Cin, Cout, dW, dbias, accumulate, ws, ws_bytes, stream);
+}
+
+// the same contract with the products in the exact bf16 three-way split (conv1x1_wgrad_bf16x6_kernel); workspace as above
+extern "C" int caspr_conv1x1_wgrad_bf16x6_f32(const float *dY, int lddy, const float *X, int ldx, const float *in_scale,
+                                              const float *in_shift, int in_relu, int in_relu_from, int B, int P, int Cin,
+                                              int Cout, float *dW, float *dbias, int accumulate, void *ws, long ws_bytes,
+                                              void *stream)
+{
+    return wgrad_impl(true, dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, B, P, Cin, Cout, dW, dbias, accumulate, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

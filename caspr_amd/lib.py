@@ -62,6 +62,8 @@ SIGNATURES = {
     "caspr_wgrad_ws_bytes": (c_long, [c_long, c_int, c_int]),
     "caspr_conv1x1_wgrad_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_int,
                                         ctypes.c_void_p, c_long, c_stream]),
+    "caspr_conv1x1_wgrad_bf16x6_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_int,
+                                        ctypes.c_void_p, c_long, c_stream]),
     "caspr_gn_bwd_ws_bytes": (c_long, [c_long, c_int, c_int, c_int]),
     "caspr_gn_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_ip, c_fp, c_int, c_long, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp,
                                  c_int, c_fp, c_fp, c_int, ctypes.c_void_p, c_long, c_stream]),

@@ -6,6 +6,7 @@ ops.py: float32 GPU tensors, point-major rows, no CPU fallback.
 import torch
 
 from . import lib as _lib
+from . import ops
 from .ops import _chk_f32, _chk_i32, _chk_rows, _p, _stream, _workspace
 
 
@@ -38,8 +39,11 @@ def conv1x1_wgrad(dy, x, cin, cout, dw, dbias=None, in_scale=None, in_shift=None
         raise ValueError("conv1x1_wgrad: dw must be (%d,%d)" % (cout, cin))
     L = _lib.load()
     ws = _workspace(L.caspr_wgrad_ws_bytes(B * P, cin, cout), x.device)
-    _lib.check(L.caspr_conv1x1_wgrad_f32(_p(dy), lddy, _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu), int(in_relu_from), B, P, cin, cout,
-                                         _p(dw), _p(dbias), int(accumulate), _p(ws), ws.numel(), _stream()), "caspr_conv1x1_wgrad_f32")
+    # matrix products as ops.set_matmul_mode says: the exact bf16 three-way split where the tile is reasonably filled, f32 MFMA otherwise
+    x6 = ops.CONV_BF16X6 and cin >= 32 and cout >= 32
+    fn, name = (L.caspr_conv1x1_wgrad_bf16x6_f32, "caspr_conv1x1_wgrad_bf16x6_f32") if x6 else (L.caspr_conv1x1_wgrad_f32, "caspr_conv1x1_wgrad_f32")
+    _lib.check(fn(_p(dy), lddy, _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu), int(in_relu_from), B, P, cin, cout,
+                  _p(dw), _p(dbias), int(accumulate), _p(ws), ws.numel(), _stream()), name)
     return dw
 
 

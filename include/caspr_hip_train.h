@@ -35,6 +35,14 @@ int caspr_conv1x1_wgrad_f32(const float *dY, int lddy, const float *X, int ldx, 
                             int Cout, float *dW, float *dbias, int accumulate, void *ws, long ws_bytes,
                             void *stream);
 
+/* The same contract with the products on the bf16 matrix pipe in the exact three-way split of caspr_conv1x1_bf16x6_f32
+ * (csrc/backward.hip: conv1x1_wgrad_bf16x6_kernel; both operands are split on the way to LDS, fragments come out of the
+ * row-major LDS image through ds_read_b64_tr_b16).  Same workspace, same fixed-order slab reduction (bit-reproducible).  */
+int caspr_conv1x1_wgrad_bf16x6_f32(const float *dY, int lddy, const float *X, int ldx, const float *in_scale,
+                            const float *in_shift, int in_relu, int in_relu_from, int B, int P, int Cin,
+                            int Cout, float *dW, float *dbias, int accumulate, void *ws, long ws_bytes,
+                            void *stream);
+
 /* GroupNorm(+ReLU) backward.  Y = raw conv output (B,P,ldy); dA (B,P,ldd) = gradient w.r.t. the
  * normalised (and, if relu, rectified) activation, or NULL for zero; dMax (B,C) + aMax (B,C) = gradient
  * of the max over points of the normalised, NOT rectified feature and its arg-max point (torch.max at

@@ -42,8 +42,17 @@ def pad4(t):
     return F.pad(t, (0, (-c) % 4)) if c % 4 else t
 
 
+@pytest.fixture(params=["bf16x6", "f32"])
+def matmul_mode(request):
+    """Both kernel families of the matrix products (ops.set_matmul_mode), same thresholds."""
+    from caspr_amd import ops
+    prev = ops.set_matmul_mode(request.param)
+    yield request.param
+    ops.set_matmul_mode(conv=prev[0], cnf=prev[1])
+
+
 @pytest.mark.parametrize("B,P,Cin,C1,C2", [(3, 1500, 7, 64, 130), (2, 2048, 64, 128, 64), (1, 333, 4, 256, 3)])
-def test_conv_gn_relu_block_backward(B, P, Cin, C1, C2):
+def test_conv_gn_relu_block_backward(matmul_mode, B, P, Cin, C1, C2):
     """x -> conv(W1,b1) -> GN(16)+ReLU -> conv(W2,b2) -> sum(. * R): every parameter gradient and dx."""
     from caspr_amd import ops, train_ops as T
     dev = "cuda:0"
@@ -90,6 +99,29 @@ def test_conv_gn_relu_block_backward(B, P, Cin, C1, C2):
     dW2c = torch.empty_like(W2d)
     T.conv1x1_wgrad(dy2, y1d, C1, C2, dW2c, None, in_scale=sc, in_shift=sh, in_relu=True)
     assert torch.equal(dW2c, dW2)
+
+
+@pytest.mark.parametrize("B,P,Cin,Cout", [(2, 1024, 608, 512), (1, 4100, 1600, 1600), (3, 700, 132, 260), (2, 96, 512, 64)])
+def test_conv1x1_wgrad_direct(matmul_mode, B, P, Cin, Cout):
+    """dW = dY^T . relu(x * scale + shift), db = column sums of dY, against float64 -- both kernel families at the same
+    tolerance (the bf16x6 one: both operands split exactly on the way to LDS, fragments through ds_read_b64_tr_b16), ragged
+    channel counts and row counts, the fused input transform, bit-reproducibility."""
+    from caspr_amd import train_ops as T
+    dev = "cuda:0"
+    x, dy = rnd(1, B, P, Cin), rnd(2, B, P, Cout)
+    sc, sh = rnd(3, B, Cin).abs() + 0.5, rnd(4, B, Cin)
+    xin = torch.relu(x.double() * sc.double().unsqueeze(1) + sh.double().unsqueeze(1))
+    want = torch.einsum("bpo,bpi->oi", dy.double(), xin)
+    xd, dyd = x.to(dev), dy.to(dev)
+    dW, db = torch.empty(Cout, Cin, device=dev), torch.empty(Cout, device=dev)
+    T.conv1x1_wgrad(dyd, xd, Cin, Cout, dW, db, in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)
+    rel("wgrad_fused[%d,%d]" % (Cin, Cout), dW, want, 3e-6)
+    rel("wgrad_bias[%d,%d]" % (Cin, Cout), db, dy.double().sum(dim=(0, 1)), 3e-6)
+    dW2 = torch.empty_like(dW)
+    T.conv1x1_wgrad(dyd, xd, Cin, Cout, dW2, None, in_scale=sc.to(dev), in_shift=sh.to(dev), in_relu=True)
+    assert torch.equal(dW, dW2)
+    T.conv1x1_wgrad(dyd, xd, Cin, Cout, dW2, None)
+    rel("wgrad_plain[%d,%d]" % (Cin, Cout), dW2, torch.einsum("bpo,bpi->oi", dy.double(), x.double()), 3e-6)
 
 
 @pytest.mark.parametrize("B,n,M,ns,C,dims", [(2, 256, 64, 16, 6, (16, 16, 32)), (2, 128, 32, 32, 96, (64, 96, 128)), (1, 64, 16, 32, 512, (256, 256, 512))])
