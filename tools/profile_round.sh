@@ -11,6 +11,7 @@ cd /tmp
 python $REPO/bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?" >> $OUT/${TAG}_bench.err
 rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats -d /tmp/pk -o r -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-subblock > $OUT/${TAG}_prof_bench.json 2> /tmp/pk.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/pk -name "*results.db" | head -1) $OUT/${TAG}_kernel_stats.txt
+python $REPO/tools/rocprof_timeline.py $(find /tmp/pk -name "*results.db" | head -1) $OUT/${TAG}_step_timeline.txt
 : > $OUT/${TAG}_traffic_pmc.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pp && rocprofv3 --kernel-trace --pmc $C -d /tmp/pp -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/pp.err
@@ -30,4 +31,7 @@ python $REPO/bench_train.py --steps 3 --warmup 1 > $OUT/${TAG}_bench_train_full.
 python $REPO/bench_train.py --steps 3 --warmup 1 --mode pretrain --no-cpu-baseline > $OUT/${TAG}_bench_train_pretrain.json 2>> $OUT/${TAG}_bench_train.err
 rm -rf /tmp/pt && rocprofv3 --kernel-trace --stats -d /tmp/pt -o r -- python $REPO/bench_train.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/pt.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/pt -name "*results.db" | head -1) $OUT/${TAG}_train_full_kernel_stats.txt
+# per-chunk phase cycles of the bf16x6 conv (debug flavour of the library, if it was built) and weight-gradient timings in both modes
+if [ -f $REPO/caspr_amd/csrc/libcaspr_hip_debug.so ]; then python $REPO/tools/conv_x6_trace.py > $OUT/${TAG}_conv_x6_trace.txt 2>&1; fi
+python $REPO/tools/wgrad_bench.py > $OUT/${TAG}_wgrad_bench.txt 2>&1
 ls -la $OUT | grep ${TAG}_ | head -30
