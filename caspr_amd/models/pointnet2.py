@@ -99,6 +99,19 @@ class PointNetFeatureExtractor(nn.Module):
             out.append((self._cache.get("l%d" % l, [conv.weight], build), conv.bias, gn.weight, gn.bias))
         return out
 
+    def row_layers(self, cin_pad):
+        """3 x (PackedWeight, bias, gamma, beta) for the row-materialised form (run_rows): reference channel order
+        [dx dy dz | features], the first layer's input width zero-padded to cin_pad."""
+        out = []
+        for l, (conv, gn) in enumerate(zip(self.conv_layers, self.bn_layers)):
+            def build(conv=conv, l=l):
+                w = conv.weight.detach()[:, :, 0]
+                if l == 0 and cin_pad > w.shape[1]:
+                    w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[1]))
+                return ops.PackedWeight(w.contiguous())
+            out.append((self._cache.get(("rows", l, cin_pad), [conv.weight], build), conv.bias, gn.weight, gn.bias))
+        return out
+
     def forward(self, x):
         """Reference signature (B', C, ns) -> (B', feat_size): one neighbourhood per row."""
         if not (self.global_feat and self.transposed_input):
@@ -118,6 +131,12 @@ class PointNetFeatureExtractor(nn.Module):
         out = torch.empty(Bp, 1, self.feat_size, device=x.device, dtype=torch.float32)
         ops.sa_mlp_max(xyz, centre, feat, idx, Cf, self.kernel_layers(), out, 0)
         return out.view(Bp, self.feat_size)
+
+
+# Set-abstraction scales whose point MLP reads at least this many channels run row-materialised (_run_rows) instead of fused: at
+# cfg-2 that is the coarsest level (515 inputs, 16 centres per frame: 13.97 vs 14.31 ms for the PointNet++ stage); one level
+# finer (259 inputs) the extra passes over the rows cost more than the bf16 pipe returns (14.16 ms).
+ROWS_MIN_CIN = 500
 
 
 class PointNet2SetAbstraction(nn.Module):
@@ -177,12 +196,32 @@ class PointNet2SetAbstraction(nn.Module):
         out = torch.empty(B, M, self.get_num_features_out(), device=xyz.device, dtype=torch.float32)
         off = 0
         for i, ns in enumerate(self.layers):
+            if ops.CONV_BF16X6 and C + 3 >= ROWS_MIN_CIN and (M * ns) % 128 == 0:
+                self._run_rows(xyz, new_xyz, feat, C, idx["ball_idx"][i], i, out, off)
+                off += self.pointnet_layer_dims_list[i][-1]
+                continue
             ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off,
                            feat_kind=feat_kind)  # :391-409
             off += self.pointnet_layer_dims_list[i][-1]
         if record is not None:
             record.append(idx)
         return new_xyz, out
+
+    def _run_rows(self, xyz, new_xyz, feat, C, ball_idx, i, out, off):
+        """One scale with materialised neighbourhood rows: gather -> 3 x (bf16x6 conv -> per-neighbourhood GroupNorm [-> ReLU]) ->
+        max over the samples.  For the widest levels (few centres, inputs of 500+ channels) the fused kernel streams the whole
+        point MLP (1.3 MB of weights at the coarsest level) from L2 once per neighbourhood; as pointwise convs over all
+        neighbourhood rows the weights are shared by 256-row tiles and the products run on the bf16 pipe."""
+        from .. import train_ops as T
+        ns = self.layers[i]
+        pn = self.pointnet_modules[i]
+        kin = (3 + C + 31) // 32 * 32
+        layers = pn.row_layers(kin)
+        cur = T.group_rows(xyz, new_xyz, feat, C, ball_idx, align=32)
+        for l, (pw, bias, gamma, beta) in enumerate(layers):
+            y = ops.conv1x1(pw, bias, cur)
+            last = l == len(layers) - 1
+            cur, _, _, _ = T.gn_rows(y, ns, pw.cout, gamma, beta, relu=not last, maxout=out[:, :, off:off + pw.cout] if last else None)
 
     def forward(self, xyz, features=None):
         """Reference signature: xyz (B,n,3), features (B,C,n) -> new_xyz (B,M,3), new_features (B,Cout,M)."""

@@ -102,15 +102,15 @@ def three_interp_bwd(dout, idx, weight, C, dfeat):
     return dfeat
 
 
-def group_rows(xyz, new_xyz, feat, C, idx, centred=False, feat_kind=0):
-    """-> G (B, M*ns, roundup4(3+C)) rows [dxyz | feat | 0]; centred: minus the neighbourhood's sample-0 row
+def group_rows(xyz, new_xyz, feat, C, idx, centred=False, feat_kind=0, align=4):
+    """-> G (B, M*ns, roundup(3+C, align)) rows [dxyz | feat | 0]; centred: minus the neighbourhood's sample-0 row
     (include/caspr_hip_train.h), feat_kind as ops.sa_mlp_max."""
     _chk_f32(xyz, new_xyz)
     _chk_i32(idx)
     B, n, _ = xyz.shape
     M, ns = idx.shape[1], idx.shape[2]
     ldf = 0 if feat is None else _chk_rows(feat)
-    ldg = (3 + C + 3) // 4 * 4
+    ldg = (3 + C + align - 1) // align * align
     G = torch.empty(B, M * ns, ldg, device=xyz.device, dtype=torch.float32)
     _lib.check(_lib.load().caspr_group_rows_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, int(bool(centred)), int(feat_kind),
                                                 _p(G), ldg, _stream()),
