@@ -380,7 +380,9 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float *__re
 
 static void launch_slab_reduce(const float *part, long n, int S, int accumulate, float *out, hipStream_t st)
 {
-    if (S > 64)
+    // many slabs AND few elements: 32 lanes per element (its lanes read addresses n floats apart); with 64K+ elements one thread per
+    // element keeps every load coalesced and there are enough threads in flight to cover the S dependent adds
+    if (S > 64 && n < 65536)
         slab_reduce_wide_kernel<<<dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st>>>(part, n, S, accumulate, out);
     else
         slab_reduce_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(part, n, S, accumulate, out);
