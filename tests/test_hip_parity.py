@@ -260,6 +260,23 @@ def test_conv1x1_repeatable_under_load(ops, dev):
         exact("conv1x1_repeat", ops.conv1x1(pw, None, x, in_scale=sc, in_shift=sh, in_relu=True), y1)
 
 
+@pytest.mark.parametrize("P_,Cin,Cout", [(8, 64, 512), (8, 512, 512), (16, 512, 64), (1, 7, 3), (5, 515, 130)])
+def test_conv1x1_few_rows(ops, dev, P_, Cin, Cout):
+    """conv1x1 over at most 16 rows of one batch entry (the latent ODE's layers in training) takes conv1x1_skinny_kernel:
+    against float64, with bias, the sigmoid epilogue, ragged widths and garbage in the input's pad columns."""
+    w, b = rnd(1, Cout, Cin, scale=1.0 / np.sqrt(Cin)), rnd(2, Cout, scale=0.1)
+    ldx = (Cin + 3) // 4 * 4
+    xw = rnd(3, 1, P_, ldx)                       # pad columns hold noise
+    x = xw[:, :, :Cin]
+    pw = ops.PackedWeight(w.to(dev))
+    want = x.double() @ w.double().t() + b.double()
+    got = ops.conv1x1(pw, b.to(dev), xw.to(dev)[:, :, :Cin] if ldx == Cin else xw.to(dev))
+    record("conv1x1_few_rows_%dx%dx%d" % (P_, Cin, Cout), got[:, :, :Cout], want, 2e-6 * max(1.0, float(want.abs().max())))
+    got = ops.conv1x1(pw, None, xw.to(dev), act=1)
+    record("conv1x1_few_rows_sigmoid", got[:, :, :Cout], torch.sigmoid(x.double() @ w.double().t()), 2e-6)
+    exact("conv1x1_few_rows_repeat", ops.conv1x1(pw, None, xw.to(dev), act=1)[:, :, :Cout], got[:, :, :Cout])
+
+
 @pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 256, 512, 512), (1, 128, 1600, 1600), (3, 384, 608, 512), (1, 1024, 1536, 132)])
 def test_conv1x1_bf16x6(ops, dev, monkeypatch, B, P_, Cin, Cout):
     """Default kernel of the large pointwise convs (csrc/gemm_bf16x6.hip): exact three-way bf16 split of both operands, six
