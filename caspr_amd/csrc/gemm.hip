@@ -500,23 +500,24 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// conv1x1 over at most 16 rows (the latent ODE's layers in training: 8 sequences per GPU, 576 products per step of 64-512
-// channels): one workgroup per 16 output channels, the K chunks dealt round-robin to its four waves (A fragment straight from
+// conv1x1 over at most 16 rows per batch entry (the latent ODE's layers in training: 8 sequences per GPU, 576 products per step of
+// 64-512 channels; the per-sequence bias of the head conv): one workgroup per (16 output channels, batch entry) -- the choice of
+// this kernel depends on P only, never on B, so a batch entry's result does not depend on the batch around it --, the K chunks dealt round-robin to its four waves (A fragment straight from
 // the packed weight, B fragment = 16 bytes of the lane's row: columns past P read row P-1 and are not stored), partial tiles
 // summed in wave order through LDS.  The tiled kernels above spend ~36 us on such a call (four workgroups walking K = 512 through
 // their LDS stages); this one is a few microseconds of weight streaming.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv1x1_skinny_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
-                                                             const float *__restrict__ X, int ldx, float *__restrict__ Y, int ldy, int P,
-                                                             int Cin, int Cout, int act)
+                                                             const float *__restrict__ bbias, const float *__restrict__ X, int ldx,
+                                                             float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int act)
 {
     __shared__ __attribute__((aligned(16))) float s_part[4][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
-    const int mt = blockIdx.x;
+    const int mt = blockIdx.x, b = blockIdx.y;
     const int KC = 2 * ((Cin + 31) / 32);
     const int Cin4 = (Cin + 3) & ~3;
-    const float *xrow = X + (long)(j < P ? j : P - 1) * ldx + 4 * g;
+    const float *xrow = X + ((long)b * P + (j < P ? j : P - 1)) * ldx + 4 * g;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kc = wave; kc < KC; kc += 4) {
         const f32x4 af = ld4(wp + (((long)mt * KC + kc) * 64 + lane) * 4);     // zero beyond Cout / Cin (pack_weight_kernel)
@@ -538,8 +539,9 @@ __global__ __launch_bounds__(256) void conv1x1_skinny_kernel(const float *__rest
         for (int r = 0; r < 4; ++r) {
             if (co + r >= Cout) continue;
             float o = v[r] + (bias ? bias[co + r] : 0.f);
+            if (bbias) o += bbias[(long)b * Cout + co + r];
             if ((act & 0xff) == 1) o = sigmoid_f(o);
-            Y[(long)j * ldy + co + r] = o;
+            Y[((long)b * P + j) * ldy + co + r] = o;
         }
     }
 }
@@ -573,8 +575,9 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     const int force = CASPR_DEBUG_ENV_INT("CASPR_GEMM_KERNEL");   // debug build only: 1 = 128-point tiles, 7 = streaming (experiments)
     const size_t lds_pad = (size_t)CASPR_DEBUG_ENV_INT("CASPR_GEMM_LDS_PAD") * 1024;   // occupancy experiments, debug build only
     CASPR_REQUIRE(ceil_div(P, 128) <= 65535, "conv1x1: P=%d rows per batch entry exceed the grid (split the call)", P);
-    if (force == 0 && B == 1 && P <= 16 && !in_scale && !bbias && !(act & CASPR_CONV_ROW_INVARIANT)) {
-        conv1x1_skinny_kernel<<<dim3(ceil_div(Cout, 16)), dim3(256), 0, (hipStream_t)stream>>>(wp, bias, X, ldx, Y, ldy, P, Cin, Cout, act);
+    if (force == 0 && P <= 16 && !in_scale && !(act & CASPR_CONV_ROW_INVARIANT)) {
+        conv1x1_skinny_kernel<<<dim3(ceil_div(Cout, 16), B), dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, Y, ldy, P, Cin, Cout,
+                                                                                                  act);
         CASPR_CHECK_LAUNCH("conv1x1(skinny)");
         return CASPR_OK;
     }

@@ -275,6 +275,9 @@ def test_conv1x1_few_rows(ops, dev, P_, Cin, Cout):
     got = ops.conv1x1(pw, None, xw.to(dev), act=1)
     record("conv1x1_few_rows_sigmoid", got[:, :, :Cout], torch.sigmoid(x.double() @ w.double().t()), 2e-6)
     exact("conv1x1_few_rows_repeat", ops.conv1x1(pw, None, xw.to(dev), act=1)[:, :, :Cout], got[:, :, :Cout])
+    # a batch entry's rows give the same bits whatever the batch around them (the kernel is chosen by P, not by B)
+    xb = torch.cat([rnd(9, 2, P_, ldx), xw], dim=0).to(dev)
+    exact("conv1x1_few_rows_batch_invariance", ops.conv1x1(pw, None, xb, act=1)[2:, :, :Cout], got[:, :, :Cout])
 
 
 @pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 256, 512, 512), (1, 128, 1600, 1600), (3, 384, 608, 512), (1, 1024, 1536, 132)])
