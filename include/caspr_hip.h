@@ -106,6 +106,9 @@ int caspr_three_interp_f32(const float *feat, int ldf, const int32_t *idx, const
  *          row's data only -- not on P or on the row's position in the batch entry (same kernel, same K order for every
  *          row tile).  The hyper-network conv of the CNF runs over frames-as-rows with this flag so that a frame's gates do
  *          not change with the batch it is part of (sharding invariance).
+ * Kernel choice inside (by shape only, never by B, so a batch entry's result does not depend on the batch around it): P <= 16
+ * rows per entry without a fused input transform -> one workgroup per (16 outputs, entry); Cout <= 16 -> streaming kernel with
+ * one row tile per wave; P >= 128 and Cin >= 192 -> streaming kernel; otherwise the LDS-tiled kernel.
  * caspr_pack_weight_f32: W (Cout,Cin) row-major [+ column offset/count to pack a slice] -> packed
  * buffer of caspr_packed_size(Cout, ncols) floats.                                                 */
 long caspr_packed_size(int Cout, int Cin);
