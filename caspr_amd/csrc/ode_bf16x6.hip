@@ -24,57 +24,14 @@
 // Measured at cfg-2 (160 frames x 2048 points, 8 RK4 steps): 51.3 ms per launch against 80.4 ms for the f32 kernel
 // (DESIGN.md section 3 lists the steps from 64.8 ms and what is left: MFMA issue floor 26 ms, exposed VALU 3.6 ms,
 // piece barriers ~6 ms, weight DMA 8-9.5 ms -- the 3 MB of split weights go L2 -> LDS once per 64 points and stage).
-#include "common.h"
+#include "ode_x6.h"
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-#define XC_H 512
 #define XC_COLS 64
 #define XC_PA (256 * 64)          // one plane of a piece
 #define XC_PIECE (3 * XC_PA)      // 48 KB: 256 rows x 32 k x 3 planes
 #define XC_NPIECE 32              // per layer: 16 k chunks x 2 row halves
 #define XC_RING 2                 // LDS double buffer of pieces
 #define XC_LDS (XC_RING * XC_PIECE + (6 * XC_H + 3 * XC_H + 3 * XC_H + 8) * 4)
-
-__device__ __forceinline__ void xc_split(float x, float &h1, float &h2, float &h3)
-{
-    h1 = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
-    const float r1 = x - h1;
-    h2 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-    const float r2 = r1 - h2;
-    h3 = __uint_as_float(__float_as_uint(r2) & 0xffff0000u);
-}
-// the same exact split for a pair of values with the hardware round-to-nearest conversion (v_cvt_pk_bf16_f32): the three
-// packed words are the pair's entries of the three planes.  Exact as well: the remainder after rounding 24 bits to 8 has
-// at most 15 significant bits, after the second rounding at most 7.  4.5 VALU operations per value instead of 5.5.
-typedef __bf16 xc_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float xc_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void xc_split_pair(float x0, float x1, unsigned &p1, unsigned &p2, unsigned &p3)
-{
-    xc_f32x2 v = {x0, x1};
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, xc_bf16x2));
-    xc_f32x2 h = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
-    v = v - h;
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, xc_bf16x2));
-    h = (xc_f32x2){__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
-    v = v - h;
-    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, xc_bf16x2));
-}
-__device__ __forceinline__ unsigned xc_pack(float lo, float hi) { return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u); }
-
-struct CnfX6Args {
-    const float *y_in, *hyper, *tcol, *w0, *b0, *b1, *b2, *w3, *b3, *mbn_in, *mbn_out;
-    const float *e, *logp_in;     // DIV only: Hutchinson noise (BT,n,3), initial log-density (BT,n) or NULL
-    float *logp_out;              // DIV only
-    const unsigned char *w1x, *w2x;
-    float *y_out;
-    int ldh, n, steps, reverse;
-    float t_end;
-    unsigned long long *trace;   // debug build: per-piece s_memtime stamps of workgroup (0,0), thread 0, RK4 step 0 / stage 1
-    int diag;   // timing experiment only (CASPR_X6_DIAG=2): no product loop.  (Switches for 'no weight DMA' and 'no piece
-                // barriers' gave the breakdown in the header; as runtime branches they split the scheduling regions.)
-};
 
 // value of lane (l ^ 8) inside its 16-lane row: the partner column (value <-> tangent) of the same hidden-unit rows
 __device__ __forceinline__ float xc_partner(float v) { return dpp_mov<0x128>(v); }   // row_ror:8
@@ -481,462 +438,6 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6_kernel(CnfX6Args a)
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Wide sampling kernel: 128 points per workgroup, 32 per wave (two 16-column tiles).
-//
-// The 64-point kernel above re-streams the 3 MB of split hidden-layer weights L2 -> LDS once per 64 points and stage.
-// This kernel doubles the points per weight pass -- half the DMA, half the piece barriers and half the fragment reads per
-// point -- but 32 points per wave need 256 accumulator registers per layer, and two live layers do not fit.  It keeps ONE
-// full layer live and runs the second in row quarters:
-//   layer 1 : all 512 hidden units accumulate at once (acc1, 256 registers), k-chunk-major as before, the input-layer
-//             values of chunk kc+1 produced inside chunk kc's MFMA shadows;
-//   layer 2 : four passes over 128 output rows each (acc2, 64 registers).  Pass 0 applies layer 1's gate / bias /
-//             softplus to acc1 IN PLACE, chunk by chunk, as it splits chunk kc+1 into bf16 planes; passes 1-3 only split
-//             the stored activations again (4.5 VALU per value pair instead of a 384-register fragment file).  After each
-//             pass its 128 rows go through layer 2's epilogue and the 512 -> 3 output dot product.
-// Weights stream as 24 KB pieces (128 rows x 32 k x 3 planes; 96 MFMAs per wave per piece, as before) through a
-// four-deep LDS ring: the DMA runs three pieces ahead behind COUNTED vmcnt waits, one raw barrier per piece.  A fragments
-// live in two half-sets of two row tiles refilled alternately (6 ds_read_b128 per 24 MFMAs: half the LDS reads per MFMA of
-// the 64-point kernel, each fragment feeds two column tiles).  Sampling only; a frame's last workgroup runs padded columns.
-// ---------------------------------------------------------------------------------------------
-#define XW_PTS 128
-#define XW_PA (128 * 64)            // one plane of a piece: 128 rows x 64 B
-#define XW_PIECE (3 * XW_PA)        // 24 KB
-#define XW_RING 4
-#define XW_LDS (XW_RING * XW_PIECE + (6 * XC_H + 3 * XC_H + 3 * XC_H + 8) * 4)
-
-#define XW_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
-#define XW_RM XW_SGB(0x100, 1) XW_SGB(0x008, 1) XW_SGB(0x100, 1) XW_SGB(0x008, 1) XW_SGB(0x100, 1) XW_SGB(0x008, 1) XW_SGB(0x100, 1) XW_SGB(0x008, 1) \
-    XW_SGB(0x100, 1) XW_SGB(0x008, 1) XW_SGB(0x100, 1) XW_SGB(0x008, 1)
-#define XW_VM6(v) XW_SGB(0x002, v) XW_SGB(0x008, 1) XW_SGB(0x002, v) XW_SGB(0x008, 1) XW_SGB(0x002, v) XW_SGB(0x008, 1) XW_SGB(0x002, v) XW_SGB(0x008, 1) \
-    XW_SGB(0x002, v) XW_SGB(0x008, 1) XW_SGB(0x002, v) XW_SGB(0x008, 1)
-#define XW_VM2(v) XW_SGB(0x002, v) XW_SGB(0x008, 1) XW_SGB(0x002, v) XW_SGB(0x008, 1)
-// A region = 6 fragment reads + the 20 tail MFMAs of the half-group read one region earlier + the 4 head MFMAs of the
-// half-group just read: the reads go with the first tail MFMAs, v VALU per MFMA with the next 14, the heads last (hipcc
-// drains lgkmcnt completely in front of them -- never a counted wait -- and there the wait is free); sched_barrier closes it.
-#define XW_REGION(v) XW_RM XW_VM6(v) XW_VM6(v) XW_VM2(v) XW_SGB(0x008, 4) __builtin_amdgcn_sched_barrier(0);
-// ... with the nt table reads of a producer issued FIRST: a table read issued late in the region would be an exposed LDS
-// round trip in front of the head MFMAs
-#define XW_REGION_TAB(nt, v) XW_SGB(0x100, nt) XW_RM XW_VM6(v) XW_VM6(v) XW_VM2(v) XW_SGB(0x008, 4) __builtin_amdgcn_sched_barrier(0);
-#ifdef CASPR_DEBUG_HOOKS
-#define XW_STAMP(i) if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && step == 0 && stage == 1) a.trace[i] = __builtin_amdgcn_s_memtime();
-#else
-#define XW_STAMP(i)
-#endif
-
-__global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
-{
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char *wbuf = lds;                                   // [XW_RING][XW_PIECE]
-    float *s_gate = (float *)(lds + XW_RING * XW_PIECE);         // [3][512] sigmoid gates of layers 0,1,2
-    float *s_hb = s_gate + 3 * XC_H;                             // [3][512] layer bias * gate + hyper bias
-    float *s_w0 = s_hb + 3 * XC_H;                               // [512][3]
-    float *s_w3 = s_w0 + 3 * XC_H;                               // [3][512] output layer
-    float *s_g3 = s_w3 + 3 * XC_H;                               // [8]: gate3[3], hb3[3]
-
-    const int tid = threadIdx.x, lane0 = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g0 = lane0 >> 4;
-    const int bt = blockIdx.y;
-    const float *hy = a.hyper + (long)bt * a.ldh;
-    constexpr int GOFF = 0, BOFF = 3 * XC_H + 3;
-    const int sd = g0 < 3 ? g0 : 0;   // state component of this lane (lanes g == 3 carry a copy of component 0, never stored)
-
-    for (int i = tid; i < 3 * XC_H; i += 256) {
-        s_w0[i] = a.w0[i];
-        s_w3[i] = a.w3[i];
-    }
-
-    // state of the lane's two columns (column tile ct: point blockIdx.x * 128 + 32 * wave + 16 * ct + j)
-    float y[2], kacc[2] = {0.f, 0.f}, kprev[2] = {0.f, 0.f};
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int col = blockIdx.x * XW_PTS + 32 * wave + 16 * ct + (lane0 & 15);
-        const int cc = col < a.n ? col : a.n - 1;
-        float v = a.y_in[((long)bt * a.n + cc) * 3 + sd];
-        if (a.mbn_in) {
-            const float w = a.mbn_in[sd], bb = a.mbn_in[3 + sd], mean = a.mbn_in[6 + sd], var = a.mbn_in[9 + sd];
-            if (a.reverse) v = (v - bb) * expf(-w) * expf(0.5f * logf(var + 1e-4f)) + mean;   // normalization.py:92-94
-            else v = (v - mean) * expf(-0.5f * logf(var + 1e-4f)) * expf(w) + bb;             // normalization.py:70-74
-        }
-        y[ct] = v;
-    }
-
-    // The weight stream of one stage is a fixed sequence of 128 pieces: layer 1 chunk-major (s = 4 kc + rq), then layer 2
-    // quarter-major (s = 64 + 16 q + kc); piece (rq, kc) of a layer's wide pack sits at (rq * 16 + kc) * XW_PIECE.
-    auto piece_src = [&](int s_) -> const unsigned char * {
-        s_ &= 127;
-        const int l2 = s_ >> 6, t_ = s_ & 63;
-        const int rq = l2 ? (t_ >> 4) : (t_ & 3), kc = l2 ? (t_ & 15) : (t_ >> 2);
-        return (l2 ? a.w2x : a.w1x) + (long)(rq * 16 + kc) * XW_PIECE;
-    };
-    // LDS-DMA of sequence piece s into ring slot s & 3: 6 wave-instructions of 1 KB per wave, issued two at a time
-    auto dma = [&](int s_, int lane16, int i0) {
-        const unsigned char *src = piece_src(s_) + (wave * 6) * 1024;
-#pragma unroll
-        for (int i = i0; i < i0 + 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 1024 + lane16),
-                                             (__attribute__((address_space(3))) void *)(wbuf + (s_ & 3) * XW_PIECE + (wave * 6 + i) * 1024), 16, 0, 0);
-    };
-    const double t0 = a.reverse ? (double)a.t_end : 0.0, t1 = a.reverse ? 0.0 : (double)a.t_end;
-    const double h = (t1 - t0) / (double)a.steps;
-    const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
-
-    // three pieces in flight before the first one is consumed
-#pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-        dma(s_, lane0 * 16, 0);
-        dma(s_, lane0 * 16, 2);
-        dma(s_, lane0 * 16, 4);
-    }
-
-    f32x4 acc1[32][2];            // layer 1: pre-activations, then (pass 0 of layer 2) the activations, in place
-    f32x4 acc2[8][2];             // layer 2: the 128 rows of the running quarter
-    u32x4 bkw[2][2][3];           // B-fragment planes [chunk parity][column tile][plane]
-    f32x4 tg_, tb, tw[3];         // table values of the half chunk being produced (layer 1; half 0 in layer 2's first pass)
-    f32x4 tg2, tb2;               // layer 2, first pass: the tables of half 1 (loaded while half 0's are still in use)
-    bf16x8 afA[2][3], afB[2][3];  // A fragments: two half-sets of two row tiles x three planes
-
-    for (int step = 0; step < a.steps; ++step) {
-#pragma unroll 1
-        for (int stage = 0; stage < 4; ++stage) {
-            const double tc = (stage == 0) ? 0.0 : (stage == 3 ? 1.0 : 0.5);
-            const float t = (float)(t0 + (double)step * h + tc * h);
-            const float aw = (stage == 0) ? 0.f : (stage == 3 ? hh : h2);
-            int lane = lane0;
-            asm volatile("" : "+v"(lane));     // opaque: nothing derived from the lane id is hoisted out of the stage loop
-            const int g = lane >> 4, j = lane & 15, lane16 = lane * 16;
-            const int aoff = j * 64 + ((g ^ ((0 - (j >> 2)) & 3)) << 4);   // A-fragment read offset inside a 16-row tile of a plane
-#ifdef CASPR_DEBUG_HOOKS
-            if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && step == 0 && stage == 1) a.trace[271] = __builtin_amdgcn_s_memtime();
-            if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && step == 0 && stage == 2) a.trace[272] = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads();   // the previous stage's epilogues are done with the gate tables
-            for (int i = tid; i < 3 * XC_H; i += 256) {
-                const float gt = sigmoid_fast(hy[GOFF + i] + t * a.tcol[GOFF + i]);
-                const float hb = hy[BOFF + i] + t * a.tcol[BOFF + i];
-                const float bl = i < XC_H ? a.b0[i] : (i < 2 * XC_H ? a.b1[i - XC_H] : a.b2[i - 2 * XC_H]);
-                s_gate[i] = gt;
-                s_hb[i] = bl * gt + hb;
-            }
-            if (tid < 3) {
-                const float gt = sigmoid_fast(hy[GOFF + 3 * XC_H + tid] + t * a.tcol[GOFF + 3 * XC_H + tid]);
-                const float hb = hy[BOFF + 3 * XC_H + tid] + t * a.tcol[BOFF + 3 * XC_H + tid];
-                s_g3[tid] = gt;
-                s_g3[4 + tid] = a.b3[tid] * gt + hb;
-            }
-            __syncthreads();
-
-            // ---- stage input of this lane's two columns, all three components
-            float ys[2][3];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const float yst = (stage == 0) ? y[ct] : y[ct] + aw * kprev[ct];
-                ys[ct][0] = __shfl(yst, j);
-                ys[ct][1] = __shfl(yst, 16 + j);
-                ys[ct][2] = __shfl(yst, 32 + j);
-            }
-
-            auto put_pair = [&](int kc, int ct, int q, float v0, float v1) __attribute__((always_inline)) {
-                unsigned p1, p2, p3;
-                xc_split_pair(v0, v1, p1, p2, p3);
-                bkw[kc & 1][ct][0][q] = p1;
-                bkw[kc & 1][ct][1][q] = p2;
-                bkw[kc & 1][ct][2][q] = p3;
-            };
-            // input layer 3 -> 512 (diffeq_layers.py:83-90 + softplus): slots 2q, 2q+1 of chunk kc = units 32kc + 16h + 4g + r
-            auto wtab_in = [&](int kc, int hf) __attribute__((always_inline)) {
-                const int c = 32 * kc + 16 * hf + 4 * g;
-                tg_ = ld4(s_gate + c);
-                tb = ld4(s_hb + c);
-                tw[0] = ld4(s_w0 + 3 * c);
-                tw[1] = ld4(s_w0 + 3 * c + 4);
-                tw[2] = ld4(s_w0 + 3 * c + 8);
-            };
-            auto wquad_in = [&](int kc, int ct, int q) __attribute__((always_inline)) {
-                const float w[12] = {tw[0][0], tw[0][1], tw[0][2], tw[0][3], tw[1][0], tw[1][1], tw[1][2], tw[1][3], tw[2][0], tw[2][1], tw[2][2], tw[2][3]};
-                float v[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int r = 2 * (q & 1) + e;
-                    const float pre = (w[3 * r] * ys[ct][0] + w[3 * r + 1] * ys[ct][1] + w[3 * r + 2] * ys[ct][2]) * tg_[r] + tb[r];
-                    v[e] = softplus_fast(pre);
-                }
-                put_pair(kc, ct, q, v[0], v[1]);
-            };
-            // layer 2's operand from acc1: units 32kc + 16h + 4g + r = rows of acc1[2kc + h]; FIRST pass: gate / bias /
-            // softplus applied in place (tables of half 0 in tg_/tb, of half 1 in tg2/tb2), later passes: the stored
-            // activation is only split again
-            auto wtab_e1 = [&](int kc, int hf) __attribute__((always_inline)) {
-                const int c = 32 * kc + 16 * hf + 4 * g;
-                if (hf == 0) {
-                    tg_ = ld4(s_gate + XC_H + c);
-                    tb = ld4(s_hb + XC_H + c);
-                } else {
-                    tg2 = ld4(s_gate + XC_H + c);
-                    tb2 = ld4(s_hb + XC_H + c);
-                }
-            };
-            auto wquad_e1 = [&](int kc, int ct, int q, bool first) __attribute__((always_inline)) {
-                float v[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int r = 2 * (q & 1) + e;
-                    float hv = acc1[2 * kc + (q >> 1)][ct][r];
-                    if (first) {
-                        hv = softplus_fast(hv * (q < 2 ? tg_[r] : tg2[r]) + (q < 2 ? tb[r] : tb2[r]));
-                        acc1[2 * kc + (q >> 1)][ct][r] = hv;
-                    } else {
-                        // opaque: the split of a stored activation is the same in passes 1-3, and hipcc would hoist all sixteen
-                        // chunks' planes (384 registers) out of the pass loop into scratch
-                        asm volatile("" : "+v"(hv));
-                    }
-                    v[e] = hv;
-                }
-                put_pair(kc, ct, q, v[0], v[1]);
-            };
-            // layer 1 producer schedule of chunk kn: slot 0 = tables of half 0, 1..4 = its quads, 5 = tables of half 1, 6..9 = its quads
-            auto prod_in = [&](int kn, int slot) __attribute__((always_inline)) {
-                if (slot == 0) wtab_in(kn, 0);
-                else if (slot >= 1 && slot <= 4) wquad_in(kn, (slot - 1) & 1, (slot - 1) >> 1);
-                else if (slot == 5) wtab_in(kn, 1);
-                else if (slot >= 6 && slot <= 9) wquad_in(kn, (slot - 6) & 1, 2 + ((slot - 6) >> 1));
-            };
-            // layer 2: four slots of two quads each (slot = quad index q: half 0 in slots 0, 1, half 1 in slots 2, 3)
-            auto prod_e1 = [&](int kn, int slot, bool first) __attribute__((always_inline)) {
-                wquad_e1(kn, 0, slot, first);
-                wquad_e1(kn, 1, slot, first);
-            };
-
-            // 24 MFMAs of a half-group = row tiles m0, m0 + 1 x both column tiles x six terms (smallest first, term-major: four
-            // independent accumulators between dependent MFMAs), issued as a HEAD of the first term's 4 at the end of the region
-            // that read the fragments and a TAIL of 20 in the next region
-            auto mma_terms = [&](auto &acc, int m0, const bf16x8 (&af)[2][3], const u32x4 (&b)[2][3], int tm0, int tm1) __attribute__((always_inline)) {
-                bf16x8 bb[2][3];
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bb[ct][pl] = __builtin_bit_cast(bf16x8, b[ct][pl]);
-                constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-                for (int tm = tm0; tm < tm1; ++tm)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-                            acc[m0 + u][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][TA[tm]], bb[ct][TB[tm]], acc[m0 + u][ct], 0, 0, 0);
-            };
-            auto whead = [&](auto &acc, int m0, const bf16x8 (&af)[2][3], const u32x4 (&b)[2][3]) __attribute__((always_inline)) {
-                mma_terms(acc, m0, af, b, 0, 1);
-            };
-            auto wtail = [&](auto &acc, int m0, const bf16x8 (&af)[2][3], const u32x4 (&b)[2][3]) __attribute__((always_inline)) {
-                mma_terms(acc, m0, af, b, 1, 6);
-            };
-            auto wrd = [&](bf16x8 (&af)[2][3], const unsigned char *A, int hg) __attribute__((always_inline)) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) af[u][pl] = *(const bf16x8 *)(A + pl * XW_PA + (2 * hg + u) * 1024);
-            };
-            // barrier in front of sequence piece sq: this wave's share of it has landed once at most the 12 DMA instructions of
-            // the two younger pieces are outstanding; lgkmcnt: this wave's reads of the ring slot about to be refilled
-            auto piece_head = [&](int sq_) __attribute__((always_inline)) {
-                XW_STAMP(2 * sq_)
-                asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                XW_STAMP(2 * sq_ + 1)
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            };
-
-            // ================= layer 1: 16 chunks x 4 row quarters, sequence pieces 0..63 =================
-#pragma unroll
-            for (int mi = 0; mi < 32; ++mi) {
-                acc1[mi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc1[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            // chunk 0 of the input layer up front (exposed: 1/16 of the input layer)
-#pragma unroll
-            for (int slot = 0; slot < 10; ++slot) prod_in(0, slot);
-#pragma unroll
-            for (int s1 = 0; s1 < 64; ++s1) {
-                const int kc = s1 >> 2, rq = s1 & 3;
-                const int kcp = (s1 - 1) >> 2, rqp = (s1 - 1) & 3;
-                const bool more = kc + 1 < 16;
-                const unsigned char *A = wbuf + (s1 & 3) * XW_PIECE + aoff;
-                piece_head(s1);
-                // The 16 regions of chunk kc (index 4 rq + r) carry the producers of chunk kc + 1: its slot k in region k + 1
-                // (region 0 still multiplies chunk kc - 1's planes); a table slot goes FIRST in its region.
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int slot = 4 * rq + r - 1;
-                    const bool prod = more && slot >= 0 && slot <= 9, tab = prod && (slot == 0 || slot == 5);
-                    if (tab) prod_in(kc + 1, slot);
-                    // region r: reads hg r -> afA / afB alternately | tail of the previous half-group | head of hg r
-                    if ((r & 1) == 0) wrd(afA, A, r); else wrd(afB, A, r);
-                    if (r < 3) dma(s1 + 3, lane16, 2 * r);
-                    if (r == 0) {
-                        if (s1 > 0) wtail(acc1, 8 * rqp + 6, afB, bkw[kcp & 1]);
-                        whead(acc1, 8 * rq + 0, afA, bkw[kc & 1]);
-                    } else if (r == 1) {
-                        wtail(acc1, 8 * rq + 0, afA, bkw[kc & 1]);
-                        whead(acc1, 8 * rq + 2, afB, bkw[kc & 1]);
-                    } else if (r == 2) {
-                        wtail(acc1, 8 * rq + 2, afB, bkw[kc & 1]);
-                        whead(acc1, 8 * rq + 4, afA, bkw[kc & 1]);
-                    } else {
-                        wtail(acc1, 8 * rq + 4, afA, bkw[kc & 1]);
-                        whead(acc1, 8 * rq + 6, afB, bkw[kc & 1]);
-                    }
-                    if (prod && !tab) prod_in(kc + 1, slot);
-                    if (tab) { XW_REGION_TAB(5, 2) } else { XW_REGION(2) }
-                }
-            }
-            wtail(acc1, 8 * 3 + 6, afB, bkw[1]);          // the rest of the last half-group of layer 1 (chunk 15)
-            XW_STAMP(256)
-
-            // ================= layer 2: four passes of 16 pieces, sequence pieces 64 + 16 q + kc =================
-            float part[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-            auto pass = [&](int q, bool first) __attribute__((always_inline)) {
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    acc2[mi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    acc2[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                // chunk 0 of this pass up front (exposed)
-                if (first) {
-                    wtab_e1(0, 0);
-                    wtab_e1(0, 1);
-                }
-#pragma unroll
-                for (int slot = 0; slot < 4; ++slot) prod_e1(0, slot, first);
-#pragma unroll
-                for (int kc = 0; kc < 16; ++kc) {
-                    const int sq = 64 + 16 * q + kc;
-                    const bool more = kc + 1 < 16;
-                    const unsigned char *A = wbuf + (kc & 3) * XW_PIECE + aoff;     // (64 + 16 q + kc) & 3 == kc & 3
-                    piece_head(sq);
-                    // Producer schedule of chunk kc + 1 (tables one region ahead of their first use, in their own registers):
-                    //   region 0: tables of half 0 | slot 3 of chunk kc     region 1: slot 0
-                    //   region 2: tables of half 1 | slot 1                 region 3: slot 2        (slot 3: next piece's region 0)
-                    // region 0: reads hg0 -> afA | tail of hg3 of the previous piece (afB) | head of hg0
-                    if (first && more) wtab_e1(kc + 1, 0);
-                    wrd(afA, A, 0);
-                    dma(sq + 3, lane16, 0);
-                    if (kc > 0) wtail(acc2, 6, afB, bkw[(kc - 1) & 1]);
-                    if (kc > 0) prod_e1(kc, 3, first);
-                    whead(acc2, 0, afA, bkw[kc & 1]);
-                    if (first) { XW_REGION_TAB(2, 3) } else { XW_REGION(1) }
-                    // region 1: reads hg1 -> afB | tail of hg0 (afA) | head of hg1
-                    wrd(afB, A, 1);
-                    dma(sq + 3, lane16, 2);
-                    wtail(acc2, 0, afA, bkw[kc & 1]);
-                    whead(acc2, 2, afB, bkw[kc & 1]);
-                    if (more) prod_e1(kc + 1, 0, first);
-                    if (first) { XW_REGION(3) } else { XW_REGION(1) }
-                    // region 2: reads hg2 -> afA | tail of hg1 (afB) | head of hg2
-                    if (first && more) wtab_e1(kc + 1, 1);
-                    wrd(afA, A, 2);
-                    dma(sq + 3, lane16, 4);
-                    wtail(acc2, 2, afB, bkw[kc & 1]);
-                    whead(acc2, 4, afA, bkw[kc & 1]);
-                    if (more) prod_e1(kc + 1, 1, first);
-                    if (first) { XW_REGION_TAB(2, 3) } else { XW_REGION(1) }
-                    // region 3: reads hg3 -> afB | tail of hg2 (afA) | head of hg3
-                    wrd(afB, A, 3);
-                    wtail(acc2, 4, afA, bkw[kc & 1]);
-                    whead(acc2, 6, afB, bkw[kc & 1]);
-                    if (more) prod_e1(kc + 1, 2, first);
-                    if (first) { XW_REGION(3) } else { XW_REGION(1) }
-                }
-                wtail(acc2, 6, afB, bkw[1]);               // the rest of the last half-group of the pass (chunk 15)
-                XW_STAMP(257 + 2 * q)
-                // ---- epilogue of hidden layer 2 for rows 128 q .. 128 q + 127 + their share of the 512 -> 3 output layer
-                int le = lane;   // opaque again: the table addresses must not be hoisted above the product loop
-                asm volatile("" : "+v"(le));
-                const int ge = le >> 4;
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    const int c = 128 * q + 16 * mi + 4 * ge;
-                    const f32x4 gt = ld4(s_gate + 2 * XC_H + c), hb = ld4(s_hb + 2 * XC_H + c);
-                    const f32x4 wx3 = ld4(s_w3 + c), wy3 = ld4(s_w3 + XC_H + c), wz3 = ld4(s_w3 + 2 * XC_H + c);
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float hv = softplus_fast(acc2[mi][ct][r] * gt[r] + hb[r]);
-                            part[0][ct] += wx3[r] * hv;
-                            part[1][ct] += wy3[r] * hv;
-                            part[2][ct] += wz3[r] * hv;
-                        }
-                }
-                XW_STAMP(258 + 2 * q)
-            };
-            XW_STAMP(270)
-            pass(0, true);
-#pragma unroll 1
-            for (int q = 1; q < 4; ++q) pass(q, false);
-
-            // ---- output ConcatSquash (no softplus: odefunc.py:103): sum the four lane groups, every lane gets all three
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                float o[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    float v = part[d][ct];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
-                    o[d] = v * s_g3[d] + s_g3[4 + d];
-                }
-                const float od = sd == 0 ? o[0] : (sd == 1 ? o[1] : o[2]);
-                kprev[ct] = od;
-                kacc[ct] = (stage == 0) ? od : ((stage == 3) ? kacc[ct] + od : kacc[ct] + 2.0f * od);
-            }
-        }
-        y[0] = y[0] + h6 * kacc[0];
-        y[1] = y[1] + h6 * kacc[1];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the three pieces left in flight by the last stage
-
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int col = blockIdx.x * XW_PTS + 32 * wave + 16 * ct + (lane0 & 15);
-        if (col < a.n && g0 < 3) {
-            float v = y[ct];
-            if (a.mbn_out) {
-                const float w = a.mbn_out[sd], bb = a.mbn_out[3 + sd], mean = a.mbn_out[6 + sd], var = a.mbn_out[9 + sd];
-                if (a.reverse) v = (v - bb) * expf(-w) * expf(0.5f * logf(var + 1e-4f)) + mean;
-                else v = (v - mean) * expf(-0.5f * logf(var + 1e-4f)) * expf(w) + bb;
-            }
-            a.y_out[((long)bt * a.n + col) * 3 + sd] = v;
-        }
-    }
-}
-
-// wide pack: (512, ldw) f32 -> [row quarter 4][k chunk 16][plane 3][row 0..127][piece'][8 bf16]; k order and swizzle as below
-__global__ void pack_weight_cnf_x6w_kernel(const float *__restrict__ w, int ldw, unsigned char *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (row quarter * 16 + chunk) * 512 + row * 4 + piece
-    if (i >= 4 * 16 * 512) return;
-    const int piece = i & 3, row = (i >> 2) & 127;
-    const int ck = i >> 9, kc = ck & 15, rq = ck >> 4;
-    const int co = rq * 128 + row;
-    float hs[3][8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int k = 32 * kc + (q < 4 ? 4 * piece + q : 16 + 4 * piece + q - 4);
-        xc_split(w[(long)co * ldw + k], hs[0][q], hs[1][q], hs[2][q]);
-    }
-    const int sw = (0 - (row >> 2)) & 3;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        u32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = xc_pack(hs[pl][2 * q], hs[pl][2 * q + 1]);
-        *(u32x4 *)(out + (long)ck * XW_PIECE + pl * XW_PA + row * 64 + ((piece ^ sw) << 4)) = v;
-    }
-}
-
 // (512, ldw) f32 hidden-layer weight -> [row half 2][k chunk 16][plane 3][row 0..255][piece'][8 bf16], k listed in the
 // D-fragment order of the producing layer (see the header): piece g, element q <-> k = 32 kc + (q < 4 ? 4g + q : 16 + 4g + q - 4)
 __global__ void pack_weight_cnf_x6_kernel(const float *__restrict__ w, int ldw, unsigned char *__restrict__ out)
@@ -964,19 +465,19 @@ __global__ void pack_weight_cnf_x6_kernel(const float *__restrict__ w, int ldw, 
 
 #ifdef CASPR_DEBUG_HOOKS
 static unsigned long long *g_x6_trace = nullptr;
-extern "C" void caspr_debug_set_x6_trace(unsigned long long *dev_buf) { g_x6_trace = dev_buf; }   // debug build only: >= 288 u64
+extern "C" void caspr_debug_set_x6_trace(unsigned long long *dev_buf) { g_x6_trace = dev_buf; }   // debug build only: >= 512 u64
 #endif
 // one buffer per hidden layer holds BOTH images: [0, XC_PACK) the 48 KB-piece layout of cnf_rk4_x6_kernel (divergence
-// variant, short frames), [XC_PACK, 2 XC_PACK) the 24 KB-piece layout of cnf_rk4_x6w_kernel
+// variant), [XC_PACK, XC_PACK + XW_PACK) the 24 KB-piece fragment-order layout of cnf_rk4_x6w_kernel (sampling)
 #define XC_PACK (2L * 16 * XC_PIECE)
-extern "C" long caspr_cnf_x6_packed_bytes(void) { return 2 * XC_PACK; }
+extern "C" long caspr_cnf_x6_packed_bytes(void) { return XC_PACK + XW_PACK; }
 
 extern "C" int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream)
 {
     CASPR_REQUIRE(w && packed && ldw >= XC_H, "pack_weight_cnf_x6: bad arguments");
     CASPR_REQUIRE(((uintptr_t)packed % 16) == 0, "pack_weight_cnf_x6: packed must be 16-byte aligned");
     pack_weight_cnf_x6_kernel<<<2 * 16 * 1024 / 256, 256, 0, (hipStream_t)stream>>>(w, ldw, (unsigned char *)packed);
-    pack_weight_cnf_x6w_kernel<<<4 * 16 * 512 / 256, 256, 0, (hipStream_t)stream>>>(w, ldw, (unsigned char *)packed + XC_PACK);
+    caspr_cnf_x6w_pack(w, ldw, (unsigned char *)packed + XC_PACK, (hipStream_t)stream);
     CASPR_CHECK_LAUNCH("pack_weight_cnf_x6");
     return CASPR_OK;
 }
@@ -1001,23 +502,26 @@ extern "C" int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int l
     CASPR_IF_DEBUG(a.trace = g_x6_trace;)
     a.diag = CASPR_DEBUG_ENV_INT("CASPR_X6_DIAG");   // timing experiments, debug build only
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
-    static CasprLdsOptIn optin_s, optin_d, optin_w;
-    // The 128-point kernel is an experiment (53.5 ms against this kernel's 50.5 at cfg-2, see its header and DESIGN.md): only
-    // the debug build can select it (CASPR_X6_WIDE=1), for tools/cnf_x6w_trace.py
-    const bool wide = !e && CASPR_DEBUG_ENV_INT("CASPR_X6_WIDE") != 0;
+    // Kernel choice by the presence of e only, never by BT or n: a frame's result does not depend on the batch around it.
+    // Sampling (no divergence): the 128-point kernel of ode_bf16x6w.hip; the debug build can force the 64-point one
+    // (CASPR_X6_NARROW=1) for A/B timing (tools/cnf_x6w_trace.py).
+    if (!e && CASPR_DEBUG_ENV_INT("CASPR_X6_NARROW") == 0) {
+        a.w1x += XC_PACK;
+        a.w2x += XC_PACK;
+        const int rc = caspr_cnf_x6w_launch(a, BT, (hipStream_t)stream);
+        if (rc != CASPR_OK) return rc;
+        CASPR_CHECK_LAUNCH("cnf_rk4_x6 (128-point kernel)");
+        return CASPR_OK;
+    }
+    static CasprLdsOptIn optin_s, optin_d;
     const hipError_t err = e ? caspr_lds_opt_in(optin_d, (const void *)cnf_rk4_x6_kernel<true>, XC_LDS)
-                             : (wide ? caspr_lds_opt_in(optin_w, (const void *)cnf_rk4_x6w_kernel, XW_LDS)
-                                     : caspr_lds_opt_in(optin_s, (const void *)cnf_rk4_x6_kernel<false>, XC_LDS));
+                             : caspr_lds_opt_in(optin_s, (const void *)cnf_rk4_x6_kernel<false>, XC_LDS);
     if (err != hipSuccess) {
         caspr_set_error("cnf_rk4_x6: hipFuncSetAttribute failed: %s", hipGetErrorString(err));
         return CASPR_ELAUNCH;
     }
     if (e) cnf_rk4_x6_kernel<true><<<dim3(ceil_div(n, XC_COLS / 2), BT), dim3(256), XC_LDS, (hipStream_t)stream>>>(a);
-    else if (wide) {
-        a.w1x += XC_PACK;
-        a.w2x += XC_PACK;
-        cnf_rk4_x6w_kernel<<<dim3(ceil_div(n, XW_PTS), BT), dim3(256), XW_LDS, (hipStream_t)stream>>>(a);
-    } else cnf_rk4_x6_kernel<false><<<dim3(ceil_div(n, XC_COLS), BT), dim3(256), XC_LDS, (hipStream_t)stream>>>(a);
+    else cnf_rk4_x6_kernel<false><<<dim3(ceil_div(n, XC_COLS), BT), dim3(256), XC_LDS, (hipStream_t)stream>>>(a);
     CASPR_CHECK_LAUNCH("cnf_rk4_x6");
     return CASPR_OK;
 }

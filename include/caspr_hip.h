@@ -193,12 +193,17 @@ int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const floa
                       int n, void *stream);
 
 /* The same solve with the two hidden layers on the bf16 matrix pipe in the exact three-way split of
- * caspr_conv1x1_bf16x6_f32 (csrc/ode_bf16x6.hip; the Python host's default, ops.set_matmul_mode): a workgroup owns 64
- * points (32 points + their 32 tangent columns when the divergence is integrated), each wave keeps all 512 hidden units
- * of its 16 columns in registers across the layers (accumulator fragments are the next layer's operand fragments), LDS
- * only stages the shared weight pieces.  w1x / w2x = the (512,512) hidden weights packed by caspr_pack_weight_cnf_x6
- * (caspr_cnf_x6_packed_bytes() bytes each); every other argument as caspr_cnf_rk4_f32, including e / logp_in / logp_out
- * (NULL together: sampling; given: forward()/NLL with the Hutchinson divergence, odefunc.py:119-142).                 */
+ * caspr_conv1x1_bf16x6_f32 (the Python host's default, ops.set_matmul_mode).  Two kernels behind one entry, chosen by the
+ * presence of e ONLY (never by BT or n: a frame's result does not depend on the batch around it):
+ *   e == NULL (sampling, cnf.py:71-74 with logpx = None): csrc/ode_bf16x6w.hip -- a workgroup owns 128 points, a wave all
+ *     512 hidden units of its 32 points on v_mfma_f32_32x32x16_bf16; layer 1's accumulators / activations live in the
+ *     accumulator file, layer 2 runs in four 128-row passes over them; weights stream through a four-deep LDS ring;
+ *   e given (forward()/NLL with the Hutchinson divergence, odefunc.py:119-142): csrc/ode_bf16x6.hip -- a workgroup owns 32
+ *     points + their 32 tangent columns, a wave all 512 hidden units of its 16 columns on v_mfma_f32_16x16x32_bf16.
+ * In both the hidden activation never leaves the registers of its lane (accumulator fragments are the next layer's operand
+ * fragments) and LDS only stages the shared weight pieces.  w1x / w2x = the (512,512) hidden weights packed by
+ * caspr_pack_weight_cnf_x6 (caspr_cnf_x6_packed_bytes() bytes each: the images of both kernels); every other argument as
+ * caspr_cnf_rk4_f32, including e / logp_in / logp_out (NULL together, or given together).                              */
 long caspr_cnf_x6_packed_bytes(void);
 int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream);
 int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int ldh, const float *tcol,

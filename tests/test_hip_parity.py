@@ -440,11 +440,11 @@ def test_cnf_sample(dev, seeded_sd, model, n, steps):
     record("cnf_sample_n%d_s%d" % (n, steps), got, want, 1e-5)
 
 
-@pytest.mark.parametrize("n,steps", [(256, 8), (100, 3), (2048, 2)])
+@pytest.mark.parametrize("n,steps", [(256, 8), (100, 3), (2048, 2), (333, 4)])
 def test_cnf_sample_bf16x6(dev, seeded_sd, model, n, steps):
-    """Default sampling kernel (csrc/ode_bf16x6.hip): hidden layers as six bf16 MFMA products of exactly split operands,
-    activations kept in registers between the layers.  Same 1e-5 criterion against the oracle as the f32 kernel, and
-    within 5e-6 of the f32 kernel itself."""
+    """Default sampling kernel (csrc/ode_bf16x6w.hip, 128 points per workgroup; n = 100 / 333: ragged last workgroup): hidden
+    layers as six bf16 MFMA products of exactly split operands, activations kept in registers between the layers.  Same 1e-5
+    criterion against the oracle as the f32 kernel, and within 5e-6 of the f32 kernel itself."""
     from caspr_amd import ops
     BT = 3
     c, y = rnd(31, BT, 1600), rnd(32, BT, n, 3)

@@ -355,3 +355,39 @@ def test_bf16x6_split_is_exact_and_six_products_are_f32_accurate():
     assert e6 <= 1.5 * e32 + 1e-7, (e6, e32)
     three = (w1 @ a1) + (w1 @ a2) + (w2 @ a1)                                  # what "bf16x3" would give: not f32-accurate
     assert float((three.double() - ref).abs().max()) > 3.0 * e32
+
+
+def test_cnf_x6w_kernel_keeps_its_accumulator_file_to_itself():
+    """cnf_rk4_x6w_kernel (csrc/ode_bf16x6w.hip) manages a0..a255 by hand through inline asm; hipcc must keep out of them and
+    must not spill (a scratch reload would also drain the LDS-DMA queue with vmcnt(0)).  Checked on the code object that was
+    linked into libcaspr_hip.so: no scratch, no spills, exactly the accumulator moves the source writes (256 zeroing writes +
+    256 in-place activation writes, 256 + 256 reads in pass 0 / passes 1-3), layer 1's MFMAs on a[..] and every other MFMA in
+    the VGPR form, M0 written once per LDS-DMA statement and by nothing else."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "caspr_amd", "csrc", "ode_bf16x6w.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("needs the in-tree object and the ROCm LLVM tools")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        fat, elf = os.path.join(d, "w.fatbin"), os.path.join(d, "w.elf")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
+        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", elf], text=True)
+        dis = subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", elf], text=True)
+    meta = notes[notes.index("_Z18cnf_rk4_x6w_kernel9CnfX6Args") - 400:]
+    meta = meta[:meta.index("_Z18cnf_rk4_x6w_kernel9CnfX6Args") + 600]
+    assert re.search(r"\.private_segment_fixed_size:\s+0\b", meta) and re.search(r"\.vgpr_spill_count:\s+0\b", meta), meta
+    assert re.search(r"\.agpr_count:\s+256\b", meta), meta
+    body = dis[dis.index("<_Z18cnf_rk4_x6w_kernel9CnfX6Args>:"):]
+    body = body[:body.index("s_endpgm")]
+    ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.startswith("\t")]
+    count = lambda pat: sum(1 for i in ins if re.match(pat, i))
+    assert count(r"scratch_") == 0
+    assert count(r"v_accvgpr_read_b32") == 512 and count(r"v_accvgpr_write_b32") == 512, (count(r"v_accvgpr_read_b32"), count(r"v_accvgpr_write_b32"))
+    assert count(r"v_accvgpr_mov") == 0
+    mfma = [i for i in ins if i.startswith("v_mfma")]
+    on_acc = [i for i in mfma if re.match(r"v_mfma_f32_32x32x16_bf16 a\[", i)]
+    assert len(on_acc) == 8 * 4 * 12 and all(" a[" not in i for i in mfma if i not in on_acc), (len(mfma), len(on_acc))
+    dma = count(r"global_load_lds_dwordx4")
+    assert dma % 2 == 0 and sum(1 for i in ins if re.search(r"\bm0\b", i)) == dma // 2, dma
