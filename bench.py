@@ -119,8 +119,7 @@ def main():
     times_cpu = sp_all[0, :, 0, 3].clone() if sp_all is not None else x_all[0, :, 0, 3] / 5.0
     x = x_all.to(dev)
     ts = times_cpu.to(dev)
-    torch.manual_seed(rank)
-    ybase = torch.randn(hi - lo, T, N, 3).to(dev)        # base samples (models/utils.py:25), resident before timing
+    torch.manual_seed(rank)      # the base samples are drawn inside every reconstruct() call, on the CPU generator (models/utils.py:25)
 
     calibration = None
     if args.calibrate_cnf_steps > 0:
@@ -128,8 +127,10 @@ def main():
         calibration = {"tol": args.calibrate_cnf_steps, "chosen": args.cnf_steps, "step_doubling_diffs": {str(k): v for k, v in diffs.items()}}
 
     def step():
+        # the reference's own call (evaluations.py:108-114): the CPU draw of the base samples and their host-to-device copy are
+        # INSIDE the step (reconstruct() overlaps them with the encoder, caspr_amd/models/caspr.py:_draw_early)
         with torch.no_grad():
-            return model.reconstruct(x, num_points=N, timestamps=ts, y=ybase)
+            return model.reconstruct(x, num_points=N, timestamps=ts)
 
     def timed_steps(k):
         """k steps bracketed by barrier + synchronize on both sides; returns (seconds [max over ranks], last outputs)."""
@@ -156,6 +157,16 @@ def main():
     elapsed, out = timed_steps(args.steps)
     timers = {k: list(v) for k, v in ops.TIMERS.items()}
     mode = ops.matmul_mode()
+    # ---- detail pass (NOT part of the headline timing): one HIP-event pair per launch of the other matrix kernels, for the
+    # per-kernel roofline entries (every rank runs it so that the barriers of the sub-blocks below still pair up)
+    torch.cuda.synchronize()
+    ops.TIMERS.clear()
+    ops.TIMING = 2
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ops.TIMING = False
+    detail = {k: [a.elapsed_time(b_) for a, b_ in v] for k, v in ops.TIMERS.items() if k.startswith("k:")}
 
     # ---- the same step on the pure f32-MFMA kernels (sub-block; every rank takes part so the barriers pair up)
     f32_block = None
@@ -188,24 +199,24 @@ def main():
         # HBM traffic per launch cannot be counted from inside this process: it comes from the committed PMC passes of this same
         # command and workload (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, gfx950 correction), keyed by kernel + shape
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "cnf_traffic.json")
-        if os.path.exists(tpath):
-            key = "%s:%dx%dx%d:s%d" % ("cnf_rk4_x6_kernel" if x6 else "cnf_rk4_kernel", hi - lo, T, N, args.cnf_steps)
-            tj = json.load(open(tpath)).get(key)
-            if tj:
-                traffic = int(1024 * (tj["fetch_size_kb_per_launch"] * tj["fetch_correction"] + tj["write_size_kb_per_launch"]))
-                traffic_src = tj["source"]
-        roofline = {"kernel": "cnf_rk4_x6_kernel (csrc/ode_bf16x6.hip)" if x6 else "cnf_rk4_kernel<false> (csrc/ode.hip)",
+        tpath = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+        traffic_table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        tj = traffic_table.get("%s:%dx%dx%d:s%d" % ("cnf_rk4_x6w_kernel" if x6 else "cnf_rk4_kernel", hi - lo, T, N, args.cnf_steps))
+        if tj:
+            traffic = int(1024 * (tj["fetch_size_kb_per_launch"] * tj["fetch_correction"] + tj["write_size_kb_per_launch"]))
+            traffic_src = tj["source"]
+        roofline = {"kernel": "cnf_rk4_x6w_kernel (csrc/ode_bf16x6w.hip)" if x6 else "cnf_rk4_kernel<false> (csrc/ode.hip)",
                     "bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per f32 product = 416.7 f32-equivalent TFLOP/s"
                                   if x6 else "dense f32-input MFMA peak"),
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launch_ms": round(cnf_ms, 3), "launches_timed": len(ev), "flop_per_launch": flop}
         breakdown = {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3) for k, v in timers.items()}
+        roofline["kernels"] = kernel_rooflines(roofline, detail, traffic_table, (hi - lo, T, N))
 
         cpu, parity_ok = None, None
         if not args.no_cpu_baseline:
-            cpu, parity_ok = cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, ybase, times_cpu, ts, T, N, dense_sequences)
+            cpu, parity_ok = cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, out[0], times_cpu, ts, T, N, dense_sequences)
             if not parity_ok:
                 rc = 1
 
@@ -222,6 +233,7 @@ def main():
                                    % (cfg_name, B, T, N, N, weights_desc),
                        "global_batch": world * B, "seq_len": T, "num_pts": N, "cnf_rk4_steps": args.cnf_steps,
                        "latent_rk4_steps": args.latent_steps, "cnf_divergence": "skipped (sampling)", "parallelism": "seq-shard x%d" % world,
+                       "base_samples": "drawn in-step (CPU generator, models/utils.py:25), pinned buffer + async copy under the encoder",
                        "matrix_products": mode, "calibration": calibration,
                        "nfe": [int(v) for v in model.get_nfe()]},
             "roofline": roofline, "f32_mfma_path": f32_block, "cpu_baseline": cpu, "parity_ok": parity_ok, "stage_ms_per_step": breakdown,
@@ -237,12 +249,48 @@ def main():
     sys.exit(rc)
 
 
+def kernel_rooflines(cnf, detail, traffic_table, shape):
+    """achieved / peak / frac for the matrix kernels behind the CNF solve, from the detail pass' per-launch HIP events:
+    the largest pointwise conv on the bf16x6 kernel (the 1600 -> 1600 head layer at cfg-2) and all of them together
+    (2 Cin Cout FLOP per row; conv -> GroupNorm calls include their statistics epilogue and finalize kernel), and the fused
+    set-abstraction kernels (f32 MFMA; 2 FLOP per multiply-add over every gathered sample).  `traffic` = HBM-side bytes per
+    launch from the committed PMC passes (profiles/kernel_traffic.json, keyed by kernel + workload shape), or null."""
+    out = [{k: cnf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms")}]
+    wl = "%dx%dx%d" % shape
+    convs = {}
+    for k, ms in detail.items():
+        p = k.split(":")
+        if p[1] == "conv1x1_bf16x6":
+            convs.setdefault((int(p[2]), int(p[3]), int(p[4])), []).extend(ms)
+    if convs:
+        flop_all = sum(2.0 * ci * co * rows * len(ms) for (ci, co, rows), ms in convs.items())
+        ms_all = sum(sum(ms) for ms in convs.values())
+        (ci, co, rows), ms = max(convs.items(), key=lambda kv: kv[0][0] * kv[0][1] * kv[0][2])
+        a_big = 2.0 * ci * co * rows / (sum(ms) / len(ms) * 1e-3) / 1e12
+        tj = traffic_table.get("conv1x1_bf16x6_kernel:%dx%d:%s" % (ci, co, wl))
+        out.append({"kernel": "conv1x1_bf16x6_kernel (csrc/gemm_bf16x6.hip), largest layer %d -> %d over %d rows" % (ci, co, rows), "bound": "mfma",
+                    "achieved": round(a_big, 3), "peak": round(PEAK_MFMA_BF16_TFLOPS / 6.0, 1), "unit": "TFLOP/s", "frac": round(a_big / (PEAK_MFMA_BF16_TFLOPS / 6.0), 4),
+                    "traffic": int(1024 * (tj["fetch_size_kb_per_launch"] * tj["fetch_correction"] + tj["write_size_kb_per_launch"])) if tj else None,
+                    "launch_ms": round(sum(ms) / len(ms), 3),
+                    "all_layers": {"launches_per_step": sum(len(m) for m in convs.values()) // 2, "ms_per_step": round(ms_all / 2, 3),
+                                   "achieved": round(flop_all / (ms_all * 1e-3) / 1e12, 3), "frac": round(flop_all / (ms_all * 1e-3) / 1e12 / (PEAK_MFMA_BF16_TFLOPS / 6.0), 4)}})
+    sa = [(float(k.split(":")[5]) * 1e6, ms) for k, ms in detail.items() if k.split(":")[1] == "sa_mlp_max"]
+    if sa:
+        flop = sum(f * len(ms) for f, ms in sa)
+        ms_all = sum(sum(ms) for _, ms in sa)
+        a_sa = flop / (ms_all * 1e-3) / 1e12
+        out.append({"kernel": "sa_small_kernel / sa_mlp_kernel (csrc/sa_mlp.hip), all fused set-abstraction launches", "bound": "mfma", "achieved": round(a_sa, 3),
+                    "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(a_sa / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": sum(len(ms) for _, ms in sa) // 2, "ms_per_step": round(ms_all / 2, 3)})
+    return out
+
+
 def cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, ybase, times_cpu, ts, T, N, dense_sequences):
     """The CPU oracle on a bounded sample of the same workload (timed), and the asserted HIP-vs-oracle parity:
-      * the FIRST and the LAST sequence of this rank's batch against the f32 oracle and -- sequence 0 -- its f64 evaluation:
-        |hip - f64| <= 1e-5 + 5 |oracle32 - f64| on sampled xyz, T-NOCS and Chamfer-L2 (conditioning-aware: the car clouds put
-        duplicate-padded neighbourhoods through GroupNorm, where ANY f32 implementation carries up to 1/sqrt(eps) = 316x its
-        rounding noise; the f32 oracle's own distance to f64 is printed next to the HIP path's);
+      * the FIRST and the LAST sequence of this rank's batch against the f64 evaluation of the reference graph (the oracle in
+        double precision): |hip - f64| <= 1e-5 flat -- north_star's tolerance as written -- on sampled xyz, T-NOCS and
+        Chamfer-L2.  The f32 oracle's own distance from f64 is printed next to it (on these sparse car clouds the reference's
+        f32 arithmetic is 6e-5 / 3e-4 away: duplicate-padded neighbourhoods amplify f32 rounding inside GroupNorm);
       * every sequence of the full batch: bitwise equal to reconstructing the second half of the batch on its own
         (sequences are independent, so the two oracle-checked sequences stand for all B);
       * a well-conditioned (dense) cloud of the same shape directly: |hip - oracle32| <= DENSE_TOL on xyz and T-NOCS."""
@@ -259,34 +307,31 @@ def cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, yb
     cpu_s = time.perf_counter() - t1
     gx, gt = out[2][pick].cpu(), out[3][pick].cpu()
     sd64 = {k: v.double() for k, v in sd.items()}
-    _, _, x64, t64 = O.reconstruct(sd64, xs[:1].double(), ys[:1].double(), timestamps=times_cpu.double(), cnf_steps=args.cnf_steps,
+    _, _, x64, t64 = O.reconstruct(sd64, xs.double(), ys.double(), timestamps=times_cpu.double(), cnf_steps=args.cnf_steps,
                                    latent_steps=args.latent_steps)
     checks = []
+    TOL = 1e-5            # north_star: "T-NOCS / CNF-sampled xyz within 1e-5 abs", asserted flat against the f64 evaluation
 
     def cond(name, g, w32, w64):
         e_gpu, e_ref = float((g.double() - w64).abs().max()), float((w32.double() - w64).abs().max())
-        ok = e_gpu <= 1e-5 + 5.0 * e_ref
+        ok = e_gpu <= TOL
         checks.append(ok)
-        return {"hip_vs_f64": e_gpu, "oracle32_vs_f64": e_ref, "hip_vs_oracle32": float((g - w32).abs().max()), "bound": 1e-5 + 5.0 * e_ref, "ok": ok}
+        return {"hip_vs_f64": e_gpu, "oracle32_vs_f64": e_ref, "hip_vs_oracle32": float((g - w32).abs().max()), "bound": TOL, "ok": ok}
 
-    parity = {"sequences_checked": pick, "x": cond("x", gx[:1], wx[:1], x64), "tnocs": cond("tnocs", gt[:1], wt[:1], t64),
+    parity = {"sequences_checked": pick, "x": cond("x", gx, wx, x64), "tnocs": cond("tnocs", gt, wt, t64),
               "x_max_abs_err_vs_oracle32": float((gx - wx).abs().max()), "tnocs_max_abs_err_vs_oracle32": float((gt - wt).abs().max())}
-    # loose direct bound for the sequence that has no f64 evaluation (the last one): within 10x the first one's oracle32-vs-f64 noise
-    last_ok = float((gx[-1] - wx[-1]).abs().max()) <= 1e-5 + 10.0 * parity["x"]["oracle32_vs_f64"] + 10.0 * parity["tnocs"]["oracle32_vs_f64"]
-    checks.append(last_ok)
-    parity["last_sequence_ok"] = last_ok
     if sp_all is not None:   # Chamfer-L2 against the ground-truth NOCS points (evaluations.py:40-43)
         n = len(pick)
         gt_pts = sp_all[pick][:, :, :, :3].reshape(n * T, N, 3).contiguous()
         cd32 = O.chamfer_l2(wx.reshape(n * T, N, 3), gt_pts)
-        cd64 = O.chamfer_l2(x64.reshape(T, N, 3).float(), gt_pts[:T])
+        cd64 = O.chamfer_l2(x64.reshape(n * T, N, 3).float(), gt_pts)
         d1, d2 = ops.chamfer_distance(out[2][pick].reshape(n * T, N, 3).contiguous(), gt_pts.to(dev))
         cd_gpu = (d1.mean(dim=1) + d2.mean(dim=1)).cpu()
-        e_gpu, e_ref = float((cd_gpu[:T] - cd64).abs().max()), float((cd32[:T] - cd64).abs().max())
-        ok = e_gpu <= 1e-5 + 5.0 * e_ref
+        e_gpu, e_ref = float((cd_gpu - cd64).abs().max()), float((cd32 - cd64).abs().max())
+        ok = e_gpu <= TOL
         checks.append(ok)
         parity["chamfer_l2"] = {"mean": float(cd_gpu.mean()), "hip_vs_f64": e_gpu, "oracle32_vs_f64": e_ref,
-                                "hip_vs_oracle32": float((cd_gpu - cd32).abs().max()), "bound": 1e-5 + 5.0 * e_ref, "ok": ok}
+                                "hip_vs_oracle32": float((cd_gpu - cd32).abs().max()), "bound": TOL, "ok": ok}
     # full batch: the second half on its own must reproduce its part of the full-batch outputs bit for bit
     if nb >= 2:
         h = nb // 2

@@ -18,7 +18,7 @@ from .. import ops
 from .tpointnet2 import TPointNet2
 from .latent_ode_model import LatentODE
 from .flow import get_point_cnf, count_nfe, PointCNFArgs
-from .utils import standard_normal_logprob, sample_gaussian, sphere_surface_points
+from .utils import standard_normal_logprob, sample_gaussian, sphere_surface_points, truncated_normal
 
 
 class CaSPR(nn.Module):
@@ -138,7 +138,28 @@ class CaSPR(nn.Module):
         """caspr.py:198-202."""
         return np.array([count_nfe(self.latent_ode), count_nfe(self.point_cnf)])
 
-    def _base_samples(self, B, T, num_points, constant_in_time, truncate_std, sample_contours, y, like):
+    def _draw_early(self, B, T, num_points, constant_in_time, device):
+        """The Gaussian base samples of decode, drawn as the reference draws them -- torch.randn on the CPU generator, then moved
+        (models/utils.py:25-26; caspr.py:252) -- but EARLY in reconstruct(): the encoder's kernels are already queued, so the
+        ~7 ms draw of a cfg-2 batch (983,040 values, serial MT19937) runs on the host while the GPU encodes; the copy goes from a
+        pinned buffer on a side stream.  Same values, same position in the CPU generator's stream (nothing else draws from it
+        in between).  -> (device tensor, event the consuming stream must wait for)."""
+        samp_batch = B if constant_in_time else B * T
+        size = (samp_batch, num_points, self.cnf_args.input_dim)
+        st = self.__dict__.setdefault("_early_draw_state", {})
+        ent = st.get(size)
+        if ent is None:
+            ent = st[size] = {"buf": torch.empty(size, dtype=torch.float32, pin_memory=True), "ev": None, "stream": torch.cuda.Stream(device=device)}
+        if ent["ev"] is not None:
+            ent["ev"].synchronize()          # the previous call's copy out of the pinned buffer (a whole step ago)
+        torch.randn(*size, out=ent["buf"])   # == torch.randn(*size): same generator, same stream position
+        with torch.cuda.stream(ent["stream"]):
+            yd = ent["buf"].to(device, non_blocking=True)
+            ent["ev"] = torch.cuda.Event()
+            ent["ev"].record(ent["stream"])
+        return yd, ent["ev"]
+
+    def _base_samples(self, B, T, num_points, constant_in_time, truncate_std, sample_contours, y, like, early=None):
         """The base-distribution draw of decode (caspr.py:228-256) -> (B*T, num_points, 3) on `like`'s device."""
         samp_batch = B if constant_in_time else B * T
         input_dim = self.cnf_args.input_dim
@@ -157,17 +178,23 @@ class CaSPR(nn.Module):
                 contours.append(pts)
                 nsamp_pts += num_points // len(radii)
             y = torch.from_numpy(np.concatenate(contours, axis=1)).to(like).view(samp_size)
+        elif early is not None:
+            y, ev = early
+            torch.cuda.current_stream().wait_event(ev)
+            y.record_stream(torch.cuda.current_stream())
+            if truncate_std is not None:
+                truncated_normal(y, mean=0, std=1, trunc_std=truncate_std)
         else:
             y = sample_gaussian(samp_size, truncate_std, device=like.device)
         if constant_in_time:
             y = y.view((B, 1, num_points, input_dim)).expand((B, T, num_points, input_dim)).reshape((B * T, num_points, input_dim))
         return y.contiguous()
 
-    def decode(self, z, num_points=1024, constant_in_time=False, truncate_std=None, sample_contours=None, y=None):
+    def decode(self, z, num_points=1024, constant_in_time=False, truncate_std=None, sample_contours=None, y=None, _early=None):
         """caspr.py:204-267.  `y` (B,T,num_points,3) optionally supplies the base samples."""
         B, T, H = z.size()
         input_dim = self.cnf_args.input_dim
-        y = self._base_samples(B, T, num_points, constant_in_time, truncate_std, sample_contours, y, z)
+        y = self._base_samples(B, T, num_points, constant_in_time, truncate_std, sample_contours, y, z, early=_early)
         logp_y = standard_normal_logprob(y).view(B * T, num_points, -1).sum(2)
         z = z.reshape((B * T, H))
         x = self.point_cnf(y, z, reverse=True)
@@ -186,12 +213,14 @@ class CaSPR(nn.Module):
             # latency-bound); joined before the flow starts
             defer = x.is_cuda and not self._differentiable(x)
             z0, tnocs_pred = self.encoder(x, defer_tnocs=True) if defer else self.encode(x)
+            # the encoder is queued: draw the base samples on the host now (as the reference does inside decode), under it
+            early = self._draw_early(B, T, num_points, constant_in_time, x.device) if (defer and y is None and sample_contours is None) else None
             with ops.timed("latent"):
                 z = self.aggregate_and_solve_latent(z0, all_times)
             if defer:
                 self.encoder.join()
             with ops.timed("decode"):
-                y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y)
+                y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y, _early=early)
             return y, logp_y, x, tnocs_pred
 
     def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16), num_points=512, timestamps=None, max_timestamp=5.0):

@@ -22,19 +22,23 @@ TIMERS = {}
 
 
 class timed:
-    """with ops.timed("name"): ...  -> appends a (start, end) event pair to TIMERS[name] when TIMING is on."""
+    """with ops.timed("name"): ...  -> appends a (start, end) event pair to TIMERS[name] when TIMING is on.
+    level 2 = per-kernel timers (one pair per launch, keyed by kernel and shape): recorded only when TIMING >= 2, i.e. in
+    bench.py's separate detail pass, never inside the timed region of the headline number."""
 
-    def __init__(self, name):
+    def __init__(self, name, level=1):
         self.name = name
+        self.level = level
 
     def __enter__(self):
-        if TIMING:
+        self.on = TIMING >= self.level
+        if self.on:
             self.t0 = torch.cuda.Event(enable_timing=True)
             self.t0.record(torch.cuda.current_stream())
         return self
 
     def __exit__(self, *exc):
-        if TIMING:
+        if self.on:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record(torch.cuda.current_stream())
             TIMERS.setdefault(self.name, []).append((self.t0, t1))
@@ -269,9 +273,10 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
         out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
     ldy = _chk_rows(out)
     if CONV_BF16X6 and pw.x6_ok and P % 128 == 0 and not row_invariant and in_relu_from % 8 == 0:
-        _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
-                                                        int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()),
-                   "caspr_conv1x1_bf16x6_f32")
+        with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, pw.cout, B * P), 2):
+            _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                                            int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()),
+                       "caspr_conv1x1_bf16x6_f32")
         return out
     _lib.check(_lib.load().caspr_conv1x1_f32(_p(pw.data), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
                                              int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()), "caspr_conv1x1_f32")
@@ -335,10 +340,11 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
     pmax = torch.empty(B, C, device=dev, dtype=torch.float32) if want_max else None
     L = _lib.load()
     ws = _workspace(L.caspr_conv_gn_ws_bytes(B, P, C), dev)
-    _lib.check(L.caspr_conv1x1_gn_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
-                                             int(in_relu_from), _p(y), ldy, B, P, pw.cin, C, groups, _p(gamma), _p(beta), float(eps),
-                                             _p(scale), _p(shift), _p(pmax), _p(mean), _p(rstd), _p(ws), ws.numel(), _stream()),
-               "caspr_conv1x1_gn_bf16x6_f32")
+    with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):     # conv + statistics epilogue + the finalize kernel
+        _lib.check(L.caspr_conv1x1_gn_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                                 int(in_relu_from), _p(y), ldy, B, P, pw.cin, C, groups, _p(gamma), _p(beta), float(eps),
+                                                 _p(scale), _p(shift), _p(pmax), _p(mean), _p(rstd), _p(ws), ws.numel(), _stream()),
+                   "caspr_conv1x1_gn_bf16x6_f32")
     res = (y, scale, shift)
     if want_moments:
         res += (mean, rstd)
@@ -363,8 +369,11 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0):
     for (pw, b, g, be) in layers:
         _chk_f32(b, g, be)
         args += [_p(pw.data), _p(b), _p(g), _p(be), pw.cout]
-    _lib.check(_lib.load().caspr_sa_mlp_max_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, int(feat_kind), *args,
-                                                _p(out), out.shape[2], out_off, _stream()), "caspr_sa_mlp_max_f32")
+    # 2 FLOP per multiply-add of the three layers over every gathered sample (C + 3 input channels: xyz first)
+    flop = 2.0 * B * M * ns * ((C + 3) * layers[0][0].cout + layers[0][0].cout * layers[1][0].cout + layers[1][0].cout * layers[2][0].cout)
+    with timed("k:sa_mlp_max:%d:%d:%d:%d" % (C + 3, layers[2][0].cout, B * M * ns, int(flop // 1000000)), 2):
+        _lib.check(_lib.load().caspr_sa_mlp_max_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, int(feat_kind), *args,
+                                                    _p(out), out.shape[2], out_off, _stream()), "caspr_sa_mlp_max_f32")
     return out
 
 

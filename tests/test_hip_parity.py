@@ -38,21 +38,27 @@ def record(name, got, want, tol):
     assert err <= tol, "%s: max abs err %.3e > %.1e (|ref|max %.3e)" % (name, err, tol, REPORT[name]["ref_absmax"])
 
 
-def record_cond(name, got, want32, want64, base_tol, factor=3.0):
-    """Conditioning-aware check for paths that contain GroupNorm over degenerate (duplicate-padded)
-    neighbourhoods, where f32 rounding is amplified by up to 1/sqrt(eps) in ANY implementation: the HIP
-    result must be as close to the f64 evaluation of the same graph as the f32 CPU oracle is
-    (err_gpu <= base_tol + factor * err_oracle32), instead of within base_tol of the f32 oracle."""
+def record_f64(name, got, want32, want64, tol=1e-5, slack_cap=None):
+    """The pipeline-level criterion: |hip - f64| <= tol, flat, against the f64 evaluation of the same graph (north_star: 1e-5 abs on
+    T-NOCS / sampled xyz; the f32 oracle's own distance from f64 is recorded next to it -- on sparse inputs the reference's f32
+    arithmetic itself is 4e-5 ... 1e-3 away, duplicate-padded neighbourhoods amplify f32 rounding inside GroupNorm by up to
+    1/sqrt(eps)).  slack_cap: ONLY for the named degenerate-input checks that do not reach 1e-5 -- the bound becomes
+    min(slack_cap, tol + |oracle32 - f64|): never looser than the f32 reference's own error (factor 1: HIP must be no worse
+    than the reference's arithmetic), capped within 10x of what the path measures; such checks are listed under
+    "_slack_checks" in gpurun_out/parity_report.json."""
     def a(t):
         return t.detach().cpu().double().numpy() if torch.is_tensor(t) else np.asarray(t, dtype=np.float64)
     got, want32, want64 = a(got), a(want32), a(want64)
     e_gpu, e_ref, e_direct = float(np.abs(got - want64).max()), float(np.abs(want32 - want64).max()), float(np.abs(got - want32).max())
-    REPORT[name] = {"max_abs_err_vs_f64": e_gpu, "oracle32_vs_f64": e_ref, "max_abs_err_vs_oracle32": e_direct, "base_tol": base_tol}
+    bound = tol if slack_cap is None else max(tol, min(slack_cap, tol + e_ref))
+    REPORT[name] = {"max_abs_err_vs_f64": e_gpu, "oracle32_vs_f64": e_ref, "max_abs_err_vs_oracle32": e_direct, "bound": bound}
+    if slack_cap is not None:
+        REPORT.setdefault("_slack_checks", {})[name] = {"bound": bound, "measured": e_gpu, "oracle32_vs_f64": e_ref, "cap": slack_cap}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     assert np.isfinite(got).all(), "%s: non-finite output" % name
-    assert e_gpu <= base_tol + factor * e_ref, "%s: |hip-f64| %.3e > %.1e + %g*|oracle32-f64| (%.3e)" % (name, e_gpu, base_tol, factor, e_ref)
+    assert e_gpu <= bound, "%s: |hip-f64| %.3e > %.2e (|oracle32-f64| %.3e)" % (name, e_gpu, bound, e_ref)
 
 
 def exact(name, got, want):
@@ -413,7 +419,10 @@ def test_sa_mlp_max(dev, seeded_sd, model, level, scale):
     fpad[:, :, :C] = feat
     out = torch.zeros(2, M, want.shape[2] + 8, device=dev)
     ops.sa_mlp_max(c.to(dev), ctr.to(dev), fpad.to(dev), bidx.to(dev), C, sa.pointnet_modules[scale].kernel_layers(), out, 8)
-    record_cond("sa_mlp_l%d_s%d" % (level, scale), out[:, :, 8:], want, want64, 1e-5)
+    # the two narrow scales whose duplicate-padded neighbourhoods put f32 rounding through 1/sqrt(eps) three times (the f32 oracle is
+    # 5e-4 / 6e-4 from f64 there) keep a capped slack; level 0 scale 1 measures 1.1e-5
+    cap = {(0, 0): 1e-3, (1, 0): 1.5e-3, (0, 1): 3e-5}.get((level, scale))
+    record_f64("sa_mlp_l%d_s%d" % (level, scale), out[:, :, 8:], want, want64, 1e-5, slack_cap=cap)
     assert float(out[:, :, :8].abs().max()) == 0.0
 
 
@@ -519,11 +528,11 @@ def test_encode_parity_dense(dev, seeded_sd, sd64, model):
     record("dense_tnocs_hip_vs_f64", gt, t64, 3e-6)
     record("dense_z0_hip_vs_f64", gz0, z64, 1e-5)
     record("dense_z0", gz0, z0, 1e-4)   # direct: the f32 oracle's own error on this 1600-wide max feature is 7.5e-5 (|z0| ~ 4)
-    record_cond("dense_z0_vs_f64", gz0, z0, z64, 1e-5, factor=1.0)
+    record_f64("dense_z0_vs_f64", gz0, z0, z64, 1e-5)
 
 
 def test_encode_parity_cars(dev, seeded_sd, sd64, model):
-    """Sparse car-like clouds: indices bit-exact; floats conditioning-aware (degenerate neighbourhoods)."""
+    """Sparse car-like clouds: indices bit-exact; floats within 1e-5 of the f64 evaluation (z0: capped slack, see record_f64)."""
     x, _ = car_sequences(2, 2, 1024, seed=1234)
     inter = []
     z0, tnocs = O.encode(seeded_sd, x, intermediates=inter)
@@ -535,8 +544,8 @@ def test_encode_parity_cars(dev, seeded_sd, sd64, model):
         exact("enc_fps_l%d" % l, rec[l]["fps_idx"], inter[l]["fps_idx"])
         for s in range(2):
             exact("enc_ball_l%d_s%d" % (l, s), rec[l]["ball_idx"][s], inter[l]["ball_idx"][s])
-    record_cond("enc_tnocs", gt, tnocs, t64, 1e-5, factor=5.0)
-    record_cond("enc_z0", gz0, z0, z64, 1e-5, factor=5.0)
+    record_f64("enc_tnocs", gt, tnocs, t64, 1e-5)
+    record_f64("enc_z0", gz0, z0, z64, 1e-5, slack_cap=1e-4)      # measured 2.1e-5 (f32 oracle 5.9e-4): the max over 20,480 pre-ReLU values
 
 
 @pytest.mark.parametrize("mode", ["bf16x6", "f32"])
@@ -583,8 +592,8 @@ def test_reconstruct_vs_reference_golden(dev, seeded_sd, sd64, model, golden):
     ybase = torch.from_numpy(golden["pipe_ybase"])
     _, _, x64, t64 = O.reconstruct(sd64, x.double(), ybase.double(), timestamps=sp[0, :, 0, 3].double())
     gy, glp, gx, gt = model.reconstruct(x.to(dev), num_points=256, timestamps=sp[0, :, 0, 3].to(dev), y=ybase.to(dev))
-    record_cond("recon_x_vs_reference_golden", gx, golden["pipe_recon_x"], x64, 1e-5, factor=5.0)
-    record_cond("recon_tnocs_vs_reference_golden", gt, golden["pipe_tnocs"], t64, 1e-5, factor=5.0)
+    record_f64("recon_x_vs_reference_golden", gx, golden["pipe_recon_x"], x64, 1e-5)
+    record_f64("recon_tnocs_vs_reference_golden", gt, golden["pipe_tnocs"], t64, 1e-5)
     record("recon_logp_y", glp, golden["pipe_logp_y"], 1e-5)
     assert [int(v) for v in model.get_nfe()] == [int(v) for v in golden["pipe_nfe"]]
 
@@ -603,7 +612,7 @@ def test_reconstruct_base_samples_from_cpu_generator(dev, model):
 
 
 def test_forward_nll(dev, seeded_sd, sd64, model, golden):
-    """CaSPR.forward loss values: dense input strict; the reference's golden (sparse cars) conditioning-aware."""
+    """CaSPR.forward loss values: dense input strict; the reference's golden (sparse cars) within 1e-5 (T-NOCS) / 2e-6 relative (NLL) of the f64 evaluation."""
     x, sp = dense_sequences(1, 2, 1024)
     e = rnd(23, 2, 1024, 3)
     wr, wt = O.forward_nll(seeded_sd, x, sp, e)
@@ -615,8 +624,8 @@ def test_forward_nll(dev, seeded_sd, sd64, model, golden):
     r64, t64 = O.forward_nll(sd64, x.double(), sp.double(), e.double())
     with torch.no_grad():
         recon, tl = model(x.to(dev), sp.to(dev), e=e.to(dev))
-    record_cond("fwd_tnocs_loss_vs_reference_golden", tl, golden["fwd_tnocs_loss"], t64, 1e-5, factor=5.0)
-    record_cond("fwd_recon_loss_vs_reference_golden", recon, golden["fwd_recon_loss"], r64, 2e-4, factor=5.0)
+    record_f64("fwd_tnocs_loss_vs_reference_golden", tl, golden["fwd_tnocs_loss"], t64, 1e-5)
+    record_f64("fwd_recon_loss_vs_reference_golden", recon, golden["fwd_recon_loss"], r64, 2e-5)      # NLL ~ 1e1: 2e-6 relative
 
 
 def test_demo_config_shape(dev, seeded_sd, sd64, model):
@@ -625,8 +634,8 @@ def test_demo_config_shape(dev, seeded_sd, sd64, model):
     z0, tnocs = O.encode(seeded_sd, x)
     z64, t64 = O.encode(sd64, x.double())
     gz0, gt = model.encode(x.to(dev))
-    record_cond("demo_tnocs", gt, tnocs, t64, 1e-5, factor=5.0)
-    record_cond("demo_z0", gz0, z0, z64, 1e-5, factor=5.0)
+    record_f64("demo_tnocs", gt, tnocs, t64, 1e-5, slack_cap=2e-4)    # N = 512 < 1024: FPS repeats indices, every level degenerate; measured 4.3e-5 (f32 oracle 4.7e-4)
+    record_f64("demo_z0", gz0, z0, z64, 1e-5, slack_cap=1e-4)          # measured 2.3e-5 (f32 oracle 2.4e-3)
 
 
 def test_real_demo_sequence_vs_reference_golden(dev, seeded_sd, sd64, model, golden):
@@ -637,8 +646,8 @@ def test_real_demo_sequence_vs_reference_golden(dev, seeded_sd, sd64, model, gol
     z64, t64 = O.encode(sd64, x.double())
     _, _, x64, _ = O.reconstruct(sd64, x.double(), yb.double(), timestamps=sp[0, :, 0, 3].double())
     _, _, gx, gt = model.reconstruct(x.to(dev), num_points=128, timestamps=sp[0, :, 0, 3].to(dev), y=yb.to(dev))
-    record_cond("realdemo_tnocs", gt, golden["demo_tnocs"], t64, 1e-5, factor=5.0)
-    record_cond("realdemo_recon_x", gx, golden["demo_recon_x"], x64, 1e-5, factor=5.0)
+    record_f64("realdemo_tnocs", gt, golden["demo_tnocs"], t64, 1e-5)
+    record_f64("realdemo_recon_x", gx, golden["demo_recon_x"], x64, 1e-5)
 
 
 def test_warping_config_no_tnocs(dev, seeded_sd):
@@ -668,9 +677,9 @@ def test_ragged_shapes(dev, seeded_sd, sd64, model, B, T, N, npts):
     _, _, x64, t64 = O.reconstruct(sd64, x.double(), yb.double(), timestamps=ts.double())
     _, glp, gx, gt = model.reconstruct(x.to(dev), num_points=npts, timestamps=ts.to(dev), y=yb.to(dev))
     assert gx.shape == (B, T, npts, 3) and gt.shape == (B, T, N, 4)
-    # N < 1024: FPS repeats indices, neighbourhoods degenerate -> conditioning-aware bound (see record_cond)
-    record_cond("ragged_%dx%dx%d_tnocs" % (B, T, N), gt, wt, t64, 1e-5, factor=5.0)
-    record_cond("ragged_%dx%dx%d_x" % (B, T, N), gx, wx, x64, 1e-5, factor=5.0)
+    # N < 1024: FPS repeats indices, neighbourhoods degenerate; still within the flat 1e-5 of the f64 evaluation
+    record_f64("ragged_%dx%dx%d_tnocs" % (B, T, N), gt, wt, t64, 1e-5)
+    record_f64("ragged_%dx%dx%d_x" % (B, T, N), gx, wx, x64, 1e-5)
     assert [int(v) for v in model.get_nfe()] == [4 * 4 * (T - 1), 32]
 
 
@@ -799,7 +808,7 @@ def test_cfg5_random_clouds(dev, seeded_sd, sd64, model):
     """BASELINE.json configs[4]: synthetic random clouds, T=20, N=4096 (64 sequences per GPU in the 8-GPU run).
     (a) oracle comparison on ONE sequence at the full (20, 4096) shape -- U(0,1)^3 clouds at this density make every
         r=0.02 ball a singleton padded with 15 / 31 copies of its centre, the worst case for GroupNorm conditioning, so the
-        conditioning-aware bound applies (record_cond) and the index tensors must still be bit-exact;
+        capped slack of record_f64 applies and the index tensors must still be bit-exact;
     (b) size-independent properties at (2, 20, 4096): FPS prefix property at n = 4096, finiteness / range, bitwise
         sharding invariance, NFE."""
     from caspr_amd import ops
@@ -821,8 +830,8 @@ def test_cfg5_random_clouds(dev, seeded_sd, sd64, model):
         exact("cfg5_fps_l%d" % l, rec[l]["fps_idx"], inter[l]["fps_idx"])
         for s_ in range(2):
             exact("cfg5_ball_l%d_s%d" % (l, s_), rec[l]["ball_idx"][s_], inter[l]["ball_idx"][s_])
-    record_cond("cfg5_tnocs", gt, wt, t64, 1e-5, factor=5.0)
-    record_cond("cfg5_recon_x", gx, wx, x64, 1e-5, factor=5.0)
+    record_f64("cfg5_tnocs", gt, wt, t64, 1e-5, slack_cap=6e-4)       # i.i.d. uniform clouds: most neighbourhoods hold one point; measured 1.5e-4 (f32 oracle 9.9e-4)
+    record_f64("cfg5_recon_x", gx, wx, x64, 1e-5, slack_cap=6e-5)     # measured 1.7e-5 (f32 oracle 1.1e-4)
     # (b)
     xd = x.to(dev)
     xyz = xd.view(2 * T, N, 4)[:, :, :3].contiguous()
@@ -842,7 +851,7 @@ def test_cfg5_random_clouds(dev, seeded_sd, sd64, model):
 def test_cfg4_warping_full_size(dev, seeded_sd, sd64):
     """BASELINE.json configs[3] (warping_cars.cfg): regress_tnocs=False, max_timestamp=1.0, input = the NOCS-space cloud
     itself (caspr_dataset.py:173-175), at the config's own T=10, N=2048.  Oracle comparison on one sequence (dense NOCS
-    cloud: strict bound; car-like NOCS cloud: conditioning-aware), properties + sharding invariance at B=2, and the RK4
+    cloud: strict bound; car-like NOCS cloud: 1e-5 against the f64 evaluation), properties + sharding invariance at B=2, and the RK4
     step count an adaptive solver would choose on these weights (calibrate_rk4_steps), recorded in the parity report."""
     from caspr_amd.models import CaSPR
     m = CaSPR(regress_tnocs=False, cnf_rk4_steps=8, latent_rk4_steps=4)
@@ -857,7 +866,7 @@ def test_cfg4_warping_full_size(dev, seeded_sd, sd64):
     _, _, x64, _ = O.reconstruct(sd64, x[:1].double(), yb[:1].double(), max_timestamp=1.0, regress_tnocs=False)
     _, _, gx, gt = m.reconstruct(x[:1].to(dev), num_points=256, max_timestamp=1.0, y=yb[:1].to(dev))
     assert gt is None and wt is None
-    record_cond("cfg4_recon_x", gx, wx, x64, 1e-5, factor=5.0)
+    record_f64("cfg4_recon_x", gx, wx, x64, 1e-5)
     xd, _ = dense_sequences(1, T, N, seed=78, max_timestamp=1.0)
     _, _, wxd, _ = O.reconstruct(seeded_sd, xd, yb[:1], max_timestamp=1.0, regress_tnocs=False)
     _, _, gxd, _ = m.reconstruct(xd.to(dev), num_points=256, max_timestamp=1.0, y=yb[:1].to(dev))

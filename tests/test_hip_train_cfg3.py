@@ -77,10 +77,18 @@ def test_cfg3_training_step_at_its_own_size(seeded_sd):
             a_ += g.double()
         if b == 0:
             l0, g0 = l_b, g_b
+    # A conv bias in front of a GroupNorm with ONE channel per group (the two 16-wide layers of the first set-abstraction scale:
+    # GroupNorm(16, 16), pointnet2.py:649-703) cannot change the output: its gradient is mathematically zero, and what any f32
+    # implementation returns for it -- the reference's autograd included -- is the rounding noise of a sum of 1.3 M terms of
+    # size 1/sigma.  Those two tensors are left out of the identity (their magnitude is recorded).
+    zero_grad = {"encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.%d.bias" % i for i in (0, 1)}
     num = den = 0.0
     worst = ("", 0.0)
     for n, ga, a_ in zip(names, g_all, acc):
         avg = a_ / B
+        if n in zero_grad:
+            rep["zero_gradient_noise_l2:" + n] = [float(ga.double().norm()), float(avg.norm())]
+            continue
         d, r = float((ga.double() - avg).norm()), float(avg.norm())
         num, den = num + d * d, den + r * r
         if d > worst[1]:

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""profiles/kernel_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh: HBM-side KB per launch of the
+kernels bench.py prices, keyed by kernel + workload shape (bench.py reads it: the counters cannot be read from inside the
+benchmark process).   usage: tools/make_traffic_table.py <traffic_pmc.txt> <BxTxN> <cnf_steps> <committed name of that file>"""
+import json, os, re, sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src, wl, steps, committed = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+rows = {}
+for ln in open(src):
+    m = re.match(r"^(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([0-9.e+]+)\s+([0-9.e+]+)\s+([0-9.e+]+)\s*$", ln.rstrip("\n"))
+    if m:
+        rows.setdefault(m.group(1).strip(), {})[m.group(2)] = {"n": int(m.group(3)), "avg": float(m.group(4)), "min": float(m.group(5)), "max": float(m.group(6))}
+path = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+tab = json.load(open(path)) if os.path.exists(path) else {}
+note = "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> x2; separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1` (tools/profile_round.sh)"
+B, T, N = (int(v) for v in wl.split("x"))
+for k, v in rows.items():
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        continue
+    if k.startswith("cnf_rk4_x6w_kernel") or k.startswith("void cnf_rk4_kernel<false>"):
+        name = "cnf_rk4_x6w_kernel" if "x6w" in k else "cnf_rk4_kernel"
+        tab["%s:%s:s%d" % (name, wl, steps)] = {"fetch_size_kb_per_launch": v["FETCH_SIZE"]["avg"], "write_size_kb_per_launch": v["WRITE_SIZE"]["avg"],
+                                                "fetch_correction": 2.0, "source": "profiles/%s" % committed, "note": note}
+big = [(v["FETCH_SIZE"]["max"], v["WRITE_SIZE"]["max"]) for k, v in rows.items() if "conv1x1_bf16x6_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+if big:
+    f, w = max(big)
+    tab["conv1x1_bf16x6_kernel:1600x1600:%s" % wl] = {"fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w, "fetch_correction": 2.0,
+                                                    "source": "profiles/%s" % committed,
+                                                    "note": note + "; the largest launch of the kernel = the 1600 -> 1600 head layer over %d rows (input %.2f GB + output %.2f GB algorithmic)"
+                                                            % (B * T * N, B * T * N * 1600 * 4 / 1e9, B * T * N * 1600 * 4 / 1e9)}
+json.dump(tab, open(path, "w"), indent=1, sort_keys=True)
+print("wrote %s: %s" % (path, sorted(tab)))
