@@ -92,7 +92,7 @@ def main():
     from caspr_amd import ops
     from caspr_amd.models import CaSPR
     from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences, random_clouds, dense_sequences
-    from caspr_amd.utils.sharding import max_over_ranks, shard_range
+    from caspr_amd.utils.sharding import max_over_ranks, shard_range, per_rank_values, collective_library
     from caspr_amd.utils.torch_utils import load_weights
 
     if args.matmul is not None:
@@ -132,6 +132,8 @@ def main():
         with torch.no_grad():
             return model.reconstruct(x, num_points=N, timestamps=ts)
 
+    rank_seconds = []
+
     def timed_steps(k):
         """k steps bracketed by barrier + synchronize on both sides; returns (seconds [max over ranks], last outputs)."""
         torch.cuda.synchronize()
@@ -150,11 +152,13 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         ops.TIMING = False
+        rank_seconds[:] = per_rank_values(el, dev)
         return max_over_ranks(el, dev), out_
 
     for _ in range(args.warmup):
         step()
     elapsed, out = timed_steps(args.steps)
+    per_rank_ms = [round(1e3 * s_ / args.steps, 3) for s_ in rank_seconds]
     timers = {k: list(v) for k, v in ops.TIMERS.items()}
     mode = ops.matmul_mode()
     # ---- detail pass (NOT part of the headline timing): one HIP-event pair per launch of the other matrix kernels, for the
@@ -233,6 +237,8 @@ def main():
                                    % (cfg_name, B, T, N, N, weights_desc),
                        "global_batch": world * B, "seq_len": T, "num_pts": N, "cnf_rk4_steps": args.cnf_steps,
                        "latent_rk4_steps": args.latent_steps, "cnf_divergence": "skipped (sampling)", "parallelism": "seq-shard x%d" % world,
+                       "ranks": {"ms_per_step": per_rank_ms, "collectives": "none in the data path; barrier + max-over-ranks timing only",
+                                 "library": collective_library() if world > 1 else None},
                        "base_samples": "drawn in-step (CPU generator, models/utils.py:25), pinned buffer + async copy under the encoder",
                        "matrix_products": mode, "calibration": calibration,
                        "nfe": [int(v) for v in model.get_nfe()]},

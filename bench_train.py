@@ -63,7 +63,7 @@ def main():
 
     from caspr_amd.models import CaSPR
     from caspr_amd.train.loop import GradBucket, train_step
-    from caspr_amd.utils.sharding import max_over_ranks
+    from caspr_amd.utils.sharding import max_over_ranks, per_rank_values, collective_library
     from caspr_amd.utils.synthetic import car_sequences, seeded_state_dict
 
     B, T, N = args.batch, args.seq_len, args.num_pts
@@ -72,6 +72,8 @@ def main():
     model = CaSPR(pretrain_tnocs=not full, cnf_rk4_steps=args.cnf_steps, latent_rk4_steps=args.latent_steps)
     model.load_state_dict(sd if full else {k: v for k, v in sd.items() if k.startswith("encoder.")})
     model = model.to(dev).train()
+    from caspr_amd.train.loop import broadcast_model
+    broadcast_model(model, 0)       # replicas start from rank 0's parameters and buffers (train.py:131-132 replicates module 0)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
     bucket = GradBucket(model.parameters()) if world > 1 else None
     x_all, sp_all = car_sequences(world * B, T, N, seed=1234)
@@ -90,7 +92,9 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    el_local = time.perf_counter() - t0
+    per_rank_ms = [round(1e3 * v / args.steps, 3) for v in per_rank_values(el_local, dev)]
+    elapsed = max_over_ranks(el_local, dev)
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -132,7 +136,9 @@ def main():
             "config": {"workload": "cfg-3 shard (BASELINE.json configs[2]): run_one_epoch body, B=%d sequences/GPU, T=%d, N=%d, %s; seeded "
                                    "random-init weights" % (B, T, N, "NLL (CNF with Hutchinson divergence) + T-NOCS L1" if full else "T-NOCS L1 only"),
                        "global_batch": world * B, "seq_len": T, "num_pts": N, "cnf_rk4_steps": args.cnf_steps,
-                       "latent_rk4_steps": args.latent_steps, "parallelism": "seq-shard x%d + 1 gradient all-reduce" % world},
+                       "latent_rk4_steps": args.latent_steps, "parallelism": "seq-shard x%d + 1 gradient all-reduce" % world,
+                       "ranks": {"ms_per_step": per_rank_ms, "collectives": "1 all-reduce of the flat gradient bucket per step (in place: .grad tensors are views of it)",
+                                 "library": collective_library() if world > 1 else None}},
             "roofline": roofline, "cpu_baseline": cpu, "loss_first": losses[0], "loss_last": losses[-1],
             "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         }))

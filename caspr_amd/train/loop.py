@@ -44,44 +44,49 @@ def training_loss(losses, cnf_loss_weight, tnocs_loss_weight):
 
 
 class GradBucket:
-    """All gradients of a model in one flat f32 buffer (16,262,189 elements = 65 MB for the full model):
-    a single all-reduce per step instead of one per tensor."""
+    """All gradients of a model in one flat f32 buffer (16,262,189 elements = 65 MB for the full model): a single all-reduce
+    per step instead of one per tensor -- and no copies around it: every parameter's `.grad` IS a view of the bucket
+    (autograd accumulates into an existing .grad in place), so the collective runs on the gradients where they are.
+    `zero()` replaces optimizer.zero_grad() (whose default, set_to_none, would detach the views; `attach()` re-creates any
+    view a caller has dropped that way)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
         self.flat = None
+        self.views = None
 
-    def pack(self):
+    def attach(self):
+        """(Re)bind every .grad to its slice of the flat buffer; gradient values already present are kept."""
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.zeros(sum(self.sizes) + 1, device=dev, dtype=torch.float32)   # last slot: this rank's weight
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+            self.views, off = [], 0
+            for p, n in zip(self.params, self.sizes):
+                self.views.append(self.flat[off:off + n].view_as(p))
+                off += n
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+                p.grad = v
+            elif g.data_ptr() != v.data_ptr() or g.device != v.device:
+                v.copy_(g)
+                p.grad = v
         return self.flat
 
-    def unpack(self):
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            g = self.flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
+    def zero(self):
+        self.attach()
+        self.flat.zero_()
 
     def all_reduce_mean(self, weight=1.0):
         """Weighted average of the gradients over the ranks: sum_r weight_r * grad_r / sum_r weight_r, with weight = the
         number of sequences behind this rank's (mean-reduced) loss; weight 0 = a rank without data (its gradients are
-        taken as zero whatever .grad holds).  ONE collective.  No-op without an initialised process group."""
+        taken as zero whatever .grad holds).  ONE collective, in place on the gradients.  No-op without an initialised
+        process group."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        flat = self.pack()
+        flat = self.attach()
         if weight == 0:
             flat.zero_()
         else:
@@ -89,14 +94,39 @@ class GradBucket:
             flat[-1] = float(weight)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat[:-1].div_(flat[-1].clamp_min(1e-30))
-        self.unpack()
+
+
+def broadcast_model(model, src=0):
+    """Every replica starts from rank `src`'s parameters AND buffers (MovingBatchNorm running statistics, step counters): the
+    reference's nn.DataParallel replicates module 0 on every forward (train.py:131-132); with one process per GPU the replicas
+    agree only if they start equal and apply the same averaged gradient -- whatever seed each rank initialised with.  One
+    flat broadcast per dtype.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+    seen, uniq = set(), []
+    for t in tensors:                      # latent_ode.solver.ode_func.* aliases latent_ode.ode_func.*
+        if t.data_ptr() not in seen and t.numel():
+            seen.add(t.data_ptr())
+            uniq.append(t)
+    for dt in sorted({t.dtype for t in uniq}, key=str):
+        group = [t for t in uniq if t.dtype == dt]
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in group:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
 
 def train_step(model, optimizer, pcl_in, nocs_out, cnf_loss_weight=0.01, tnocs_loss_weight=100.0, bucket=None, e=None):
     """One optimisation step on this rank's sequences (train_utils.py:120-176).  Returns the python floats
     (loss, cnf_loss, tnocs_loss) of the local shard."""
     model.train()
-    optimizer.zero_grad()
+    if bucket is not None:
+        bucket.zero()              # the gradients live in the bucket (views): zero them there, keep the views
+    else:
+        optimizer.zero_grad()
     n_local = int(pcl_in.shape[0])
     if n_local == 0:
         # no sequence of this batch landed on this rank: zero gradient, but the collective and the (identical) Adam step
@@ -154,13 +184,15 @@ def run_one_epoch(model, data_loader, device, optimizer, cnf_loss_weight, tnocs_
                 log('%s epoch %d batch %d/%d: loss %.6f (cnf %.6f, tnocs %.6f)' % (mode, epoch, i, len(data_loader), loss, cnf_l, tnocs_l))
     if mode == 'train':
         return out
+    # validation loss = mean over every SEQUENCE of every rank, for any world size: the BEST-checkpoint decision must not
+    # depend on the number of GPUs.  (The reference averages per-batch means, train_utils.py:226 -- the same number whenever
+    # every batch is full, which its DataLoader arranges for validation with the batch sizes of its configs; with a ragged
+    # last batch the sequence-weighted mean is the one that is invariant to how the batches were cut.)
     if distributed:
-        # validation loss = mean over every sequence of every rank (BEST-checkpoint decisions must agree across ranks)
         acc = torch.tensor([wsum, float(nsum)], dtype=torch.float64, device=device)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         wsum, nsum = float(acc[0]), int(acc[1])
-        return wsum / nsum if nsum else float('nan')
-    return float(np.mean(out)) if out else float('nan')
+    return wsum / nsum if nsum else float('nan')
 
 
 def train(model, train_loader, val_loader, device, out_dir, num_epochs, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
@@ -175,6 +207,7 @@ def train(model, train_loader, val_loader, device, out_dir, num_epochs, lr=1e-4,
         model.load_state_dict(ck["model"])
         optimizer.load_state_dict(ck["optimizer"])
         start, val_losses = ck["epoch"] + 1, ck.get("val_losses", [])
+    broadcast_model(model, 0)      # replicas start from rank 0's parameters and buffers, whatever each rank's seed was
     is_rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
     for epoch in range(start, num_epochs):
         run_one_epoch(model, train_loader, device, optimizer, cnf_loss_weight, tnocs_loss_weight, epoch, log, 'train', bucket=bucket)

@@ -38,3 +38,22 @@ def gather_sharded(local, total, rank, world):
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+
+
+def per_rank_values(value, device):
+    """Every rank's python float, in rank order (self-diagnosing multi-GPU bench lines: which rank was the slow one)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
+def collective_library():
+    """What torch.distributed's "nccl" backend is on this build: RCCL's version on ROCm."""
+    try:
+        v = torch.cuda.nccl.version()
+        return "RCCL %s (torch.distributed backend \"nccl\", HIP %s)" % (".".join(str(i) for i in v) if isinstance(v, tuple) else v, torch.version.hip)
+    except Exception as ex:      # pragma: no cover
+        return "unknown (%s)" % ex

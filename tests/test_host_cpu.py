@@ -192,6 +192,68 @@ def test_two_rank_gradient_bucket_gloo(tmp_path):
     assert out.returncode == 0 and "GRAD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+SEED_WORKER = r'''
+import os, sys, torch, torch.nn as nn, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from caspr_amd.train.loop import GradBucket, broadcast_model, shard_batch, train_step
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.b = nn.Linear(4, 4), nn.Linear(4, 1)
+        self.register_buffer("running_mean", torch.randn(3))       # stands for MovingBatchNorm's statistics
+        self.register_buffer("step", torch.zeros(1, dtype=torch.long) + torch.randint(0, 100, (1,)))
+    def forward(self, x, y):
+        return (self.b(torch.tanh(self.a(x))).squeeze(-1) ** 2, (torch.sigmoid(self.a(x)) - y).abs())
+
+torch.manual_seed(1000 + rank)          # every rank initialises DIFFERENTLY
+m = Tiny()
+before = [p.detach().clone() for p in m.parameters()]
+broadcast_model(m, 0)
+def same_everywhere(tensors, what):
+    for i, t in enumerate(tensors):
+        g = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(g, t.contiguous())
+        assert all(torch.equal(g[0], u) for u in g), "%s %d differs between the ranks" % (what, i)
+same_everywhere([p.data for p in m.parameters()], "parameter after the broadcast")
+same_everywhere([b.data for b in m.buffers()], "buffer after the broadcast")
+if rank != 0:
+    assert any(not torch.equal(a, p) for a, p in zip(before, m.parameters())), "the broadcast did not change rank %d" % rank
+torch.manual_seed(7)                    # the same global batch on every rank, sharded
+x, y = torch.randn(4, 3, 8, 4), torch.rand(4, 3, 8, 4)
+opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+bucket = GradBucket(m.parameters())
+for it in range(2):
+    xs, ys = shard_batch(x, y)
+    train_step(m, opt, xs, ys, 0.01, 100.0, bucket=bucket)
+    # the gradients ARE the bucket: views of one flat buffer, no pack / unpack copies
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + bucket.flat.numel() * 4
+    assert all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in m.parameters()), "a gradient left the bucket"
+same_everywhere([p.data for p in m.parameters()], "parameter after two steps")
+# a caller that drops the gradients (optimizer.zero_grad's default) gets the views back at the next step
+opt.zero_grad()
+assert all(p.grad is None for p in m.parameters())
+train_step(m, opt, *shard_batch(x, y), 0.01, 100.0, bucket=bucket)
+assert all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in m.parameters())
+same_everywhere([p.data for p in m.parameters()], "parameter after three steps")
+dist.barrier()
+if rank == 0:
+    print("SEED_OK")
+'''
+
+
+def test_two_ranks_with_different_seeds_train_identical_replicas_gloo(tmp_path):
+    """train() broadcasts rank 0's parameters and buffers first (SURVEY.md 2.3); the gradients are views of the flat bucket."""
+    script = tmp_path / "seed_worker.py"
+    script.write_text(SEED_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29536", str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "SEED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 LAUNCH_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
