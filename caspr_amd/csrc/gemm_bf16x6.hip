@@ -99,9 +99,10 @@ __global__ void pack_weight_bf16x3_kernel(const float *__restrict__ w, int ldw, 
 }
 
 // STATS: the GroupNorm that follows the conv (conv -> GroupNorm -> ReLU is the model's building block) gets its statistics
-// from the accumulators instead of a second pass over the output: every workgroup tile leaves, per output channel, the sum,
-// the sum of squares, the max and the min over its 128 points (f32; one float4 per (batch entry, point tile, channel) in
-// `part`), conv_gn_finalize_kernel folds them in f64 in a fixed order.  Y may then be NULL (only the statistics are wanted:
+// from the accumulators instead of a second pass over the output: every workgroup tile leaves, per output channel, the mean,
+// the sum of squared deviations from it (two passes over the accumulator registers), the max and the min over its 128 points
+// (f32; one float4 per (batch entry, point tile, channel) in `part`), conv_gn_finalize_kernel combines them pairwise in f64 in
+// a fixed order.  Y may then be NULL (only the statistics are wanted:
 // the global PointNet's last layer, whose output is max-pooled).
 template <bool FUSED, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned char *__restrict__ wpk, const float *__restrict__ bias,
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
 
     // epilogue: lane holds channels co + r (D row = 4g + r) of point p (column j); Cout % 4 == 0
     const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
-    f32x4 *sp = (f32x4 *)lds;   // STATS: [2 point halves][256 channels] {sum, sum of squares, max, min}; the K loop ends on a barrier
+    f32x4 *sp = (f32x4 *)lds;   // STATS: [2 point halves][256 channels] {mean, sum of squared deviations, max, min}; the K loop ends on a barrier
     if (STATS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of the loop's last (repeated) stage targets the same LDS
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
@@ -292,7 +293,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
             f32x4 v = acc[mi][ni] + add;
             if (STATS) {
                 s4 += v;
-                q4 += v * v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     mx[r] = fmaxf(mx[r], v[r]);
@@ -306,10 +306,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
             if (!STATS || Y) st4(Y + ((long)b * P + p) * ldy + co, v);
         }
         if (STATS) {
-            // over the tile's 16 columns: four DPP steps inside the 16-lane row
+            // Moments of the wave's 64 points per channel, TWO passes over the accumulators: the mean first (four DPP steps inside
+            // the 16-lane row), then the sum of squared deviations from it -- not sum / sum of squares, whose difference loses
+            // (mean / sigma)^2 x 2^-24 of the variance in f32 (a checkpoint with large per-group means; advisor finding, round 2).
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s4[r] = row_allreduce_add<16>(s4[r]) * (1.0f / 64.0f);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 d = acc[mi][ni] + add - s4;
+                q4 += d * d;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s4[r] = row_allreduce_add<16>(s4[r]);
                 q4[r] = row_allreduce_add<16>(q4[r]);
                 mx[r] = row_allreduce_max<16>(mx[r]);
                 mn[r] = -row_allreduce_max<16>(-mn[r]);
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
                 const float qq = j == 0 ? q4[0] : (j == 1 ? q4[1] : (j == 2 ? q4[2] : q4[3]));
                 const float m1 = j == 0 ? mx[0] : (j == 1 ? mx[1] : (j == 2 ? mx[2] : mx[3]));
                 const float m0 = j == 0 ? mn[0] : (j == 1 ? mn[1] : (j == 2 ? mn[2] : mn[3]));
-                sp[wn * X6_TM + wm * 128 + mi * 16 + 4 * g + j] = (f32x4){ss, qq, m1, m0};
+                sp[wn * X6_TM + wm * 128 + mi * 16 + 4 * g + j] = (f32x4){ss, qq, m1, m0};      // {mean, M2} of 64 points
             }
         }
     }
@@ -327,8 +335,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
         __syncthreads();
         const int co = mt * X6_TM + tid;
         if (co < Cout) {
+            // the tile's two 64-point halves (Chan et al.): mean = (m0 + m1) / 2, M2 = M2_0 + M2_1 + (m1 - m0)^2 * 64 * 64 / 128
             const f32x4 a0 = sp[tid], a1 = sp[X6_TM + tid];
-            part[((long)b * Pt + pt) * Cout + co] = (f32x4){a0[0] + a1[0], a0[1] + a1[1], fmaxf(a0[2], a1[2]), fminf(a0[3], a1[3])};
+            const float dm = a1[0] - a0[0];
+            part[((long)b * Pt + pt) * Cout + co] = (f32x4){0.5f * (a0[0] + a1[0]), a0[1] + a1[1] + dm * dm * 32.0f, fmaxf(a0[2], a1[2]), fminf(a0[3], a1[3])};
         }
     }
 }
@@ -345,27 +355,36 @@ __global__ __launch_bounds__(256) void conv_gn_finalize_kernel(const f32x4 *__re
     __shared__ double s_sum[256], s_sq[256];
     const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, tid = threadIdx.x;
     const f32x4 *base = part + (long)b * PT * C + g * cpg;
-    double sum = 0.0, sq = 0.0;
+    // every element of `part` = {mean, M2, max, min} of one channel over one 128-point tile; the group's moments by the pairwise
+    // update in f64: mean = average of the tile means, M2 = sum of the tiles' M2 + 128 * sum (tile mean - mean)^2
     const int total = PT * cpg;
+    double sum = 0.0;
+    for (int e = tid; e < total; e += 256) {
+        const int pt = e / cpg, cc = e - pt * cpg;
+        sum += (double)base[(long)pt * C + cc][0];
+    }
+    s_sum[tid] = sum;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) s_sum[tid] += s_sum[tid + off];
+        __syncthreads();
+    }
+    const double mean = s_sum[0] / (double)total;
+    double sq = 0.0;
     for (int e = tid; e < total; e += 256) {
         const int pt = e / cpg, cc = e - pt * cpg;
         const f32x4 v = base[(long)pt * C + cc];
-        sum += (double)v[0];
-        sq += (double)v[1];
+        const double d = (double)v[0] - mean;
+        sq += (double)v[1] + 128.0 * d * d;
     }
-    s_sum[tid] = sum;
     s_sq[tid] = sq;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) {
-            s_sum[tid] += s_sum[tid + off];
-            s_sq[tid] += s_sq[tid + off];
-        }
+        if (tid < off) s_sq[tid] += s_sq[tid + off];
         __syncthreads();
     }
     const double cnt = (double)P * cpg;
-    const double mean = s_sum[0] / cnt;
-    double var = s_sq[0] / cnt - mean * mean;
+    double var = s_sq[0] / cnt;
     var = var < 0.0 ? 0.0 : var;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     if (mean_out && tid == 0) {

@@ -161,6 +161,61 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
     }
 }
 
+// n > 4096 (no config of BASELINE.json; Kaolin's kernel takes any n): 1024 threads, the running minimum distance in LDS
+// (4 bytes per point: up to 36,864 points in 144 KB), the cloud re-read from global memory every round (L1 / L2 resident:
+// 12 n bytes), the same keys with the point index in 22 bits.  Same selections as fps_kernel, bit for bit.
+#define FPS_BIG_MAX_N 36864
+__global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int n, int M, int bs_bits, int guard,
+                                                       int32_t *__restrict__ idx, float *__restrict__ new_xyz)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tmp = smem;                                                                              // [n]
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(smem + ((n + 3) & ~3));       // [2][16]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *p = xyz + (long)b * n * 3;
+    for (int k = tid; k < n; k += 1024) tmp[k] = 1e10f;
+    int32_t *out = idx + (long)b * M;
+    float *oxyz = new_xyz ? new_xyz + (long)b * M * 3 : nullptr;
+    int old = 0;
+    if (tid == 0) {
+        out[0] = 0;
+        if (oxyz) { oxyz[0] = p[0]; oxyz[1] = p[1]; oxyz[2] = p[2]; }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    for (int j = 1; j < M; ++j) {
+        const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+        unsigned long long best = 0ull;
+        for (int k = tid; k < n; k += 1024) {
+            const float px = p[k * 3 + 0], py = p[k * 3 + 1], pz = p[k * 3 + 2];
+            if (guard && sqsum3(px, py, pz) <= 1e-3f) continue;
+            const float d = sqdist3(px, py, pz, x1, y1, z1);
+            const float t = tmp[k];
+            const float d2 = d < t ? d : t;
+            tmp[k] = d2;
+            const unsigned rev = bs_bits ? (__brev((unsigned)k) >> (32 - bs_bits)) : 0u;
+            const unsigned long long key = ((unsigned long long)(__float_as_uint(d2) + 1u) << 32) | (unsigned long long)(~((rev << 22) | (unsigned)k));
+            best = key > best ? key : best;
+        }
+        best = wave_max_u64(best);
+        unsigned long long *s = slot + (j & 1) * 16;
+        if (lane == 0) s[wave] = best;
+        __syncthreads();
+        unsigned long long m = s[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = s[w] > m ? s[w] : m;
+        old = (m == 0ull) ? 0 : (int)((~(unsigned)m) & 0x3fffffu);
+        if (tid == 0) {
+            out[j] = old;
+            if (oxyz) {
+                oxyz[j * 3 + 0] = p[old * 3 + 0];
+                oxyz[j * 3 + 1] = p[old * 3 + 1];
+                oxyz[j * 3 + 2] = p[old * 3 + 2];
+            }
+        }
+    }
+}
+
 static int fps_block_size(int n)
 {
     int bs = 1;
@@ -172,12 +227,23 @@ extern "C" int caspr_fps_f32(const float *xyz, int B, int n, int M, int guard, i
                              float *new_xyz, void *stream)
 {
     CASPR_REQUIRE(xyz && idx && B > 0 && n > 0 && M > 0, "fps: bad arguments");
-    CASPR_REQUIRE(n <= 4096, "fps: n=%d > 4096 unsupported", n);
+    CASPR_REQUIRE(n <= FPS_BIG_MAX_N, "fps: n=%d > %d unsupported (the running minimum of a cloud is kept in LDS)", n, FPS_BIG_MAX_N);
     const int bs = fps_block_size(n);
     int bs_bits = 0;
     while ((1 << bs_bits) < bs) ++bs_bits;
-    const size_t sh = (size_t)((n * 3 + 3) & ~3) * 4 + 64;
     hipStream_t st = (hipStream_t)stream;
+    if (n > 4096) {
+        const size_t shb = (size_t)((n + 3) & ~3) * 4 + 2 * 16 * 8;
+        static CasprLdsOptIn optin;
+        if (caspr_lds_opt_in(optin, (const void *)fps_big_kernel, FPS_BIG_MAX_N * 4 + 2 * 16 * 8) != hipSuccess) {
+            caspr_set_error("fps: hipFuncSetAttribute failed");
+            return CASPR_ELAUNCH;
+        }
+        fps_big_kernel<<<dim3(B), dim3(1024), shb, st>>>(xyz, n, M, bs_bits, guard, idx, new_xyz);
+        CASPR_CHECK_LAUNCH("fps");
+        return CASPR_OK;
+    }
+    const size_t sh = (size_t)((n * 3 + 3) & ~3) * 4 + 64;
     const int ppt = ceil_div(n, 256);
 #define FPS_LAUNCH(P) fps_kernel<P><<<dim3(B), dim3(256), sh, st>>>(xyz, n, M, bs_bits, guard, idx, new_xyz)
     if (ppt <= 1) FPS_LAUNCH(1);

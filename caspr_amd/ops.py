@@ -243,15 +243,21 @@ class PackedWeight:
         self.x6_ok = self.cin % 32 == 0 and self.cin >= _X6_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128
         self.x6_gn_ok = self.cin % 32 == 0 and self.cin >= _X6_GN_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128
         self._x3 = None
-        self._src = (w2d, ldw, col0) if self.x6_gn_ok else None     # kept for the lazy bf16x3 pack
+        # kept for the lazy bf16x3 pack only, with the version the f32 pack was taken at: w2d may be a VIEW of a parameter
+        # (detach()[:, :, 0]), and a pack made after an in-place update would silently disagree with self.data
+        self._src = (w2d, ldw, col0, w2d._version) if self.x6_gn_ok else None
 
     def x3(self):
         if self._x3 is None:
-            w2d, ldw, col0 = self._src
+            w2d, ldw, col0, version = self._src
+            if w2d._version != version:
+                raise RuntimeError("PackedWeight.x3(): the weight tensor was modified in place after this pack was built; re-create the "
+                                   "PackedWeight (WeightCache does: it is keyed by (data_ptr, _version))")
             nbytes = _lib.load().caspr_bf16x3_packed_bytes(self.cout, self.cin)
             self._x3 = torch.empty(nbytes, device=w2d.device, dtype=torch.uint8)
             _lib.check(_lib.load().caspr_pack_weight_bf16x3(_p(w2d), ldw, self.cout, col0, self.cin, _p(self._x3), _stream()),
                        "caspr_pack_weight_bf16x3")
+            self._src = None        # both packs exist: release the (possibly padded) copy of the weight
         return self._x3
 
 
@@ -400,15 +406,24 @@ _team_status = {}
 _LM_WS_STRIDE_WORDS = (256 + (2 * 128 * 16 * 4 + 32 * 4 * 256) * 4) // 4      # LM_WS_STRIDE of csrc/ode.hip, in 32-bit words
 
 
+_team_pool = []          # pinned status buffers that have been read and may be reused
+
+
 def _team_raise_if_failed(key, wait=False):
-    st = _team_status.get(key)
-    if st is None:
-        return
-    host, ev = st
-    if wait:
-        ev.synchronize()
-    if ev.query() and int(host.max()) != 0:
-        del _team_status[key]
+    """Drain every status record of this stream whose copy has completed (all of them with wait=True), oldest first; one record
+    per solve, never overwritten before it has been read: a failed solve followed by a successful one still raises."""
+    ring = _team_status.get(key)
+    failed = False
+    while ring:
+        host, ev = ring[0]
+        if wait:
+            ev.synchronize()
+        if not ev.query():
+            break
+        ring.pop(0)
+        failed = failed or int(host.max()) != 0
+        _team_pool.append(host)
+    if failed:
         raise _lib.CasprHipError("caspr_latent_rk4_team_f32: a team barrier gave up (the 32 x ceil(B/16) workgroups were not co-resident "
                                  "within the spin bound); the solve's output was poisoned with NaN.  Set CASPR_LATENT_TEAM=0 to use the "
                                  "single-workgroup kernel when other streams / processes saturate the GPU")
@@ -449,12 +464,19 @@ def latent_rk4(z0, times, steps, wts):
             return out
         groups = (B + 15) // 16
         words = ws[:groups * _LM_WS_STRIDE_WORDS * 4].view(torch.int32)[16::_LM_WS_STRIDE_WORDS]      # the error word of each group
-        st = _team_status.get(key)
-        if st is None or st[0].numel() != groups:
-            st = (torch.zeros(groups, dtype=torch.int32).pin_memory(), torch.cuda.Event())
-        st[0].copy_(words, non_blocking=True)
-        st[1].record(torch.cuda.current_stream())
-        _team_status[key] = st
+        ring = _team_status.setdefault(key, [])
+        if len(ring) >= 64:                              # nobody drained for 64 solves: bound the backlog (blocks on the oldest)
+            ring[0][1].synchronize()
+            _team_raise_if_failed(key)
+        host = next((h for h in _team_pool if h.numel() == groups), None)
+        if host is not None:
+            _team_pool.remove(host)
+        else:
+            host = torch.zeros(groups, dtype=torch.int32).pin_memory()
+        ev = torch.cuda.Event()
+        host.copy_(words, non_blocking=True)
+        ev.record(torch.cuda.current_stream())
+        ring.append((host, ev))
         return out
     with timed("latent_rk4"):
         _lib.check(L.caspr_latent_rk4_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *ptrs, _p(out), _stream()), "caspr_latent_rk4_f32")

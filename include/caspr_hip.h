@@ -45,7 +45,10 @@ int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int pairs, flo
 
 /* ---------------- Kaolin furthest_point_sampling + fps_gather_by_index: models/pointnet2.py:384-387
  * xyz (B,n,3) -> idx (B,M) int32 and (optionally, may be NULL) new_xyz (B,M,3) = xyz[idx].
- * Contract = oracle/point_ops.c:oracle_fps (start index 0, temp=1e10, padding guard, tie rule). */
+ * Contract = oracle/point_ops.c:oracle_fps (start index 0, temp=1e10, padding guard, tie rule).
+ * n <= 36,864 (Kaolin's kernel takes any n; every configuration of the reference has n <= 4096): clouds up to 4096 points
+ * stay in registers, larger ones keep their running minimum in LDS (one cloud per workgroup either way); the same
+ * selections bit for bit.  EINVAL above the limit.                                                   */
 int caspr_fps_f32(const float *xyz, int B, int n, int M, int guard, int32_t *idx, float *new_xyz,
                   void *stream);
 
@@ -106,9 +109,14 @@ int caspr_three_interp_f32(const float *feat, int ldf, const int32_t *idx, const
  *          row's data only -- not on P or on the row's position in the batch entry (same kernel, same K order for every
  *          row tile).  The hyper-network conv of the CNF runs over frames-as-rows with this flag so that a frame's gates do
  *          not change with the batch it is part of (sharding invariance).
- * Kernel choice inside (by shape only, never by B, so a batch entry's result does not depend on the batch around it): P <= 16
+ * Kernel choice inside (by shape only, never by B, so a batch ENTRY's result does not depend on the batch around it): P <= 16
  * rows per entry without a fused input transform -> one workgroup per (16 outputs, entry); Cout <= 16 -> streaming kernel with
- * one row tile per wave; P >= 128 and Cin >= 192 -> streaming kernel; otherwise the LDS-tiled kernel.
+ * one row tile per wave; P >= 128 and Cin >= 192 -> streaming kernel; otherwise the LDS-tiled kernel.  The guarantee is per
+ * batch entry, NOT per row: without CASPR_CONV_ROW_INVARIANT a row's bits may depend on P (which kernel) and on its position
+ * among the P rows (K order rotated by row tile).  Callers that put independent items along P and need them bitwise
+ * independent of their neighbours (the hyper conv) set the flag; the training path's row products (train/flow_grad.py: all
+ * frames or all points of the local shard as ONE entry) do not, so training gradients are shard-invariant to rounding
+ * (tests: 1e-5 of the gradient norm), not bitwise.
  * caspr_pack_weight_f32: W (Cout,Cin) row-major [+ column offset/count to pack a slice] -> packed
  * buffer of caspr_packed_size(Cout, ncols) floats.                                                 */
 long caspr_packed_size(int Cout, int Cin);

@@ -117,6 +117,18 @@ def test_fps_bit_exact(ops, dev, n, M, dup):
     exact("fps_newxyz_n%d_M%d" % (n, M), new_xyz, torch.gather(c, 1, want.long().unsqueeze(-1).expand(-1, -1, 3)))
 
 
+@pytest.mark.parametrize("n,M,dup", [(5000, 300, False), (8192, 512, True), (20000, 64, False), (36864, 16, False)])
+def test_fps_bit_exact_beyond_4096_points(ops, dev, n, M, dup):
+    """Clouds larger than any configuration of the reference (the running minimum moves from registers to LDS)."""
+    c = clouds(2, n, seed=n + M, dup=dup)
+    want = P.furthest_point_sampling(c, M)
+    got, new_xyz = ops.furthest_point_sampling(c.to(dev), M, return_xyz=True)
+    exact("fps_big_idx_n%d_M%d" % (n, M), got, want)
+    exact("fps_big_newxyz_n%d_M%d" % (n, M), new_xyz, torch.gather(c, 1, want.long().unsqueeze(-1).expand(-1, -1, 3)))
+    with pytest.raises(Exception):
+        ops.furthest_point_sampling(torch.zeros(1, 36865, 3, device=dev), 4)
+
+
 def test_fps_guard_and_origin(ops, dev):
     c = clouds(2, 256, seed=5)
     c[:, 10:40] = 0.0           # padded origin points are skipped by the guard
@@ -389,6 +401,108 @@ def test_conv1x1_gn_fused(ops, dev, B, P_, Cin, Cout):
         exact("conv_gn_batch_invariance_max", r1[3], pm[B - 1:])
     else:
         assert res[0] is not None       # unsupported row count: conv1x1 + gn_stats
+
+
+def test_conv1x1_gn_fused_large_mean(ops, dev):
+    """The fused statistics when a group's mean dwarfs its spread (|mean| / sigma ~ 1e3: a large bias in front of the GroupNorm,
+    what a trained checkpoint may hold): the epilogue takes per-tile mean and squared deviations in two passes over the
+    accumulators and the finalize kernel combines tiles pairwise in f64, so the variance keeps its digits (E[x^2] - mean^2 in f32
+    would lose (mean / sigma)^2 2^-24 = 6 % of it here)."""
+    B, P_, Cin, Cout = 2, 512, 512, 512
+    w = rnd(1, Cout, Cin, scale=0.02 / np.sqrt(Cin))
+    b = rnd(2, Cout, scale=0.01) + 20.0
+    x = rnd(3, B, P_, Cin)
+    gamma, beta = rnd(6, Cout) * 0.2 + 1.0, rnd(7, Cout) * 0.1
+    pw = ops.PackedWeight(w.to(dev))
+    y64 = x.double() @ w.double().t() + b.double()
+    want = F.group_norm(y64.transpose(1, 2), 16, gamma.double(), beta.double(), 1e-5).transpose(1, 2)
+    y, sc, sh = ops.conv1x1_gn(pw, b.to(dev), x.to(dev), gamma.to(dev), beta.to(dev))
+    got = y64.to(dev) * sc.double().unsqueeze(1) + sh.double().unsqueeze(1)        # the statistics alone, applied to the exact output
+    m64 = y64.view(B, P_, 16, Cout // 16).transpose(1, 2).reshape(B, 16, -1)
+    REPORT["conv_gn_large_mean_ratio"] = {"mean_over_sigma": float((m64.mean(dim=2).abs() / m64.std(dim=2)).max())}
+    assert REPORT["conv_gn_large_mean_ratio"]["mean_over_sigma"] > 500
+    # f32 scale / shift (shift ~ mean * rstd ~ 1e3, one rounding = 6e-5) bound what any f32 (scale, shift) pair can deliver; a
+    # variance off by 6 % would show as 3e-2 of the normalised output
+    record("conv_gn_apply_large_mean", got, want, 5e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# the Kaolin-named operator surface (INTEGRATION.md section 2)
+# ---------------------------------------------------------------------------------------------
+def test_kaolin_compat_forward(dev):
+    """caspr_amd.compat.kaolin_amd: the six symbols of pointnet2.py:7 at Kaolin's channels-first layouts against the oracle's
+    restatement of the same operators -- exactly the calls PointNet2SetAbstraction.forward / PointNet2FeaturePropagator.forward
+    make (pointnet2.py:384-398, 514-519)."""
+    from caspr_amd.compat import kaolin_amd as K
+    B, n, M, C, ns = 2, 512, 128, 7, 16                      # C not a multiple of 4: the row padding of the binding is exercised
+    pts = torch.cat([clouds(B, n, seed=3), rnd(5, B, n, C)], dim=2)
+    xyz, feat = K.separate_xyz_and_features(pts.to(dev))
+    wxyz, wfeat = P.separate_xyz_and_features(pts)
+    exact("kaolin_separate_xyz", xyz, wxyz)
+    exact("kaolin_separate_feat", feat, wfeat)
+    idx = K.furthest_point_sampling(xyz, M)
+    widx = P.furthest_point_sampling(wxyz, M)
+    exact("kaolin_fps", idx, widx)
+    new_xyz = K.fps_gather_by_index(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    wnew = P.fps_gather_by_index(wxyz.transpose(1, 2).contiguous(), widx).transpose(1, 2).contiguous()
+    exact("kaolin_fps_gather", new_xyz, wnew)
+    grouper = K.PointNet2GroupingLayer(0.1, ns, use_xyz_feature=True, use_random_ball_query=False)
+    g = grouper(xyz, new_xyz, feat)
+    wg = P.group(wxyz, wnew, wfeat, P.ball_query(0.1, ns, wxyz, wnew))
+    assert tuple(g.shape) == (B, M, 3 + C, ns)
+    exact("kaolin_grouping_layer", g, wg)
+    g0 = grouper(xyz, new_xyz, None)                          # xyz-only level (tpointnet2.py:79: PointNet++ sees xyz + 6 features, here none)
+    exact("kaolin_grouping_layer_xyz_only", g0, P.group(wxyz, wnew, None, P.ball_query(0.1, ns, wxyz, wnew)))
+    dist, i3 = K.three_nn(xyz, new_xyz)
+    wdist, wi3 = P.three_nn(wxyz, wnew)
+    exact("kaolin_three_nn_idx", i3, wi3)
+    exact("kaolin_three_nn_dist", dist, wdist)
+    inv = 1.0 / (dist + 1e-8)
+    w = inv / inv.sum(dim=2, keepdim=True)                    # pointnet2.py:516-518
+    fprev = rnd(6, B, C, M)
+    out = K.three_interpolate(fprev.to(dev), i3, w)
+    want = P.three_interpolate(fprev, wi3, w.cpu())
+    assert tuple(out.shape) == (B, C, n)
+    record("kaolin_three_interpolate", out, want, 1e-6)
+
+
+def test_kaolin_compat_gradients(dev):
+    """The three Kaolin operators that carry a gradient, against torch.autograd through the oracle's differentiable (plain
+    indexing) route in f64."""
+    from caspr_amd.compat import kaolin_amd as K
+    B, n, M, C, ns = 2, 256, 64, 6, 16
+    xyz = clouds(B, n, seed=4)
+    idx = P.furthest_point_sampling(xyz, M)
+    new_xyz = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    feat = rnd(8, B, C, n)
+    with torch.enable_grad():
+        # grouping layer
+        f = feat.clone().to(dev).requires_grad_(True)
+        R = rnd(9, B, M, 3 + C, ns)
+        (K.PointNet2GroupingLayer(0.15, ns)(xyz.to(dev), new_xyz.to(dev), f) * R.to(dev)).sum().backward()
+        f6 = feat.double().requires_grad_(True)
+        bidx = P.ball_query(0.15, ns, xyz, new_xyz)
+        (P.group(xyz.double(), new_xyz.double(), f6, bidx) * R.double()).sum().backward()
+        record("kaolin_grouping_grad", f.grad, f6.grad, 1e-5 * float(f6.grad.abs().max()))
+        # three_interpolate
+        dist, i3 = P.three_nn(xyz, new_xyz)
+        inv = 1.0 / (dist + 1e-8)
+        w = inv / inv.sum(dim=2, keepdim=True)
+        fp = rnd(10, B, C, M)
+        a = fp.clone().to(dev).requires_grad_(True)
+        R2 = rnd(11, B, C, n)
+        (K.three_interpolate(a, i3.to(dev), w.to(dev)) * R2.to(dev)).sum().backward()
+        a6 = fp.double().requires_grad_(True)
+        (P.three_interpolate(a6, i3, w.double()) * R2.double()).sum().backward()
+        record("kaolin_three_interpolate_grad", a.grad, a6.grad, 1e-5 * float(a6.grad.abs().max()))
+        # fps_gather_by_index (repeated indices accumulate)
+        gi = torch.cat([idx[:, :M - 4], idx[:, :4]], dim=1).contiguous()
+        b = feat.clone().to(dev).requires_grad_(True)
+        R3 = rnd(12, B, C, M)
+        (K.fps_gather_by_index(b, gi.to(dev)) * R3.to(dev)).sum().backward()
+        b6 = feat.double().requires_grad_(True)
+        (P.fps_gather_by_index(b6, gi) * R3.double()).sum().backward()
+        record("kaolin_gather_grad", b.grad, b6.grad, 1e-6 * float(b6.grad.abs().max()))
 
 
 # ---------------------------------------------------------------------------------------------
