@@ -118,14 +118,15 @@ class _ThreeInterpolate(torch.autograd.Function):
         C = features.shape[1]
         ctx.save_for_backward(idx, weight)
         ctx.m, ctx.C = features.shape[2], C
-        out = ops.three_interpolate(_rows(features), idx.contiguous(), weight.contiguous(), C=C)
+        rows = _rows(features)                               # the kernel interpolates whole float4 columns: the zero padding rides along
+        out = ops.three_interpolate(rows, idx.contiguous(), weight.contiguous(), C=rows.shape[2])
         return out[:, :, :C].transpose(1, 2).contiguous()
 
     @staticmethod
     def backward(ctx, g):            # (B,C,n) -> (B,C,m)
         idx, weight = ctx.saved_tensors
         d = torch.zeros(g.shape[0], ctx.m, (ctx.C + 3) // 4 * 4, device=g.device, dtype=torch.float32)
-        train_ops.three_interp_bwd(_rows(g), idx, weight.contiguous(), ctx.C, d)
+        train_ops.three_interp_bwd(_rows(g), idx, weight.contiguous(), d.shape[2], d)
         return d[:, :, :ctx.C].transpose(1, 2).contiguous(), None, None
 
 

@@ -468,11 +468,8 @@ def latent_rk4(z0, times, steps, wts):
         if len(ring) >= 64:                              # nobody drained for 64 solves: bound the backlog (blocks on the oldest)
             ring[0][1].synchronize()
             _team_raise_if_failed(key)
-        host = next((h for h in _team_pool if h.numel() == groups), None)
-        if host is not None:
-            _team_pool.remove(host)
-        else:
-            host = torch.zeros(groups, dtype=torch.int32).pin_memory()
+        slot = next((i for i, h in enumerate(_team_pool) if h.numel() == groups), None)
+        host = _team_pool.pop(slot) if slot is not None else torch.zeros(groups, dtype=torch.int32).pin_memory()
         ev = torch.cuda.Event()
         host.copy_(words, non_blocking=True)
         ev.record(torch.cuda.current_stream())

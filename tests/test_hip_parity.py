@@ -807,8 +807,8 @@ def test_bad_arguments_raise(dev, model):
                        torch.zeros(1, 2, 8, dtype=torch.int32, device=dev), 0,
                        model.encoder.local_extract.set_abstractions[0].pointnet_modules[0].kernel_layers(),
                        torch.zeros(1, 2, 32, device=dev), 0)
-    with pytest.raises(lib.CasprHipError, match="n=5000"):
-        ops.furthest_point_sampling(torch.zeros(1, 5000, 3, device=dev), 16)
+    with pytest.raises(lib.CasprHipError, match="n=40000"):
+        ops.furthest_point_sampling(torch.zeros(1, 40000, 3, device=dev), 16)
     with pytest.raises(ValueError):
         model.point_cnf(torch.zeros(2, 8, 3, device=dev), torch.zeros(2, 1600, device=dev), integration_times=torch.tensor([0.0, 1.0]))
 
