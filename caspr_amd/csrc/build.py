@@ -5,13 +5,14 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["point_ops.hip", "gemm.hip", "gemm_bf16x6.hip", "sa_mlp.hip", "ode.hip", "ode_bf16x6.hip", "ode_bf16x6w.hip", "backward.hip", "backward_points.hip", "backward_flow.hip", "emd.hip"]
+SOURCES = ["point_ops.hip", "gemm.hip", "gemm_bf16x6.hip", "gemm_bf16x6w.hip", "sa_mlp.hip", "ode.hip", "ode_bf16x6.hip", "ode_bf16x6w.hip", "backward.hip", "backward_points.hip", "backward_flow.hip", "emd.hip"]
 EXTRA = {"point_ops.hip": ["-ffp-contract=off"], "emd.hip": ["-ffp-contract=off"],
          # the 64-piece product loop of the bf16x6 CNF kernel must unroll completely (static register indices)
          "ode_bf16x6.hip": ["-mllvm", "-pragma-unroll-threshold=400000"],
          # the 128-point CNF kernel keeps its layer-1 accumulators in the accumulator file BY HAND (inline asm): hipcc's own MFMAs
          # must take the VGPR form there, or it would park them in AGPRs it believes free (see the kernel's header)
-         "ode_bf16x6w.hip": ["-mllvm", "-pragma-unroll-threshold=400000", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+         "ode_bf16x6w.hip": ["-mllvm", "-pragma-unroll-threshold=400000", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
+         "gemm_bf16x6w.hip": ["-mllvm", "-pragma-unroll-threshold=400000", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
 # CASPR_BUILD_DEBUG=1: the flavour with phase-trace hooks and experiment switches (-DCASPR_DEBUG_HOOKS, see common.h), built
 # next to the production library as libcaspr_hip_debug.so with its own objects; tools/*_phase_trace.py load it.
 DEBUG = os.environ.get("CASPR_BUILD_DEBUG", "0") not in ("0", "")
@@ -33,11 +34,11 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     inc = os.path.join(HERE, "..", "..", "include")
-    hdrs = [os.path.join(HERE, h) for h in ("common.h", "ode_x6.h", "ode_x6w_agprs.h")] + sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
+    hdrs = [os.path.join(HERE, h) for h in ("common.h", "ode_x6.h", "ode_x6w_agprs.h", "x6w_common.h")] + sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(HERE, s)
-        xw = XW_EXP if (XW_EXP and s == "ode_bf16x6w.hip") else ""
+        xw = XW_EXP if (XW_EXP and s in ("ode_bf16x6w.hip", "gemm_bf16x6w.hip")) else ""
         obj = os.path.join(HERE, s.replace(".hip", (".dbg_xw%s.o" % xw) if xw else (".dbg.o" if DEBUG else ".o")))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):

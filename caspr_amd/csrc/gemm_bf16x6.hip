@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
                                                                 int ldx, const float *__restrict__ in_scale,
                                                                 const float *__restrict__ in_shift, int in_relu, int relu_from,
                                                                 float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int act,
-                                                                int Mt, int Pt, f32x4 *__restrict__ part, unsigned long long *trace)
+                                                                int Mt, int Pt, f32x4 *__restrict__ part, int cstride, unsigned long long *trace)
 {
     // debug build (tools/conv_x6_trace.py): s_memtime stamps of workgroup 0, thread 0, five per K chunk
 #ifdef CASPR_DEBUG_HOOKS
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     else kloop(std::integral_constant<int, 8>());
 
     // epilogue: lane holds channels co + r (D row = 4g + r) of point p (column j); Cout % 4 == 0
-    const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
+    const float *bb = bbias ? bbias + (long)b * cstride : nullptr;     // cstride: channels of the whole layer (this launch may cover a slice)
     f32x4 *sp = (f32x4 *)lds;   // STATS: [2 point halves][256 channels] {mean, sum of squared deviations, max, min}; the K loop ends on a barrier
     if (STATS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of the loop's last (repeated) stage targets the same LDS
 #pragma unroll
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
             // the tile's two 64-point halves (Chan et al.): mean = (m0 + m1) / 2, M2 = M2_0 + M2_1 + (m1 - m0)^2 * 64 * 64 / 128
             const f32x4 a0 = sp[tid], a1 = sp[X6_TM + tid];
             const float dm = a1[0] - a0[0];
-            part[((long)b * Pt + pt) * Cout + co] = (f32x4){0.5f * (a0[0] + a1[0]), a0[1] + a1[1] + dm * dm * 32.0f, fmaxf(a0[2], a1[2]), fminf(a0[3], a1[3])};
+            part[((long)b * Pt + pt) * cstride + co] = (f32x4){0.5f * (a0[0] + a1[0]), a0[1] + a1[1] + dm * dm * 32.0f, fmaxf(a0[2], a1[2]), fminf(a0[3], a1[3])};
         }
     }
 }
@@ -433,8 +433,9 @@ extern "C" void caspr_debug_set_conv_x6_trace(unsigned long long *dev_buf) { g_c
 
 static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx, const float *in_scale,
                           const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout,
-                          int act, f32x4 *part, void *stream)
+                          int act, f32x4 *part, void *stream, int cstride = 0)
 {
+    if (cstride == 0) cstride = Cout;
     CASPR_REQUIRE(wpk && X && (Y || part) && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1_bf16x6: bad arguments");
     CASPR_REQUIRE(Cin % 32 == 0 && Cout % 4 == 0 && P % X6_TP == 0,
                   "conv1x1_bf16x6: needs Cin %% 32 == 0, Cout %% 4 == 0 and P %% 128 == 0 (Cin=%d Cout=%d P=%d); use caspr_conv1x1_f32", Cin, Cout, P);
@@ -461,7 +462,7 @@ static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias
     }
 #define X6_LAUNCH(F, S)                                                                                                          \
     conv1x1_bf16x6_kernel<F, S><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(                                \
-        (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt, part, trace)
+        (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt, part, cstride, trace)
     if (which == 0) X6_LAUNCH(false, false);
     else if (which == 1) X6_LAUNCH(true, false);
     else if (which == 2) X6_LAUNCH(false, true);
@@ -503,5 +504,54 @@ extern "C" int caspr_conv1x1_gn_bf16x6_f32(const void *wpk, const float *bias, c
     conv_gn_finalize_kernel<<<dim3(G, B), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, P / X6_TP, P, Cout, G, gamma, beta, eps,
                                                                                scale, shift, pmax, mean, rstd);
     CASPR_CHECK_LAUNCH("conv1x1_gn_bf16x6");
+    return CASPR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The large layers: gemm_bf16x6w.hip's 128-point x 512-channel kernel on the first Cout - Cout % 512 channels, the kernel above
+// on the remainder (1600 = 3 x 512 + 64), both writing into one output / one statistics array; G > 0 adds the GroupNorm
+// statistics of the output (as caspr_conv1x1_gn_bf16x6_f32).
+// ---------------------------------------------------------------------------------------------------------------------------
+int caspr_conv_x6w_launch(const void *wpk, const float *bias, const float *bbias, int bb_stride, const float *X, int ldx, const float *in_scale,
+                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout, void *part,
+                          int part_stride, hipStream_t stream) __attribute__((visibility("hidden")));
+
+extern "C" int caspr_conv1x1_x6w_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                                     const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                                     int P, int Cin, int Cout, int G, const float *gamma, const float *beta, float eps, float *scale,
+                                     float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream)
+{
+    const int Cmain = Cout - Cout % 512, Ctail = Cout - Cmain;
+    CASPR_REQUIRE(wpk_main && X && B > 0 && P > 0 && Cmain >= 512 && (Ctail == 0 || wpk_tail), "conv1x1_x6w: bad arguments (Cout=%d needs >= 512 channels%s)", Cout,
+                  Ctail ? " and the bf16x3 pack of the remainder" : "");
+    CASPR_REQUIRE(Cin % 32 == 0 && Cin >= 64 && Cout % 4 == 0 && P % 128 == 0, "conv1x1_x6w: needs Cin %% 32 == 0, Cout %% 4 == 0 and P %% 128 == 0 (Cin=%d Cout=%d P=%d)", Cin, Cout, P);
+    CASPR_REQUIRE(ldx % 4 == 0 && ldx >= Cin && (!Y || (ldy % 4 == 0 && ldy >= Cout)), "conv1x1_x6w: row strides must be multiples of 4 and cover the channels");
+    CASPR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_x6w: in_scale/in_shift must be given together");
+    CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wpk_main % 16) == 0 && ((uintptr_t)wpk_tail % 16) == 0 &&
+                  ((uintptr_t)bias % 16) == 0 && ((uintptr_t)bbias % 16) == 0, "conv1x1_x6w: pointers must be 16-byte aligned");
+    CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 8 == 0, "conv1x1_x6w: in_relu_from=%d must be a non-negative multiple of 8", in_relu_from);
+    CASPR_REQUIRE((long)B * (P / 128) * (Cmain / 512) < (1L << 31) && B <= 65535, "conv1x1_x6w: too many tiles");
+    f32x4 *part = nullptr;
+    if (G > 0) {
+        CASPR_REQUIRE(gamma && beta && scale && shift && ws && Cout % G == 0 && (mean == nullptr) == (rstd == nullptr), "conv1x1_x6w: bad GroupNorm arguments");
+        CASPR_REQUIRE(ws_bytes >= caspr_conv_gn_ws_bytes(B, P, Cout) && ((uintptr_t)ws % 16) == 0, "conv1x1_x6w: workspace too small or misaligned");
+        part = (f32x4 *)ws;
+    } else {
+        CASPR_REQUIRE(Y, "conv1x1_x6w: Y is NULL");
+    }
+    int rc = caspr_conv_x6w_launch(wpk_main, bias, bbias, Cout, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cmain, part, Cout,
+                                   (hipStream_t)stream);
+    if (rc != CASPR_OK) return rc;
+    CASPR_CHECK_LAUNCH("conv1x1_x6w");
+    if (Ctail) {
+        rc = conv_x6_launch(wpk_tail, bias ? bias + Cmain : nullptr, bbias ? bbias + Cmain : nullptr, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
+                            Y ? Y + Cmain : nullptr, ldy, B, P, Cin, Ctail, 0, part ? part + Cmain : nullptr, stream, Cout);
+        if (rc != CASPR_OK) return rc;
+    }
+    if (G > 0) {
+        conv_gn_finalize_kernel<<<dim3(G, B), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, P / X6_TP, P, Cout, G, gamma, beta, eps, scale, shift,
+                                                                                   pmax, mean, rstd);
+        CASPR_CHECK_LAUNCH("conv1x1_x6w (GroupNorm statistics)");
+    }
     return CASPR_OK;
 }

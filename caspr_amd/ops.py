@@ -203,8 +203,11 @@ _mode = os.environ.get("CASPR_MATMUL", "bf16x6").strip().lower()
 if _mode not in ("bf16x6", "f32"):
     raise ValueError("CASPR_MATMUL must be 'bf16x6' or 'f32', got %r" % _mode)
 CONV_BF16X6 = _mode == "bf16x6"      # pointwise convs (conv1x1) on the bf16x6 kernel where the shape allows
+CONV_X6W = os.environ.get("CASPR_CONV_X6W", "1") != "0"     # ... and the layers with >= 512 output channels on the 512-channel kernel
 CNF_BF16X6 = _mode == "bf16x6"       # point-CNF solves on the bf16x6 kernel
 _X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstraction / input layers)
+_X6W_MIN_CIN = 1024   # the 512-channel kernel (gemm_bf16x6w.hip) runs one workgroup per CU: its prologue / epilogue are exposed, and only the
+                      # 1600-wide head layer's K loop (50 chunks) amortises them -- measured: 8.03 vs 8.50 ms there, 0.95 vs 0.91 ms at 512 -> 512
 _X6_GN_MIN_CIN = 128  # conv + GroupNorm statistics in one pass (conv1x1_gn): pays from a smaller width (no second pass over the output)
 
 
@@ -243,9 +246,12 @@ class PackedWeight:
         self.x6_ok = self.cin % 32 == 0 and self.cin >= _X6_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128
         self.x6_gn_ok = self.cin % 32 == 0 and self.cin >= _X6_GN_MIN_CIN and self.cout % 4 == 0 and self.cout >= 128
         self._x3 = None
+        self._xw = None
+        # the 128-point x 512-channel kernel (csrc/gemm_bf16x6w.hip) takes the layers with >= 512 output channels and >= 8 k chunks
+        self.x6w_ok = self.cin % 32 == 0 and self.cin >= _X6W_MIN_CIN and self.cout % 4 == 0 and self.cout >= 512
         # kept for the lazy bf16x3 pack only, with the version the f32 pack was taken at: w2d may be a VIEW of a parameter
         # (detach()[:, :, 0]), and a pack made after an in-place update would silently disagree with self.data
-        self._src = (w2d, ldw, col0, w2d._version) if self.x6_gn_ok else None
+        self._src = (w2d, ldw, col0, w2d._version) if (self.x6_gn_ok or self.x6w_ok) else None
 
     def x3(self):
         if self._x3 is None:
@@ -257,8 +263,30 @@ class PackedWeight:
             self._x3 = torch.empty(nbytes, device=w2d.device, dtype=torch.uint8)
             _lib.check(_lib.load().caspr_pack_weight_bf16x3(_p(w2d), ldw, self.cout, col0, self.cin, _p(self._x3), _stream()),
                        "caspr_pack_weight_bf16x3")
-            self._src = None        # both packs exist: release the (possibly padded) copy of the weight
+            if not self.x6w_ok or self._xw is not None:
+                self._src = None        # every pack exists: release the (possibly padded) copy of the weight
         return self._x3
+
+    def xw(self):
+        """(main, tail) packs of caspr_conv1x1_x6w_f32: the first cout - cout % 512 rows for the 512-channel kernel, the rest (or
+        None) as a bf16x3 pack for the 256-channel kernel."""
+        if self._xw is None:
+            w2d, ldw, col0, version = self._src
+            if w2d._version != version:
+                raise RuntimeError("PackedWeight.xw(): the weight tensor was modified in place after this pack was built")
+            L = _lib.load()
+            cmain = self.cout - self.cout % 512
+            main = torch.empty(L.caspr_x6w_packed_bytes(cmain, self.cin), device=w2d.device, dtype=torch.uint8)
+            _lib.check(L.caspr_pack_weight_x6w(_p(w2d), ldw, cmain, col0, self.cin, _p(main), _stream()), "caspr_pack_weight_x6w")
+            tail = None
+            if cmain != self.cout:
+                wt = w2d[cmain:]
+                tail = torch.empty(L.caspr_bf16x3_packed_bytes(self.cout - cmain, self.cin), device=w2d.device, dtype=torch.uint8)
+                _lib.check(L.caspr_pack_weight_bf16x3(_p(wt), ldw, self.cout - cmain, col0, self.cin, _p(tail), _stream()), "caspr_pack_weight_bf16x3")
+            self._xw = (main, tail)
+            if self._x3 is not None:
+                self._src = None
+        return self._xw
 
 
 CONV_ROW_INVARIANT = 0x100     # include/caspr_hip.h: act flag
@@ -278,6 +306,13 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
     if out is None:
         out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
     ldy = _chk_rows(out)
+    if CONV_BF16X6 and CONV_X6W and pw.x6w_ok and P % 128 == 0 and not row_invariant and in_relu_from % 8 == 0 and act == 0:
+        main, tail = pw.xw()
+        with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, pw.cout, B * P), 2):
+            _lib.check(_lib.load().caspr_conv1x1_x6w_f32(_p(main), _p(tail), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                                         int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, 0, None, None, 0.0, None, None, None,
+                                                         None, None, None, 0, _stream()), "caspr_conv1x1_x6w_f32")
+        return out
     if CONV_BF16X6 and pw.x6_ok and P % 128 == 0 and not row_invariant and in_relu_from % 8 == 0:
         with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, pw.cout, B * P), 2):
             _lib.check(_lib.load().caspr_conv1x1_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
@@ -346,6 +381,19 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
     pmax = torch.empty(B, C, device=dev, dtype=torch.float32) if want_max else None
     L = _lib.load()
     ws = _workspace(L.caspr_conv_gn_ws_bytes(B, P, C), dev)
+    if CONV_X6W and pw.x6w_ok:
+        main, tail = pw.xw()
+        with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):
+            _lib.check(L.caspr_conv1x1_x6w_f32(_p(main), _p(tail), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                               int(in_relu_from), _p(y), ldy, B, P, pw.cin, C, groups, _p(gamma), _p(beta), float(eps),
+                                               _p(scale), _p(shift), _p(pmax), _p(mean), _p(rstd), _p(ws), ws.numel(), _stream()),
+                       "caspr_conv1x1_x6w_f32")
+        res = (y, scale, shift)
+        if want_moments:
+            res += (mean, rstd)
+        if want_max:
+            res += (pmax,)
+        return res
     with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):     # conv + statistics epilogue + the finalize kernel
         _lib.check(L.caspr_conv1x1_gn_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
                                                  int(in_relu_from), _p(y), ldy, B, P, pw.cin, C, groups, _p(gamma), _p(beta), float(eps),

@@ -142,8 +142,8 @@ int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bb
 
 /* conv -> GroupNorm statistics in one pass (the model's conv -> GroupNorm -> ReLU blocks: pointnet.py:37-42,
  * pointnet2.py:575-590 / 247, tpointnet2.py:96-111): caspr_conv1x1_bf16x6_f32 (act = 0) whose epilogue also leaves, per
- * (batch entry, 128-point tile, output channel), the f32 sum / sum of squares / max / min of the tile's outputs in ws; a
- * second small kernel folds them in f64 in a fixed order into what caspr_gn_stats_f32 returns for Y: scale, shift (B,Cout),
+ * (batch entry, 128-point tile, output channel), the f32 mean / sum of squared deviations / max / min of the tile's outputs in
+ * ws; a second small kernel combines them pairwise in f64 in a fixed order into what caspr_gn_stats_f32 returns for Y: scale, shift (B,Cout),
  * optionally pmax (B,Cout) and the moments mean / rstd (B,G) (NULL: not wanted).  The 2 x |Y| read pass of caspr_gn_stats_f32
  * disappears; Y itself may be NULL when only the statistics are needed (pointnet.py:41-42: the output is max-pooled).
  * ws: caspr_conv_gn_ws_bytes(B, P, Cout) bytes, 16-byte aligned.  Same shape restrictions as caspr_conv1x1_bf16x6_f32.  */
@@ -153,6 +153,22 @@ int caspr_conv1x1_gn_bf16x6_f32(const void *wpk, const float *bias, const float 
                                 float *Y, int ldy, int B, int P, int Cin, int Cout, int G, const float *gamma,
                                 const float *beta, float eps, float *scale, float *shift, float *pmax, float *mean,
                                 float *rstd, void *ws, long ws_bytes, void *stream);
+
+/* The same two contracts for the LARGE layers (>= 512 output channels: the 1600-wide head convs of tpointnet2.py:96-105, the
+ * 512-wide feature-propagation / final layers of pointnet2.py:525,247), csrc/gemm_bf16x6w.hip: workgroup tile 128 points x
+ * 512 channels on v_mfma_f32_32x32x16_bf16, 256 accumulators per lane in the accumulator file, weight fragments straight from
+ * global memory (no LDS for that operand), the activation read and split once per 512 channels.  The first Cout - Cout % 512
+ * channels run there (wpk_main: caspr_pack_weight_x6w over those rows), a remainder (1600 = 3 x 512 + 64) on
+ * conv1x1_bf16x6_kernel (wpk_tail: caspr_pack_weight_bf16x3 over the remaining rows; NULL when Cout % 512 == 0); both write one
+ * output and one statistics array.  G > 0: also the GroupNorm statistics of the output, arguments as
+ * caspr_conv1x1_gn_bf16x6_f32 (Y may then be NULL); G == 0: plain conv (gamma ... ws ignored).  act is always the identity.
+ * Needs Cin % 32 == 0, Cin >= 64, P % 128 == 0, Cout >= 512, Cout % 4 == 0.                                             */
+long caspr_x6w_packed_bytes(int Cout, int Cin);
+int caspr_pack_weight_x6w(const float *w, int ldw, int Cout, int col0, int ncols, void *packed, void *stream);
+int caspr_conv1x1_x6w_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                          const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                          int P, int Cin, int Cout, int G, const float *gamma, const float *beta, float eps, float *scale,
+                          float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream);
 
 /* GroupNorm statistics of Y (B,P,C) (nn.GroupNorm(G,C), biased variance, eps):
  *   scale[b,c] = gamma[c]*rstd[b,g(c)] ; shift[b,c] = beta[c] - mean[b,g(c)]*scale[b,c]

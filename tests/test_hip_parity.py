@@ -403,6 +403,51 @@ def test_conv1x1_gn_fused(ops, dev, B, P_, Cin, Cout):
         assert res[0] is not None       # unsupported row count: conv1x1 + gn_stats
 
 
+@pytest.mark.parametrize("B,P_,Cin,Cout", [(1, 1280, 1600, 1600), (2, 256, 512, 512), (1, 384, 1536, 512), (1, 128, 256, 1088)])
+def test_conv1x1_x6w_kernel(ops, dev, B, P_, Cin, Cout):
+    """The 128-point x 512-channel conv (csrc/gemm_bf16x6w.hip; a remainder of the channels on the 256-channel kernel): plain and
+    with the producer's GroupNorm + ReLU fused, bias + per-batch bias, against the f64 contraction at the conv kernels' common
+    tolerance; the GroupNorm statistics of its epilogue against the other kernel's; and it IS the kernel that ran."""
+    w = rnd(1, Cout, Cin, scale=1.0 / np.sqrt(Cin))
+    b, bb = rnd(2, Cout, scale=0.3), rnd(3, B, Cout, scale=0.1)
+    x = rnd(Cin + Cout, B, P_, Cin)
+    sc_in, sh_in = rnd(4, B, Cin).abs() + 0.5, rnd(5, B, Cin)
+    gamma, beta = rnd(6, Cout) * 0.2 + 1.0, rnd(7, Cout) * 0.1
+    min_cin, ops._X6W_MIN_CIN = ops._X6W_MIN_CIN, 256       # the host sends only the 1600-wide head layer there by default
+    try:
+        pw = ops.PackedWeight(w.to(dev))
+    finally:
+        ops._X6W_MIN_CIN = min_cin
+    assert pw.x6w_ok
+    kw = dict(bbias=bb.to(dev), in_scale=sc_in.to(dev), in_shift=sh_in.to(dev), in_relu=True, in_relu_from=8)
+    xin = x * sc_in.unsqueeze(1) + sh_in.unsqueeze(1)
+    xin[:, :, 8:] = torch.relu(xin[:, :, 8:])
+    y64 = xin.double() @ w.double().t() + b.double() + bb.double().unsqueeze(1)
+    prev = ops.CONV_X6W
+    try:
+        ops.CONV_X6W = True
+        y = ops.conv1x1(pw, b.to(dev), x.to(dev), **kw)
+        yp = ops.conv1x1(pw, b.to(dev), x.to(dev))
+        res = ops.conv1x1_gn(pw, b.to(dev), x.to(dev), gamma.to(dev), beta.to(dev), want_max=True, want_moments=True, **kw)
+        ops.CONV_X6W = False
+        y_old = ops.conv1x1(pw, b.to(dev), x.to(dev), **kw)
+        res_old = ops.conv1x1_gn(pw, b.to(dev), x.to(dev), gamma.to(dev), beta.to(dev), want_max=True, want_moments=True, **kw)
+    finally:
+        ops.CONV_X6W = prev
+    tol = 2e-6 * max(1.0, float(y64.abs().max()))
+    record("conv_x6w_fused_%dx%d" % (Cin, Cout), y[:, :, :Cout], y64, tol)
+    record("conv_x6w_plain_%dx%d" % (Cin, Cout), yp[:, :, :Cout], x.double() @ w.double().t() + b.double(), tol)
+    assert not torch.equal(y, y_old), "both settings ran the same kernel"
+    exact("conv_x6w_gn_output", res[0], y)
+    for i, nm in ((1, "scale"), (2, "shift"), (3, "mean"), (4, "rstd"), (5, "max")):
+        record("conv_x6w_gn_%s_%dx%d" % (nm, Cin, Cout), res[i], res_old[i], 3e-6 * max(1.0, float(res_old[i].abs().max())))
+    # a batch entry does not depend on the batch around it
+    if B > 1:
+        y1 = ops.conv1x1(pw, b.to(dev), x[B - 1:].to(dev).contiguous(), bbias=bb[B - 1:].to(dev).contiguous(), in_scale=sc_in[B - 1:].to(dev).contiguous(),
+                         in_shift=sh_in[B - 1:].to(dev).contiguous(), in_relu=True, in_relu_from=8)
+        exact("conv_x6w_batch_invariance", y1, y[B - 1:])
+
+
 def test_conv1x1_gn_fused_large_mean(ops, dev):
     """The fused statistics when a group's mean dwarfs its spread (|mean| / sigma ~ 1e3: a large bias in front of the GroupNorm,
     what a trained checkpoint may hold): the epilogue takes per-tile mean and squared deviations in two passes over the
