@@ -98,6 +98,23 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
         y[d] = v;
     }
 
+    // per-thread constants of the stage tables: units tid and tid + 256 of the three gated layers (context part of the hyper
+    // networks' gate / bias, their time columns, the layer biases), and -- threads 0..2 -- the output layer's
+    float kc_g[2][3], kc_hb[2][3], kc_tg[2][3], kc_tb[2][3], kc_b[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int i = l * XC_H + tid + 256 * u;
+            kc_g[u][l] = hy[i];
+            kc_hb[u][l] = hy[BOFF + i];
+            kc_tg[u][l] = a.tcol[i];
+            kc_tb[u][l] = a.tcol[BOFF + i];
+            kc_b[u][l] = (l == 0 ? a.b0 : (l == 1 ? a.b1 : a.b2))[tid + 256 * u];
+        }
+    const int t3 = tid < 3 ? tid : 0;
+    const float k3_g = hy[3 * XC_H + t3], k3_hb = hy[BOFF + 3 * XC_H + t3], k3_tg = a.tcol[3 * XC_H + t3], k3_tb = a.tcol[BOFF + 3 * XC_H + t3], k3_b = a.b3[t3];
+
     // The weight stream of one stage is a fixed sequence of 128 pieces: layer 1 chunk-major (s = 4 kc + rq), then layer 2
     // pass-major (s = 64 + 16 q + kc); piece (rq, kc) of a layer's pack sits at (rq * 16 + kc) * XW_PIECE.  Ring slot s & 3.
     auto piece_src = [&](int s_) -> const unsigned char * {
@@ -172,27 +189,30 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
 #ifdef CASPR_DEBUG_HOOKS
             if (a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && step == 0 && stage == 2) a.trace[306] = __builtin_amdgcn_s_memtime();
 #endif
+            // layer 1 accumulates from zero (issued before the barrier: overlaps the other waves' arrival)
+            if constexpr (!(XW_EXP & 1024)) xw_for<0, 256>([&](auto N) XW_INL { xw_acc_zero<decltype(N)::value>(); });
             __syncthreads();   // the previous stage's epilogues are done with the tables
-            for (int i = tid; i < ((XW_EXP & 1024) ? 0 : XC_H); i += 256) {
-                const float g0 = sigmoid_fast(hy[i] + t * a.tcol[i]);
-                s_hb0[i] = a.b0[i] * g0 + (hy[BOFF + i] + t * a.tcol[BOFF + i]);
+            // the stage's tables from the per-thread constants loaded once (kc_*): no global memory round trip per stage
+#pragma unroll
+            for (int u = 0; u < ((XW_EXP & 1024) ? 0 : 2); ++u) {
+                const int i = tid + 256 * u;
+                const float g0 = sigmoid_fast(fmaf(t, kc_tg[u][0], kc_g[u][0]));
+                s_hb0[i] = fmaf(kc_b[u][0], g0, fmaf(t, kc_tb[u][0], kc_hb[u][0]));
                 s_w0g[i] = s_w0[3 * i] * g0;
                 s_w0g[XC_H + i] = s_w0[3 * i + 1] * g0;
                 s_w0g[2 * XC_H + i] = s_w0[3 * i + 2] * g0;
-                const float g1 = sigmoid_fast(hy[XC_H + i] + t * a.tcol[XC_H + i]);
+                const float g1 = sigmoid_fast(fmaf(t, kc_tg[u][1], kc_g[u][1]));
                 s_g1[i] = g1;
-                s_hb1[i] = a.b1[i] * g1 + (hy[BOFF + XC_H + i] + t * a.tcol[BOFF + XC_H + i]);
-                const float g2 = sigmoid_fast(hy[2 * XC_H + i] + t * a.tcol[2 * XC_H + i]);
+                s_hb1[i] = fmaf(kc_b[u][1], g1, fmaf(t, kc_tb[u][1], kc_hb[u][1]));
+                const float g2 = sigmoid_fast(fmaf(t, kc_tg[u][2], kc_g[u][2]));
                 s_g2[i] = g2;
-                s_hb2[i] = a.b2[i] * g2 + (hy[BOFF + 2 * XC_H + i] + t * a.tcol[BOFF + 2 * XC_H + i]);
+                s_hb2[i] = fmaf(kc_b[u][2], g2, fmaf(t, kc_tb[u][2], kc_hb[u][2]));
             }
             if (tid < 3) {
-                const float gt = sigmoid_fast(hy[3 * XC_H + tid] + t * a.tcol[3 * XC_H + tid]);
+                const float gt = sigmoid_fast(fmaf(t, k3_tg, k3_g));
                 s_g3[tid] = gt;
-                s_g3[4 + tid] = a.b3[tid] * gt + (hy[BOFF + 3 * XC_H + tid] + t * a.tcol[BOFF + 3 * XC_H + tid]);
+                s_g3[4 + tid] = fmaf(k3_b, gt, fmaf(t, k3_tb, k3_hb));
             }
-            // layer 1 accumulates from zero
-            if constexpr (!(XW_EXP & 1024)) xw_for<0, 256>([&](auto N) XW_INL { xw_acc_zero<decltype(N)::value>(); });
             __syncthreads();
             XW_STAMP(301)
 

@@ -319,8 +319,9 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
                                                             int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()),
                        "caspr_conv1x1_bf16x6_f32")
         return out
-    _lib.check(_lib.load().caspr_conv1x1_f32(_p(pw.data), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
-                                             int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()), "caspr_conv1x1_f32")
+    with timed("k:conv1x1_f32:%d:%d:%d" % (pw.cin, pw.cout, B * P), 2):
+        _lib.check(_lib.load().caspr_conv1x1_f32(_p(pw.data), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                                 int(in_relu_from), _p(out), ldy, B, P, pw.cin, pw.cout, act, _stream()), "caspr_conv1x1_f32")
     return out
 
 

@@ -42,8 +42,9 @@ def conv1x1_wgrad(dy, x, cin, cout, dw, dbias=None, in_scale=None, in_shift=None
     # matrix products as ops.set_matmul_mode says: the exact bf16 three-way split where the tile is reasonably filled, f32 MFMA otherwise
     x6 = ops.CONV_BF16X6 and cin >= 32 and cout >= 32
     fn, name = (L.caspr_conv1x1_wgrad_bf16x6_f32, "caspr_conv1x1_wgrad_bf16x6_f32") if x6 else (L.caspr_conv1x1_wgrad_f32, "caspr_conv1x1_wgrad_f32")
-    _lib.check(fn(_p(dy), lddy, _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu), int(in_relu_from), B, P, cin, cout,
-                  _p(dw), _p(dbias), int(accumulate), _p(ws), ws.numel(), _stream()), name)
+    with ops.timed("k:%s:%d:%d:%d" % ("wgrad_bf16x6" if x6 else "wgrad_f32", cin, cout, B * P), 2):
+        _lib.check(fn(_p(dy), lddy, _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu), int(in_relu_from), B, P, cin, cout,
+                      _p(dw), _p(dbias), int(accumulate), _p(ws), ws.numel(), _stream()), name)
     return dw
 
 

@@ -453,3 +453,34 @@ def test_cnf_x6w_kernel_keeps_its_accumulator_file_to_itself():
     assert len(on_acc) == 8 * 4 * 12 and all(" a[" not in i for i in mfma if i not in on_acc), (len(mfma), len(on_acc))
     dma = count(r"global_load_lds_dwordx4")
     assert dma % 2 == 0 and sum(1 for i in ins if re.search(r"\bm0\b", i)) == dma // 2, dma
+
+
+def test_conv_x6w_kernel_keeps_its_accumulator_file_to_itself():
+    """The same audit for conv1x1_x6w_kernel (csrc/gemm_bf16x6w.hip, four instantiations): no scratch, no spills, every MFMA on
+    the hand-managed a[..] tiles, 256 zeroing writes and 256 epilogue reads of the accumulator file and nothing else."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "caspr_amd", "csrc", "gemm_bf16x6w.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
+        pytest.skip("needs the in-tree object and the ROCm LLVM tools")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        fat, elf = os.path.join(d, "w.fatbin"), os.path.join(d, "w.elf")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
+        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", elf], text=True)
+        dis = subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", elf], text=True)
+    kernels = re.findall(r"<(_Z18conv1x1_x6w_kernelILb[01]ELb[01]EEv9ConvWArgsPKfS2_)>:", dis)
+    assert len(kernels) == 4, kernels
+    for k in kernels:
+        meta = notes[notes.index(k) - 400:]
+        meta = meta[:meta.index(k) + 600]
+        assert re.search(r"\.private_segment_fixed_size:\s+0\b", meta) and re.search(r"\.vgpr_spill_count:\s+0\b", meta), (k, meta)
+        body = dis[dis.index("<%s>:" % k):]
+        body = body[:body.index("s_endpgm")]
+        ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.startswith("\t")]
+        count = lambda pat: sum(1 for i in ins if re.match(pat, i))
+        assert count(r"scratch_") == 0, k
+        assert count(r"v_accvgpr_write_b32") == 256 and count(r"v_accvgpr_read_b32") == 256 and count(r"v_accvgpr_mov") == 0, (k, count(r"v_accvgpr_write_b32"), count(r"v_accvgpr_read_b32"))
+        mfma = [i for i in ins if i.startswith("v_mfma")]
+        assert len(mfma) == 2 * 192 and all(re.match(r"v_mfma_f32_32x32x16_bf16 a\[", i) for i in mfma), (k, len(mfma))
