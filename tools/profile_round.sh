@@ -2,7 +2,7 @@
 # Round profile of the default path on the GPU box: kernel stats of bench.py (cfg-2), HBM-side traffic counters (FETCH_SIZE /
 # WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes), the cfg-5 shape, and the training step.
 # usage (from the repo root on the GPU box): bash tools/profile_round.sh r02     -> gpurun_out/<tag>_*
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -16,21 +16,36 @@ python $REPO/tools/rocprof_timeline.py $(find /tmp/pk -name "*results.db" | head
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pp && rocprofv3 --kernel-trace --pmc $C -d /tmp/pp -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/pp.err
   python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pp -name "*results.db" | head -1) /tmp/pmc_$C.txt
-  grep -E "counter|cnf_rk4|conv1x1_bf16x6|sa_mlp|gn_partial" /tmp/pmc_$C.txt >> $OUT/${TAG}_traffic_pmc.txt
+  grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w|sa_mlp|sa_small|gn_partial" /tmp/pmc_$C.txt >> $OUT/${TAG}_traffic_pmc.txt
   rm -f /tmp/pmc_$C.txt
 done
 rm -rf /tmp/pm && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d /tmp/pm -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/pm.err
 python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pm -name "*results.db" | head -1) /tmp/pmc_sq.txt
-grep -E "counter|cnf_rk4|conv1x1_bf16x6" /tmp/pmc_sq.txt > $OUT/${TAG}_sq_pmc.txt
+grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w" /tmp/pmc_sq.txt > $OUT/${TAG}_sq_pmc.txt
+# the traffic table bench.py reads (profiles/kernel_traffic.json): cfg-2
+python $REPO/tools/make_traffic_table.py $OUT/${TAG}_traffic_pmc.txt 16x10x2048 8 ${TAG}_traffic_pmc.txt
 # cfg-5 shape (BASELINE.json configs[4], one GPU's share): 64 sequences x 20 x 4096, random clouds
 python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 3 --warmup 1 --no-f32-subblock > $OUT/${TAG}_cfg5_bench.json 2> $OUT/${TAG}_cfg5_bench.err; echo "cfg5 rc=$?" >> $OUT/${TAG}_cfg5_bench.err
 rm -rf /tmp/p5 && rocprofv3 --kernel-trace --stats -d /tmp/p5 -o r -- python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/p5.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/p5 -name "*results.db" | head -1) $OUT/${TAG}_cfg5_kernel_stats.txt
+: > $OUT/${TAG}_cfg5_traffic_pmc.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pq && rocprofv3 --kernel-trace --pmc $C -d /tmp/pq -o r -- python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 1 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/pq.err
+  python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pq -name "*results.db" | head -1) /tmp/pmq_$C.txt
+  grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w" /tmp/pmq_$C.txt >> $OUT/${TAG}_cfg5_traffic_pmc.txt
+  rm -f /tmp/pmq_$C.txt
+done
+python $REPO/tools/make_traffic_table.py $OUT/${TAG}_cfg5_traffic_pmc.txt 64x20x4096 8 ${TAG}_cfg5_traffic_pmc.txt
 # training step (cfg-3 shard)
 python $REPO/bench_train.py --steps 3 --warmup 1 > $OUT/${TAG}_bench_train_full.json 2> $OUT/${TAG}_bench_train.err
 python $REPO/bench_train.py --steps 3 --warmup 1 --mode pretrain --no-cpu-baseline > $OUT/${TAG}_bench_train_pretrain.json 2>> $OUT/${TAG}_bench_train.err
 rm -rf /tmp/pt && rocprofv3 --kernel-trace --stats -d /tmp/pt -o r -- python $REPO/bench_train.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/pt.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/pt -name "*results.db" | head -1) $OUT/${TAG}_train_full_kernel_stats.txt
+# the CNF kernel alone (kernel stats + SQ counters) and the two micro-benchmarks behind DESIGN.md's power / filler discussion
+(cd $REPO && bash tools/profile_cnf.sh ${TAG} > /dev/null 2>&1)
+[ -x $REPO/tools/micro/mfma_power ] && $REPO/tools/micro/mfma_power > $OUT/${TAG}_mfma_power.txt 2>&1
+[ -x $REPO/tools/micro/mfma_fillers ] && $REPO/tools/micro/mfma_fillers > $OUT/${TAG}_mfma_fillers.txt 2>&1
+python $REPO/tools/conv_bench.py > $OUT/${TAG}_conv_bench.txt 2>&1
 # per-chunk phase cycles of the bf16x6 conv (debug flavour of the library, if it was built) and weight-gradient timings in both modes
 if [ -f $REPO/caspr_amd/csrc/libcaspr_hip_debug.so ]; then python $REPO/tools/conv_x6_trace.py > $OUT/${TAG}_conv_x6_trace.txt 2>&1; fi
 python $REPO/tools/wgrad_bench.py > $OUT/${TAG}_wgrad_bench.txt 2>&1
