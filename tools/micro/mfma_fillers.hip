@@ -22,6 +22,8 @@ __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc,
     lds[threadIdx.x + 256] = (f32x4){1, 2, 3, 4};
     __syncthreads();
     asm volatile("" : "+v"(a), "+v"(b));
+    float ka = 1.0001f, kb = 0.5f;
+    asm volatile("" : "+v"(ka), "+v"(kb));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc,
 #pragma unroll
             for (int f = 0; f < K; ++f) {
                 const int j = (u * K + f) & 7;
-                if (KIND == 0) v[j] = __builtin_fmaf(v[j], 1.0001f, 0.5f);                       // independent v_fma_f32 (8 chains)
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(ka), "v"(kb));      // independent v_fma_f32 (8 chains); asm so that hipcc cannot sink them behind the MFMAs
                 if (KIND == 1) v[j] = __builtin_amdgcn_exp2f(v[j]);                              // v_exp_f32
                 if (KIND == 2) r[j] = lds[(threadIdx.x + 64 * j) & 1023];                        // ds_read_b128
                 if (KIND == 3) asm volatile("s_nop 0");
