@@ -8,6 +8,8 @@ from caspr_amd import lib
 if "--lib" in sys.argv:
     lib.SO_PATH = lib.SO_PATH.replace("libcaspr_hip.so", sys.argv[sys.argv.index("--lib") + 1])
 from caspr_amd import ops
+if "--min-cin" in sys.argv:          # let the 512-channel kernel take layers below ops._X6W_MIN_CIN input channels
+    ops._X6W_MIN_CIN = int(sys.argv[sys.argv.index("--min-cin") + 1])
 dev = torch.device("cuda:0")
 def t(fn, k=5):
     fn(); torch.cuda.synchronize()
@@ -16,7 +18,7 @@ def t(fn, k=5):
     for _ in range(k): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / k
-for (B, P, Cin, Cout, gn) in [(16, 20480, 1600, 1600, True), (16, 20480, 1600, 1600, False), (160, 2048, 544, 512, True), (160, 1024, 608, 512, True), (160, 2048, 512, 512, True), (160, 512, 640, 512, True)]:
+for (B, P, Cin, Cout, gn) in [(16, 20480, 1600, 1600, True), (16, 20480, 1600, 1600, False), (16, 20480, 576, 1600, True), (160, 2048, 544, 512, True), (160, 1024, 608, 512, True), (160, 2048, 512, 512, True), (160, 512, 640, 512, True)]:
     w = torch.randn(Cout, Cin, device=dev) / Cin ** 0.5
     bias = torch.randn(Cout, device=dev)
     x = torch.randn(B, P, Cin, device=dev)
