@@ -74,17 +74,35 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
         const int C4 = (a.C + 3) & ~3;
         const int nkq = a.L[0].kc * 4;
         const int qfeat = C4 >> 2;
-        for (int it = tid; it < NCOL * nkq; it += 256) {
-            const int kq = it % nkq, col = it / nkq;
-            const int k = s_idx[col];
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kq < qfeat) {
-                v = ld4(a.feat + ((long)b * a.n + k) * a.ldf + kq * 4);
+        // feature quads: four independent rows in flight per thread, no branch around the loads -- with one load per iteration
+        // the loop was a chain of dependent L2 round trips (16.5k of the kernel's 60k cycles at 64 + 3 input channels,
+        // tools/sa_mlp_phase_trace.py)
+        constexpr int GU = 4;
+        const int nfeat = NCOL * qfeat;
+        for (int base = tid; base < nfeat; base += 256 * GU) {
+            f32x4 v[GU];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (kq * 4 + q >= a.C) v[q] = 0.f;
-            } else if (kq == qfeat) {
-                const float *p = a.xyz + ((long)b * a.n + k) * 3;
+            for (int u = 0; u < GU; ++u) {
+                const int it = base + 256 * u < nfeat ? base + 256 * u : nfeat - 1;   // clamped: the store below is guarded
+                const int kq = it % qfeat, col = it / qfeat;
+                v[u] = ld4(a.feat + ((long)b * a.n + s_idx[col]) * a.ldf + kq * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int it = base + 256 * u;
+                const int kq = it % qfeat, col = it / qfeat;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] = kq * 4 + q < a.C ? v[u][q] : 0.f;
+                if (it < nfeat) st4(bufA + btile_off(kq, col, NCOL), v[u]);
+            }
+        }
+        // [dx dy dz 0] and the zero quads behind it
+        const int nrest = nkq - qfeat;
+        for (int it = tid; it < NCOL * nrest; it += 256) {
+            const int kq = qfeat + it % nrest, col = it / nrest;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kq == qfeat) {
+                const float *p = a.xyz + ((long)b * a.n + s_idx[col]) * 3;
                 const float *c = s_cen + (col / NS) * 4;
                 v[0] = p[0] - c[0];
                 v[1] = p[1] - c[1];
@@ -165,6 +183,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
         // divides near-zero deviations by sqrt(var + 1e-5) -> up to 316x amplification of any rounding in
         // the mean.  f64 sums make mean/(x - mean) exact for such groups (the reference's f32 path is not).
         const int cpg = L.cout >> 4;
+        const float inv_cpg = 1.0f / (float)cpg;
         {
             const int stat = tid / TPS, sub = tid % TPS;
             const int cen = stat >> 4, grp = stat & 15;
@@ -185,11 +204,21 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                     }
                 }
             } else {
-                for (int e = sub; e < cnt; e += TPS) {
-                    const int co = grp * cpg + e / NS, col = cen * NS + e % NS;
-                    const double d = (double)bout[btile_off(co >> 2, col, NCOL) + (co & 3)];
-                    s += d;
-                    ss += d * d;
+                // groups that are not whole channel quads (96 channels: 6 per group): 16-byte reads of every quad the group
+                // touches, entries outside it masked -- the scalar form of this loop (4-way bank conflicts on 16-byte-strided
+                // b32 reads) was 6.9k of the 68k cycles of the 64-96-128 scale
+                const int c_lo = grp * cpg, c_hi = c_lo + cpg;
+                const int q_lo = c_lo >> 2, nq = ((c_hi - 1) >> 2) - q_lo + 1;
+                for (int e = sub; e < nq * NS; e += TPS) {
+                    const int kq = q_lo + e / NS;
+                    const f32x4 x4 = ld4(bout + btile_off(kq, cen * NS + e % NS, NCOL));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = kq * 4 + q;
+                        const double d = (co >= c_lo && co < c_hi) ? (double)x4[q] : 0.0;
+                        s += d;
+                        ss += d * d;
+                    }
                 }
             }
             s = row_allreduce_add<TPS>(s);
@@ -216,12 +245,13 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
                 if (kq < nq) {
                     v = ld4(p);
                     const int cen = col / NS;
+                    const f32x4 ga = ld4(L.gamma + kq * 4), be = ld4(L.beta + kq * 4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int co = kq * 4 + q;
-                        const int st = cen * 16 + co / cpg;
+                        const int st = cen * 16 + (int)(((float)co + 0.5f) * inv_cpg);   // co / cpg without the integer division (co < 512, cpg <= 32: exact)
                         // (x - mean) first: exact for the near-constant neighbourhoods where rstd -> 1/sqrt(eps)
-                        const float y = (float)((double)v[q] - s_mean[st]) * (s_rstd[st] * L.gamma[co]) + L.beta[co];
+                        const float y = (float)((double)v[q] - s_mean[st]) * (s_rstd[st] * ga[q]) + be[q];
                         v[q] = y > 0.f ? y : 0.f;
                     }
                 }
@@ -234,10 +264,12 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
             bout = t;
         } else {
             // ---- last layer: GroupNorm (no ReLU) then max over the NS samples (pointnet2.py:690-698)
+            // (four lanes per channel quad with 16-byte reads and a cross-lane max measured SLOWER than this scalar form: 5.9k vs 5.1k cycles)
+            const float inv_cout = 1.0f / (float)L.cout;
             for (int it = tid; it < NCEN * L.cout; it += 256) {
-                const int co = it % L.cout, cen = it / L.cout;
+                const int cen = (int)(((float)it + 0.5f) * inv_cout), co = it - cen * L.cout;   // it < NCEN * cout <= 2048: exact
                 if (m0 + cen >= a.M) continue;
-                const int st = cen * 16 + co / cpg;
+                const int st = cen * 16 + (int)(((float)co + 0.5f) * inv_cpg);
                 const float sc = s_rstd[st] * L.gamma[co], be = L.beta[co];
                 const double mean = s_mean[st];
                 float mx = -INFINITY;
