@@ -136,6 +136,19 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
                      : : "s"(dst), "v"(lane16), "s"(src) : "memory");
     };
+    // ONE instruction per scheduling slot inside the product stream: a lone LDS-DMA hides behind the slot's MFMA, the second of a
+    // back-to-back pair waits for the first (tools/micro/mfma_pipe.hip: 1764 cycles per 48-MFMA piece with three pairs, 1663
+    // with six singles in slots that carry no producer step, 1632 without any DMA)
+    auto dma1 = [&](int s_, int lane16, int i0) XW_INL {
+        if constexpr (XW_EXP & 2) return;
+        if constexpr (XW_EXP & 16384) {          // debug flavour: the previous placement, pairs in the slot of the even instruction
+            if (!(i0 & 1)) dma(s_, lane16, i0);
+            return;
+        }
+        const unsigned char *src = piece_src(s_) + (wave * 6 + i0) * 1024;
+        const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(wbuf + (s_ & 3) * XW_PIECE + (wave * 6 + i0) * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(lane16), "s"(src) : "memory");
+    };
     const double t0 = a.reverse ? (double)a.t_end : 0.0, t1 = a.reverse ? 0.0 : (double)a.t_end;
     const double h = (t1 - t0) / (double)a.steps;
     const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
@@ -360,14 +373,16 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
                     region_a(std::integral_constant<int, 4 * rq>{}, fX, b1w[par][0], fY, A + 6 * XW_FRAG, [&](auto I) XW_INL {
                         constexpr int i = decltype(I)::value;
                         if constexpr (i == 0) l1_tab(ubn);
-                        if constexpr (i == 7) dma(s1 + 3, lane16, 2);
+                        if constexpr (i == 7) dma1(s1 + 3, lane16, 2);
+                        if constexpr (i == 10) dma1(s1 + 3, lane16, 3);
                     });
                     // region 1: k-step 0, row tiles 2, 3 (fY) | reads k-step 1, row tiles 0, 1 -> fX
                     XW_STAMPC(it == 1 || it == 2, 320 + 32 * (it - 1) + 4 * pc + 1)
                     region_a(std::integral_constant<int, 4 * rq + 2>{}, fY, b1w[par][0], fX, A + 12 * XW_FRAG, [&](auto I) XW_INL {
                         constexpr int i = decltype(I)::value;
                         l1_pair_step(I, bn, rq & 1, 0);
-                        if constexpr (i == 8) dma(s1 + 3, lane16, 4);
+                        if constexpr (i == 8) dma1(s1 + 3, lane16, 4);       // slots 8 and 11 carry no producer step
+                        if constexpr (i == 11) dma1(s1 + 3, lane16, 5);
                     });
                     // region 2: k-step 1, row tiles 0, 1 (fX) | reads k-step 1, row tiles 2, 3 -> fY
                     XW_STAMPC(it == 1 || it == 2, 320 + 32 * (it - 1) + 4 * pc + 2)
@@ -379,7 +394,8 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
                     XW_STAMPC(it == 1 || it == 2, 320 + 32 * (it - 1) + 4 * pc + 3)
                     region_a_last(std::integral_constant<int, 4 * rq + 2>{}, fY, b1w[par][1], fX, An, s1 + 1, [&](auto I) XW_INL {
                         constexpr int i = decltype(I)::value;
-                        if constexpr (i == 9) dma(s1 + 4, lane16, 0);
+                        if constexpr (i == 8) dma1(s1 + 4, lane16, 0);
+                        if constexpr (i == 11) dma1(s1 + 4, lane16, 1);
                     });
                 });
             }
@@ -485,14 +501,16 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
                         constexpr int i = decltype(I)::value;
                         l2_step(I, std::integral_constant<int, tb>{}, std::integral_constant<int, 0>{}, FC, b2w[1], 0);
                         if constexpr (first && i == 6) l2_tab(1, tb, 1);
-                        if constexpr (i == 7) dma(sq + 3, lane16, 2);
+                        if constexpr (i == 7) dma1(sq + 3, lane16, 2);
+                        if constexpr (i == 10) dma1(sq + 3, lane16, 3);
                     });
                     // region 1: k-step 2 kc, row tiles 2, 3 (fY) | reads tb, row tiles 0, 1 -> fX | group 1 of tb
                     region_v(acc2[2], acc2[3], fY, b2w[0], fX, A + 12 * XW_FRAG, [&](auto I) XW_INL {
                         constexpr int i = decltype(I)::value;
                         l2_step(I, std::integral_constant<int, tb>{}, std::integral_constant<int, 1>{}, FC, b2w[1], 1);
                         if constexpr (first && kc < 15 && i == 6) l2_tab(0, tn, 0);
-                        if constexpr (i == 8) dma(sq + 3, lane16, 4);
+                        if constexpr (i == 8) dma1(sq + 3, lane16, 4);
+                        if constexpr (i == 11) dma1(sq + 3, lane16, 5);
                     });
                     // region 2: k-step tb, row tiles 0, 1 (fX) | reads tb, row tiles 2, 3 -> fY | group 0 of k-step tb + 1
                     region_v(acc2[0], acc2[1], fX, b2w[1], fY, A + 18 * XW_FRAG, [&](auto I) XW_INL {
@@ -506,7 +524,8 @@ __global__ __launch_bounds__(256, 1) void cnf_rk4_x6w_kernel(CnfX6Args a)
                         constexpr int i = decltype(I)::value;
                         if constexpr (kc < 15) l2_step(I, std::integral_constant<int, tn>{}, std::integral_constant<int, 1>{}, FC, b2w[0], 1);
                         if constexpr (first && kc < 15 && i == 6) l2_tab(0, tn + 1, 0);
-                        if constexpr (i == 9) dma(sq + 4, lane16, 0);
+                        if constexpr (i == 8) dma1(sq + 4, lane16, 0);
+                        if constexpr (i == 11) dma1(sq + 4, lane16, 1);
                     });
                 });
                 // ---- epilogue of hidden layer 2 for rows 128 q .. 128 q + 127 + their share of the 512 -> 3 output layer:

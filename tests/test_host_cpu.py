@@ -451,8 +451,11 @@ def test_cnf_x6w_kernel_keeps_its_accumulator_file_to_itself():
     mfma = [i for i in ins if i.startswith("v_mfma")]
     on_acc = [i for i in mfma if re.match(r"v_mfma_f32_32x32x16_bf16 a\[", i)]
     assert len(on_acc) == 8 * 4 * 12 and all(" a[" not in i for i in mfma if i not in on_acc), (len(mfma), len(on_acc))
+    # M0 is written by the LDS-DMA statements only: one write per instruction inside the product stream (one instruction per
+    # scheduling slot), one per PAIR in the prologue (ten pairs: three whole pieces and a third of the fourth)
     dma = count(r"global_load_lds_dwordx4")
-    assert dma % 2 == 0 and sum(1 for i in ins if re.search(r"\bm0\b", i)) == dma // 2, dma
+    m0 = sum(1 for i in ins if re.search(r"\bm0\b", i))
+    assert dma > 20 and m0 == dma - 10, (dma, m0)
 
 
 def test_conv_x6w_kernel_keeps_its_accumulator_file_to_itself():
