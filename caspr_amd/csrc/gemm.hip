@@ -687,6 +687,72 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict
     }
 }
 
+// The same partials with ROW-contiguous reads, for C <= 1024: one workgroup per (point split, batch entry) covers all channels --
+// thread (tp, tq) walks rows tp, tp + TP, ... of the split with the 16 bytes of channel quad tq, so a wave reads whole rows
+// (gn_partial_kernel above gives every group its own workgroup: at 4 channels per group each reads 16 bytes per row, a quarter
+// of every 64-byte sector it touches, and the 16 workgroups of a split fetch the same rows 16 times: 0.8 TB/s on the
+// 327,680 x 64 layer of the global PointNet, 103 us; this form 1/4 of that).  Same sums in the same f64 arithmetic; the order of
+// the additions differs (fixed, so still deterministic).
+__global__ __launch_bounds__(256) void gn_partial_rows_kernel(const float *__restrict__ Y, int ldy, int P, int C, int G,
+                                                              double *__restrict__ psum, float *__restrict__ pmm)
+{
+    __shared__ double s_sum[256], s_sq[256];
+    __shared__ float s_mx[256 * 4], s_mn[256 * 4];
+    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    const int CQ = C >> 2, cpg = C / G, qpg = cpg >> 2;     // host: C % 4 == 0, cpg % 4 == 0, CQ <= 256
+    const int TP = 256 / CQ;
+    const int tq = threadIdx.x % CQ, tp = threadIdx.x / CQ;
+    const int pbeg = s * GN_SPLIT, pend = (pbeg + GN_SPLIT) < P ? (pbeg + GN_SPLIT) : P;
+    double sum = 0.0, sq = 0.0;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    if (tp < TP) {
+        const float *base = Y + (long)b * P * ldy + tq * 4;
+#pragma unroll 8
+        for (int p = pbeg + tp; p < pend; p += TP) {
+            const f32x4 v = ld4(base + (long)p * ldy);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sum += (double)v[q];
+                sq += (double)v[q] * (double)v[q];
+                mx[q] = v[q] > mx[q] ? v[q] : mx[q];
+                mn[q] = v[q] < mn[q] ? v[q] : mn[q];
+            }
+        }
+    }
+    s_sum[threadIdx.x] = sum;
+    s_sq[threadIdx.x] = sq;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s_mx[threadIdx.x * 4 + q] = mx[q];
+        s_mn[threadIdx.x * 4 + q] = mn[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {        // one thread per group: its quads x the TP row lanes, in index order
+        const int g = threadIdx.x;
+        double a0 = 0.0, a1 = 0.0;
+        for (int r = 0; r < TP; ++r)
+            for (int k = 0; k < qpg; ++k) {
+                a0 += s_sum[r * CQ + g * qpg + k];
+                a1 += s_sq[r * CQ + g * qpg + k];
+            }
+        double *o = psum + (((long)b * G + g) * S + s) * 2;
+        o[0] = a0;
+        o[1] = a1;
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int q4 = c >> 2, q = c & 3;
+        float m1 = -INFINITY, m0 = INFINITY;
+        for (int r = 0; r < TP; ++r) {
+            const float a = s_mx[(r * CQ + q4) * 4 + q], bb = s_mn[(r * CQ + q4) * 4 + q];
+            m1 = a > m1 ? a : m1;
+            m0 = bb < m0 ? bb : m0;
+        }
+        float *o = pmm + (((long)b * C + c) * S + s) * 2;
+        o[0] = m1;
+        o[1] = m0;
+    }
+}
+
 __global__ void gn_finalize_kernel(const double *__restrict__ psum, const float *__restrict__ pmm, int B, int P, int C,
                                    int G, int S, const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float eps, float *__restrict__ scale, float *__restrict__ shift,
@@ -737,7 +803,10 @@ static int gn_stats_impl(const float *Y, int ldy, int B, int P, int C, int G, co
     double *psum = (double *)ws;
     float *pmm = (float *)((char *)ws + (((long)B * G * S * 16 + 63) & ~63L));
     hipStream_t st = (hipStream_t)stream;
-    gn_partial_kernel<<<dim3(G, S, B), dim3(256), 0, st>>>(Y, ldy, P, C, G, psum, pmm);
+    if (C <= 1024 && G <= 256 && 256 % (C >> 2) == 0)
+        gn_partial_rows_kernel<<<dim3(S, B), dim3(256), 0, st>>>(Y, ldy, P, C, G, psum, pmm);
+    else
+        gn_partial_kernel<<<dim3(G, S, B), dim3(256), 0, st>>>(Y, ldy, P, C, G, psum, pmm);
     gn_finalize_kernel<<<dim3(ceil_div(B * C, 256)), dim3(256), 0, st>>>(psum, pmm, B, P, C, G, S, gamma, beta, eps, scale,
                                                                          shift, pmax, mean, rstd);
     CASPR_CHECK_LAUNCH("gn_stats");

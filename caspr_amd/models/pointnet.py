@@ -36,8 +36,8 @@ class PointNetfeat(nn.Module):
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
         y1 = ops.conv1x1(self._packed("conv1"), c1.bias, x_pm, out=y1_out)                     # pointnet.py:37
         s1, t1 = ops.gn_stats(y1, c1.out_channels, self.bn1.weight, self.bn1.bias)
-        y2 = ops.conv1x1(self._packed("conv2"), c2.bias, y1, in_scale=s1, in_shift=t1, in_relu=True)  # :39
-        s2, t2 = ops.gn_stats(y2, c2.out_channels, self.bn2.weight, self.bn2.bias)
+        y2, s2, t2 = ops.conv1x1_gn(self._packed("conv2"), c2.bias, y1, self.bn2.weight, self.bn2.bias,
+                                    in_scale=s1, in_shift=t1, in_relu=True)                     # :39, statistics in the conv's epilogue
         # conv3 -> bn3 -> max over points (:40-42): only the pooled maximum is used, so the 1024-channel output is not stored
         _, _, _, gmax = ops.conv1x1_gn(self._packed("conv3"), c3.bias, y2, self.bn3.weight, self.bn3.bias, want_max=True, write=False,
                                        in_scale=s2, in_shift=t2, in_relu=True)

@@ -208,7 +208,7 @@ CNF_BF16X6 = _mode == "bf16x6"       # point-CNF solves on the bf16x6 kernel
 _X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstraction / input layers)
 _X6W_MIN_CIN = 1024   # the 512-channel kernel (gemm_bf16x6w.hip) runs one workgroup per CU: its prologue / epilogue are exposed, and only the
                       # 1600-wide head layer's K loop (50 chunks) amortises them -- measured: 8.03 vs 8.50 ms there, 0.95 vs 0.91 ms at 512 -> 512
-_X6_GN_MIN_CIN = 128  # conv + GroupNorm statistics in one pass (conv1x1_gn): pays from a smaller width (no second pass over the output)
+_X6_GN_MIN_CIN = 64   # conv + GroupNorm statistics in one pass (conv1x1_gn): pays from a smaller width (no second pass over the output)
 
 
 def set_matmul_mode(mode=None, conv=None, cnf=None):

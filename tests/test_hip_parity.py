@@ -354,7 +354,7 @@ def test_gn_stats(ops, dev, B, P_, C):
     record("gn_max_C%d" % C, pm, want.max(dim=1)[0], 5e-6)
 
 
-@pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 256, 512, 512), (1, 2560, 1600, 1600), (3, 384, 128, 1024), (2, 128, 544, 512), (1, 200, 512, 512)])
+@pytest.mark.parametrize("B,P_,Cin,Cout", [(2, 256, 512, 512), (1, 2560, 1600, 1600), (3, 384, 128, 1024), (2, 128, 544, 512), (1, 200, 512, 512), (2, 256, 64, 128)])
 def test_conv1x1_gn_fused(ops, dev, B, P_, Cin, Cout):
     """conv -> GroupNorm statistics in one pass (caspr_conv1x1_gn_bf16x6_f32): the statistics taken from the conv's
     accumulators (f32 per 128-point tile, f64 across tiles) against an f64 GroupNorm of the f64 conv, at gn_stats' tolerance;
