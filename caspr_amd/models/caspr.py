@@ -113,14 +113,15 @@ class CaSPR(nn.Module):
         """caspr.py:148-155."""
         return self.encoder(x)
 
-    def aggregate_and_solve_latent(self, z0, time_tensor):
+    def aggregate_and_solve_latent(self, z0, time_tensor, _plan=None):
         """caspr.py:157-183: unique sorted times -> latent ODE -> map back -> concat the static feature.
-        Inference on the GPU takes the synchronisation-free route of LatentODE.solve_at (same values)."""
+        Inference on the GPU takes the synchronisation-free route of LatentODE.solve_at (same values); _plan: what
+        reconstruct() prepared ahead of the encoder (LatentODE.plan_times)."""
         B, T = time_tensor.size()
         z_init = z0[:, :self.latent_ode.input_size]
         z_global = z0[:, self.latent_ode.input_size:]
         if z0.is_cuda and not self._differentiable(z0, time_tensor):
-            sample_feats = self.latent_ode.solve_at(z_init, time_tensor)
+            sample_feats = self.latent_ode.solve_at(z_init, time_tensor, _plan)
         else:
             solve_t, time_map = torch.unique(time_tensor, sorted=True, return_inverse=True)
             pred_z = self.gen_latent(z_init, solve_t)
@@ -212,11 +213,14 @@ class CaSPR(nn.Module):
             # the T-NOCS regression of the encoder's last layer runs on a side stream underneath the latent solve (32 workgroups,
             # latency-bound); joined before the flow starts
             defer = x.is_cuda and not self._differentiable(x)
+            # what the latent solve needs from the time stamps alone is queued before the encoder (a dozen tiny kernels that
+            # otherwise sit between the encoder's last layer and the solve, behind the T-NOCS layer's workgroups)
+            plan = self.latent_ode.plan_times(all_times) if defer else None
             z0, tnocs_pred = self.encoder(x, defer_tnocs=True) if defer else self.encode(x)
             # the encoder is queued: draw the base samples on the host now (as the reference does inside decode), under it
             early = self._draw_early(B, T, num_points, constant_in_time, x.device) if (defer and y is None and sample_contours is None) else None
             with ops.timed("latent"):
-                z = self.aggregate_and_solve_latent(z0, all_times)
+                z = self.aggregate_and_solve_latent(z0, all_times, plan)
             if defer:
                 self.encoder.join()
             with ops.timed("decode"):

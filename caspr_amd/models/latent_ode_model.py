@@ -57,22 +57,31 @@ class LatentODE(nn.Module):
         self.ode_func._num_evals += 4 * self.rk4_steps * max(Tu - 1, 0)
         return out
 
-    def solve_at(self, z0, time_tensor):
-        """z(t) for every entry of time_tensor (B,T) [any order, repeats allowed] -> (B,T,H), without a host
-        synchronisation: the reference takes torch.unique of the times (caspr.py:166), whose output size is
-        data-dependent; here ALL B*T stamps are sorted on the device and handed to the kernel, which skips the
-        zero-length intervals between repeated stamps -- the same integration steps, the same values."""
+    def plan_times(self, time_tensor):
+        """Everything of solve_at that depends on the time stamps only (the sort, its inverse, the gather rows, the number of
+        evaluations): a dozen tiny device kernels that `reconstruct` issues BEFORE the encoder, off the path between the
+        encoder's last layer and the solve (they took 0.25 ms there, queued behind the T-NOCS layer's workgroups)."""
         B, T = time_tensor.shape
         flat = time_tensor.reshape(-1).float()
         sorted_t, perm = torch.sort(flat, stable=True)
         pos = torch.empty_like(perm)
         pos[perm] = torch.arange(perm.numel(), device=perm.device)
-        self.ode_func._num_evals.fill_(0)
-        out = ops.latent_rk4(z0, sorted_t.contiguous(), self.rk4_steps, self._weights())       # (B, B*T, H)
         distinct = (sorted_t[1:] != sorted_t[:-1]).sum()
-        self.ode_func._num_evals.copy_(4.0 * self.rk4_steps * distinct)                         # evaluations actually run
-        rows = torch.arange(B, device=z0.device).view(-1, 1).expand(B, T)
-        return out[rows, pos.view(B, T), :]
+        rows = torch.arange(B, device=time_tensor.device).view(-1, 1).expand(B, T)
+        return {"shape": (B, T), "sorted_t": sorted_t.contiguous(), "rows": rows, "pos": pos.view(B, T),
+                "evals": (4.0 * self.rk4_steps * distinct).to(self.ode_func._num_evals.dtype)}
+
+    def solve_at(self, z0, time_tensor, plan=None):
+        """z(t) for every entry of time_tensor (B,T) [any order, repeats allowed] -> (B,T,H), without a host
+        synchronisation: the reference takes torch.unique of the times (caspr.py:166), whose output size is
+        data-dependent; here ALL B*T stamps are sorted on the device and handed to the kernel, which skips the
+        zero-length intervals between repeated stamps -- the same integration steps, the same values.
+        plan: plan_times(time_tensor) made earlier on this stream."""
+        if plan is None or plan["shape"] != tuple(time_tensor.shape):
+            plan = self.plan_times(time_tensor)
+        out = ops.latent_rk4(z0, plan["sorted_t"], self.rk4_steps, self._weights())            # (B, B*T, H)
+        self.ode_func._num_evals.copy_(plan["evals"])                                           # evaluations actually run
+        return out[plan["rows"], plan["pos"], :]
 
     def num_evals(self):
         return self.ode_func._num_evals.item()

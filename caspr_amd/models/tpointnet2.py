@@ -64,6 +64,8 @@ class TPointNet2(nn.Module):
         self.record = None  # set to a list to capture FPS / ball-query indices (parity tests)
 
     def _side_stream(self, device):
+        # (a CU-masked side stream -- hipExtStreamCreateWithCUMask leaving one unit in eight to the latent team -- was tried in
+        # round 3: the mask had no measurable effect on where kernels ran, and the step got 3 ms slower with the external stream)
         key = (device.type, device.index)
         if not hasattr(self, "_streams"):
             self._streams = {}
