@@ -383,6 +383,11 @@ __global__ __launch_bounds__(256) void latent_rk4_team_kernel(const float *__res
 
 #define LM_WS_STRIDE (256 + (2 * 128 * LAT_NCOL * 4 + LM_TEAM * 4 * 256) * 4)
 
+__global__ void latent_team_zero_kernel(char *ws, long stride)
+{
+    reinterpret_cast<unsigned *>(ws + (long)blockIdx.x * stride)[threadIdx.x] = 0u;      // 64 lanes x 4 B = the 256-byte header
+}
+
 extern "C" long caspr_latent_team_ws_bytes(int B) { return (long)ceil_div(B, LAT_NCOL) * LM_WS_STRIDE + 256; }
 
 extern "C" int caspr_latent_rk4_team_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H,
@@ -397,11 +402,9 @@ extern "C" int caspr_latent_rk4_team_f32(const float *z0, int ldz, const float *
     const int groups = ceil_div(B, LAT_NCOL);
     CASPR_REQUIRE(groups * LM_TEAM <= 128, "latent_rk4_team: %d sequences need %d co-resident workgroups (> 128); use caspr_latent_rk4_f32", B, groups * LM_TEAM);
     hipStream_t st = (hipStream_t)stream;
-    for (int gidx = 0; gidx < groups; ++gidx)
-        if (hipMemsetAsync((char *)ws + (long)gidx * LM_WS_STRIDE, 0, 256, st) != hipSuccess) {
-            caspr_set_error("latent_rk4_team: hipMemsetAsync failed");
-            return CASPR_ELAUNCH;
-        }
+    // the barrier words of every group, zeroed by a KERNEL: a hipMemsetAsync here is a runtime blit, and behind a long kernel of
+    // the same stream it started ~215 us after that kernel's end (step timelines of round 3) -- on the critical path of the step
+    latent_team_zero_kernel<<<dim3(groups), dim3(64), 0, st>>>((char *)ws, (long)LM_WS_STRIDE);
     latent_rk4_team_kernel<<<dim3(LM_TEAM, groups), dim3(256), 0, st>>>(z0, ldz, times, B, Tu, D, steps, w0p, b0, w1p, b1, w2p, b2, w3p, b3,
                                                                         out, (char *)ws, (long)LM_WS_STRIDE);
     CASPR_CHECK_LAUNCH("latent_rk4_team");
