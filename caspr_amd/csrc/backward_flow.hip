@@ -10,19 +10,34 @@
 //                       dg[f]    = sum_{r in f} da*(zv+b) + dad*zt         dbeta[f] = sum_{r in f} da
 // Only Z is kept between the two passes; a, ad, s are recomputed.  The per-frame sums are taken by the one workgroup
 // that owns (frame, 64 channels): fixed order, no atomics.
+//
+// Row layout (round 3): `blk` = R is the layout above; blk = 32 interleaves, per 64 rows, 32 value rows and the tangent rows of
+// the SAME 32 points -- value row of point p = (p / blk) 2 blk + p % blk, tangent row = value row + blk -- which is what lets
+// the conv kernel apply this layer in its epilogue (conv1x1_bf16x6_kernel, act mode 2: a lane's column tiles 0, 1 are values,
+// 2, 3 their tangents).  Every entry point takes blk; all tensors of one solve share it.
 #include "common.h"
+
+// value row of point p; the tangent row is + toff (= blk).  shift < 0: blk == R (rows [0,R) | [R,2R))
+__device__ __forceinline__ long cnf_vrow(long p, int shift) { return shift < 0 ? p : (((p >> shift) << (shift + 1)) | (p & ((1L << shift) - 1))); }
+static int cnf_blk_shift(long R, long blk)   // -1 for blk == R, log2 otherwise, -2 if unsupported
+{
+    if (blk == R) return -1;
+    for (int sft = 0; sft < 30; ++sft)
+        if ((1L << sft) == blk) return R % blk == 0 ? sft : -2;
+    return -2;
+}
 
 __global__ __launch_bounds__(256) void cnf_act_fwd_kernel(const float *__restrict__ Z, int ldz, const float *__restrict__ b,
                                                           const float *__restrict__ gate, const float *__restrict__ beta,
-                                                          long R, int n, int C, float *__restrict__ H, int ldh)
+                                                          long R, int n, int C, float *__restrict__ H, int ldh, int shift, long toff)
 {
     const int C4 = C >> 2;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R * C4) return;
-    const long r = t / C4;
+    const long pt = t / C4, r = cnf_vrow(pt, shift);
     const int c = (int)(t % C4) * 4;
-    const long f = r / n;
-    const f32x4 zv = ld4(Z + r * ldz + c), zt = ld4(Z + (R + r) * ldz + c);
+    const long f = pt / n;
+    const f32x4 zv = ld4(Z + r * ldz + c), zt = ld4(Z + (toff + r) * ldz + c);
     const f32x4 bb = ld4(b + c), g = ld4(gate + f * C + c), be = ld4(beta + f * C + c);
     f32x4 hv, ht;
 #pragma unroll
@@ -32,14 +47,14 @@ __global__ __launch_bounds__(256) void cnf_act_fwd_kernel(const float *__restric
         ht[q] = sigmoid_f(a) * (zt[q] * g[q]);
     }
     st4(H + r * ldh + c, hv);
-    st4(H + (R + r) * ldh + c, ht);
+    st4(H + (toff + r) * ldh + c, ht);
 }
 
 __global__ __launch_bounds__(256) void cnf_act_bwd_kernel(const float *__restrict__ Z, int ldz, const float *__restrict__ b,
                                                           const float *__restrict__ gate, const float *__restrict__ beta,
                                                           const float *__restrict__ dH, int ldd, long R, int n, int C,
                                                           float *__restrict__ dZ, int lddz, float *__restrict__ dgate,
-                                                          float *__restrict__ dbeta)
+                                                          float *__restrict__ dbeta, int shift, long toff)
 {
     __shared__ float s_g[4][64], s_b[4][64];
     const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -49,15 +64,15 @@ __global__ __launch_bounds__(256) void cnf_act_bwd_kernel(const float *__restric
     if (c < C) {
         const float bb = b[c], g = gate[f * C + c], be = beta[f * C + c];
         for (int p = sub; p < n; p += 4) {
-            const long r = f * n + p;
-            const float zv = Z[r * ldz + c], zt = Z[(R + r) * ldz + c];
-            const float dhv = dH[r * ldd + c], dht = dH[(R + r) * ldd + c];
+            const long r = cnf_vrow(f * n + p, shift);
+            const float zv = Z[r * ldz + c], zt = Z[(toff + r) * ldz + c];
+            const float dhv = dH[r * ldd + c], dht = dH[(toff + r) * ldd + c];
             const float a = (zv + bb) * g + be, ad = zt * g;
             const float s = sigmoid_f(a);
             const float da = dhv * s + dht * (s * (1.0f - s)) * ad;
             const float dad = dht * s;
             dZ[r * lddz + c] = da * g;
-            dZ[(R + r) * lddz + c] = dad * g;
+            dZ[(toff + r) * lddz + c] = dad * g;
             acc_g += da * (zv + bb) + dad * zt;
             acc_b += da;
         }
@@ -72,28 +87,32 @@ __global__ __launch_bounds__(256) void cnf_act_bwd_kernel(const float *__restric
 }
 
 extern "C" int caspr_cnf_act_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta, long R,
-                                 int n, int C, float *H, int ldh, void *stream)
+                                 int n, int C, long blk, float *H, int ldh, void *stream)
 {
+    const int shift = cnf_blk_shift(R, blk);
+    CASPR_REQUIRE(shift >= -1, "cnf_act: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
     CASPR_REQUIRE(Z && b && gate && beta && H && R > 0 && n > 0 && R % n == 0 && C > 0 && C % 4 == 0 && ldz % 4 == 0 && ldh % 4 == 0 &&
                       ldz >= C && ldh >= C,
                   "cnf_act: bad arguments (C=%d must be a multiple of 4, R a multiple of n)", C);
     const long total = R * (C / 4);
-    cnf_act_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(Z, ldz, b, gate, beta, R, n, C, H, ldh);
+    cnf_act_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(Z, ldz, b, gate, beta, R, n, C, H, ldh, shift, blk);
     CASPR_CHECK_LAUNCH("cnf_act");
     return CASPR_OK;
 }
 
 extern "C" int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
-                                     const float *dH, int ldd, long R, int n, int C, float *dZ, int lddz, float *dgate,
+                                     const float *dH, int ldd, long R, int n, int C, long blk, float *dZ, int lddz, float *dgate,
                                      float *dbeta, void *stream)
 {
+    const int shift = cnf_blk_shift(R, blk);
+    CASPR_REQUIRE(shift >= -1, "cnf_act_bwd: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
     CASPR_REQUIRE(Z && b && gate && beta && dH && dZ && dgate && dbeta && R > 0 && n > 0 && R % n == 0 && C > 0 && ldz >= C && ldd >= C &&
                       lddz >= C,
                   "cnf_act_bwd: bad arguments");
     const long frames = R / n;
     CASPR_REQUIRE(frames <= 65535, "cnf_act_bwd: %ld frames > 65535", frames);
     cnf_act_bwd_kernel<<<dim3(ceil_div(C, 64), (unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(Z, ldz, b, gate, beta, dH, ldd, R, n,
-                                                                                                       C, dZ, lddz, dgate, dbeta);
+                                                                                                       C, dZ, lddz, dgate, dbeta, shift, blk);
     CASPR_CHECK_LAUNCH("cnf_act_bwd");
     return CASPR_OK;
 }
@@ -118,16 +137,16 @@ static __device__ __forceinline__ float wave_sum_f(float v)   // uniform result:
 __global__ __launch_bounds__(256) void cnf_in_fwd_kernel(const float *__restrict__ Yp, const float *__restrict__ E,
                                                          const float *__restrict__ W0, const float *__restrict__ b,
                                                          const float *__restrict__ gate, const float *__restrict__ beta,
-                                                         long R, int n, int C, float *__restrict__ H)
+                                                         long R, int n, int C, float *__restrict__ H, int shift, long toff)
 {
     const int C4 = C >> 2;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R * C4) return;
-    const long r = t / C4;
+    const long pt = t / C4, r = cnf_vrow(pt, shift);
     const int c = (int)(t % C4) * 4;
-    const long f = r / n;
-    const float y0 = Yp[r * 3], y1 = Yp[r * 3 + 1], y2 = Yp[r * 3 + 2];
-    const float e0 = E[r * 3], e1 = E[r * 3 + 1], e2 = E[r * 3 + 2];
+    const long f = pt / n;
+    const float y0 = Yp[pt * 3], y1 = Yp[pt * 3 + 1], y2 = Yp[pt * 3 + 2];
+    const float e0 = E[pt * 3], e1 = E[pt * 3 + 1], e2 = E[pt * 3 + 2];
     const f32x4 bb = ld4(b + c), g = ld4(gate + f * C + c), be = ld4(beta + f * C + c);
     f32x4 hv, ht;
 #pragma unroll
@@ -140,7 +159,46 @@ __global__ __launch_bounds__(256) void cnf_in_fwd_kernel(const float *__restrict
         ht[q] = sigmoid_f(a) * (zt * g[q]);
     }
     st4(H + r * C + c, hv);
-    st4(H + (R + r) * C + c, ht);
+    st4(H + (toff + r) * C + c, ht);
+}
+
+// The same for C a multiple of 256 (the model's 512): a workgroup owns 32 points of one frame, a thread four channels -- its
+// weights, bias, gate and beta in registers for all of them -- and a wave's 64 threads share the point, so y / e are SCALAR
+// loads.  The element-per-thread kernel above issues 21 load instructions per two 16-byte stores and ran at 1.7 TB/s of its
+// output (193 us per evaluation at cfg-3); this one is bound by the 2R x C write.
+__global__ __launch_bounds__(256) void cnf_in_fwd_rows_kernel(const float *__restrict__ Yp, const float *__restrict__ E,
+                                                              const float *__restrict__ W0, const float *__restrict__ b,
+                                                              const float *__restrict__ gate, const float *__restrict__ beta,
+                                                              long R, int n, int C, float *__restrict__ H, int shift, long toff)
+{
+    const int C4 = C >> 2, RL = 256 / C4;                 // C4 = 64, 128 or 256: whole waves per point
+    const int tq = threadIdx.x % C4;
+    const int rl = __builtin_amdgcn_readfirstlane(threadIdx.x / C4);
+    const long f = blockIdx.y;
+    const int c = tq * 4;
+    float w[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w[q][d] = W0[(long)(c + q) * 3 + d];
+    const f32x4 bb = ld4(b + c), g = ld4(gate + f * C + c), be = ld4(beta + f * C + c);
+    const int p_end = (blockIdx.x * 32 + 32) < n ? (blockIdx.x * 32 + 32) : n;
+    for (int pi = blockIdx.x * 32 + rl; pi < p_end; pi += RL) {
+        const long pt = f * n + pi, r = cnf_vrow(pt, shift);
+        const float *yp = Yp + pt * 3, *ep = E + pt * 3;                 // wave-uniform addresses
+        const float y0 = yp[0], y1 = yp[1], y2 = yp[2], e0 = ep[0], e1 = ep[1], e2 = ep[2];
+        f32x4 hv, ht;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float zv = (w[q][0] * y0 + w[q][1] * y1) + w[q][2] * y2;
+            const float zt = (w[q][0] * e0 + w[q][1] * e1) + w[q][2] * e2;
+            const float a = (zv + bb[q]) * g[q] + be[q];
+            hv[q] = softplus_f(a);
+            ht[q] = sigmoid_f(a) * (zt * g[q]);
+        }
+        st4(H + r * C + c, hv);
+        st4(H + (toff + r) * C + c, ht);
+    }
 }
 
 __global__ __launch_bounds__(256) void cnf_in_bwd_kernel(const float *__restrict__ Yp, const float *__restrict__ E,
@@ -148,7 +206,7 @@ __global__ __launch_bounds__(256) void cnf_in_bwd_kernel(const float *__restrict
                                                          const float *__restrict__ gate, const float *__restrict__ beta,
                                                          const float *__restrict__ dH, long R, int n, int C,
                                                          float *__restrict__ dgate, float *__restrict__ dbeta,
-                                                         float *__restrict__ dW0p, float *__restrict__ dYp)
+                                                         float *__restrict__ dW0p, float *__restrict__ dYp, int shift, long toff)
 {
     __shared__ float s_red[4][64][8];
     const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -159,7 +217,7 @@ __global__ __launch_bounds__(256) void cnf_in_bwd_kernel(const float *__restrict
     if (ok) { w0 = W0[(long)c * 3]; w1 = W0[(long)c * 3 + 1]; w2 = W0[(long)c * 3 + 2]; bb = b[c]; g = gate[f * C + c]; be = beta[f * C + c]; }
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dgate, dbeta, dW0[0..2] (value part), dW0[0..2] (tangent part)
     for (int p = sub; p < n; p += 4) {
-        const long r = f * n + p;
+        const long r = f * n + p, rv = cnf_vrow(r, shift);
         const float y0 = Yp[r * 3], y1 = Yp[r * 3 + 1], y2 = Yp[r * 3 + 2];
         const float e0 = E[r * 3], e1 = E[r * 3 + 1], e2 = E[r * 3 + 2];
         float dzv = 0.f;
@@ -167,7 +225,7 @@ __global__ __launch_bounds__(256) void cnf_in_bwd_kernel(const float *__restrict
             const float zv = (w0 * y0 + w1 * y1) + w2 * y2, zt = (w0 * e0 + w1 * e1) + w2 * e2;
             const float a = (zv + bb) * g + be, ad = zt * g;
             const float s = sigmoid_f(a);
-            const float dhv = dH[r * C + c], dht = dH[(R + r) * C + c];
+            const float dhv = dH[rv * C + c], dht = dH[(toff + rv) * C + c];
             const float da = dhv * s + dht * (s * (1.0f - s)) * ad;
             const float dad = dht * s;
             dzv = da * g;
@@ -199,26 +257,118 @@ __global__ __launch_bounds__(256) void cnf_in_bwd_kernel(const float *__restrict
     }
 }
 
+// Backward for C a multiple of 256: a workgroup = (256-channel chunk, frame, point split); a thread owns four channels (16-byte
+// reads of dH: the element-per-thread kernel above reads 256 bytes per wave and row), a wave one point at a time (y / e scalar),
+// and the channel sums behind dy are three wave reductions per FOUR channels' worth of work.  Partials per point split, summed by
+// the caller: dgate / dbeta (frames, nsplit, C), dW0 (frames * nsplit, C, 3), dy (C / 256, R, 3).
+__global__ __launch_bounds__(256) void cnf_in_bwd_rows_kernel(const float *__restrict__ Yp, const float *__restrict__ E,
+                                                              const float *__restrict__ W0, const float *__restrict__ b,
+                                                              const float *__restrict__ gate, const float *__restrict__ beta,
+                                                              const float *__restrict__ dH, long R, int n, int C, int nsplit,
+                                                              float *__restrict__ dgate, float *__restrict__ dbeta,
+                                                              float *__restrict__ dW0p, float *__restrict__ dYp, int shift, long toff)
+{
+    __shared__ float s_red[3][64][20];
+    const int lane = threadIdx.x & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x, c = chunk * 256 + lane * 4;
+    const long f = blockIdx.y;
+    const int ps = blockIdx.z, per = (n + nsplit - 1) / nsplit;
+    const int p_beg = ps * per, p_end = (p_beg + per) < n ? (p_beg + per) : n;
+    float w[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w[q][d] = W0[(long)(c + q) * 3 + d];
+    const f32x4 bb = ld4(b + c), g = ld4(gate + f * C + c), be = ld4(beta + f * C + c);
+    float acc[20];                 // [q]: dgate, [4 + q]: dbeta, [8 + 3 q + d]: dW0
+#pragma unroll
+    for (int k = 0; k < 20; ++k) acc[k] = 0.f;
+    for (int pi = p_beg + sub; pi < p_end; pi += 4) {
+        const long pt = f * n + pi, rv = cnf_vrow(pt, shift);
+        const float *yp = Yp + pt * 3, *ep = E + pt * 3;                 // wave-uniform
+        const float y0 = yp[0], y1 = yp[1], y2 = yp[2], e0 = ep[0], e1 = ep[1], e2 = ep[2];
+        const f32x4 dhv = ld4(dH + rv * C + c), dht = ld4(dH + (toff + rv) * C + c);
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float zv = (w[q][0] * y0 + w[q][1] * y1) + w[q][2] * y2, zt = (w[q][0] * e0 + w[q][1] * e1) + w[q][2] * e2;
+            const float a = (zv + bb[q]) * g[q] + be[q], ad = zt * g[q];
+            const float sg = sigmoid_f(a);
+            const float da = dhv[q] * sg + dht[q] * (sg * (1.0f - sg)) * ad;
+            const float dad = dht[q] * sg;
+            const float dzv = da * g[q], dzt = dad * g[q];
+            acc[q] += da * (zv + bb[q]) + dad * zt;
+            acc[4 + q] += da;
+            acc[8 + 3 * q] += dzv * y0 + dzt * e0;
+            acc[9 + 3 * q] += dzv * y1 + dzt * e1;
+            acc[10 + 3 * q] += dzv * y2 + dzt * e2;
+            d0 += dzv * w[q][0];
+            d1 += dzv * w[q][1];
+            d2 += dzv * w[q][2];
+        }
+        d0 = wave_sum_f(d0); d1 = wave_sum_f(d1); d2 = wave_sum_f(d2);
+        if (lane == 0) {
+            float *o = dYp + ((long)chunk * R + pt) * 3;
+            o[0] = d0; o[1] = d1; o[2] = d2;
+        }
+    }
+    if (sub > 0) {
+#pragma unroll
+        for (int k = 0; k < 20; ++k) s_red[sub - 1][lane][k] = acc[k];
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = (acc[k] + s_red[0][lane][k]) + (s_red[1][lane][k] + s_red[2][lane][k]);
+        const long fs = f * nsplit + ps;
+        st4(dgate + fs * C + c, (f32x4){acc[0], acc[1], acc[2], acc[3]});
+        st4(dbeta + fs * C + c, (f32x4){acc[4], acc[5], acc[6], acc[7]});
+        float *o = dW0p + (fs * C + c) * 3;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = acc[8 + k];
+    }
+}
+
+// channels per dy partial / point splits the backward entry uses for this C (the caller sizes dY_part, dgate, dbeta, dW0_part with them)
+extern "C" int caspr_cnf_in_bwd_chunk(int C) { return (C > 0 && C % 256 == 0) ? 256 : 64; }
+extern "C" int caspr_cnf_in_bwd_splits(int C, int n) { return (C > 0 && C % 256 == 0 && n >= 256) ? 8 : 1; }
+
 extern "C" int caspr_cnf_in_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
-                                const float *beta, long R, int n, int C, float *H, void *stream)
+                                const float *beta, long R, int n, int C, long blk, float *H, void *stream)
 {
     CASPR_REQUIRE(Y && E && W0 && b && gate && beta && H && R > 0 && n > 0 && R % n == 0 && C > 0 && C % 4 == 0, "cnf_in: bad arguments");
-    const long total = R * (C / 4);
-    cnf_in_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, R, n, C, H);
+    const int shift = cnf_blk_shift(R, blk);
+    CASPR_REQUIRE(shift >= -1, "cnf_in: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
+    const long frames = R / n;
+    if (C % 256 == 0 && C <= 1024 && frames <= 65535)
+        cnf_in_fwd_rows_kernel<<<dim3(ceil_div(n, 32), (unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, R, n, C, H,
+                                                                                                             shift, blk);
+    else {
+        const long total = R * (C / 4);
+        cnf_in_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, R, n, C, H, shift, blk);
+    }
     CASPR_CHECK_LAUNCH("cnf_in");
     return CASPR_OK;
 }
 
 extern "C" int caspr_cnf_in_bwd_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
-                                    const float *beta, const float *dH, long R, int n, int C, float *dgate, float *dbeta,
+                                    const float *beta, const float *dH, long R, int n, int C, long blk, float *dgate, float *dbeta,
                                     float *dW0_part, float *dY_part, void *stream)
 {
     CASPR_REQUIRE(Y && E && W0 && b && gate && beta && dH && dgate && dbeta && dW0_part && dY_part && R > 0 && n > 0 && R % n == 0 && C > 0,
                   "cnf_in_bwd: bad arguments");
+    const int shift = cnf_blk_shift(R, blk);
+    CASPR_REQUIRE(shift >= -1, "cnf_in_bwd: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
     const long frames = R / n;
     CASPR_REQUIRE(frames <= 65535, "cnf_in_bwd: %ld frames > 65535", frames);
-    cnf_in_bwd_kernel<<<dim3(ceil_div(C, 64), (unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, dH, R, n, C,
-                                                                                                      dgate, dbeta, dW0_part, dY_part);
+    if (caspr_cnf_in_bwd_chunk(C) == 256) {
+        const int ns = caspr_cnf_in_bwd_splits(C, n);
+        cnf_in_bwd_rows_kernel<<<dim3(C / 256, (unsigned)frames, ns), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, dH, R, n, C, ns,
+                                                                                                         dgate, dbeta, dW0_part, dY_part, shift, blk);
+    } else
+        cnf_in_bwd_kernel<<<dim3(ceil_div(C, 64), (unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(Y, E, W0, b, gate, beta, dH, R, n, C,
+                                                                                                          dgate, dbeta, dW0_part, dY_part, shift, blk);
     CASPR_CHECK_LAUNCH("cnf_in_bwd");
     return CASPR_OK;
 }

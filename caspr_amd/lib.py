@@ -81,10 +81,12 @@ SIGNATURES = {
     "caspr_segment_sum_f32": (c_int, [c_fp, c_int, c_int, c_ip, c_ip, c_fp, c_long, c_int, c_fp, c_int, c_int, c_stream]),
     "caspr_gn_rows_f32": (c_int, [c_fp, c_int, c_long, c_int, c_int, c_fp, c_fp, c_float, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_ip,
                                   c_stream]),
-    "caspr_cnf_act_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_fp, c_int, c_stream]),
-    "caspr_cnf_act_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_long, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_stream]),
-    "caspr_cnf_in_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_fp, c_stream]),
-    "caspr_cnf_in_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_stream]),
+    "caspr_cnf_act_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_long, c_fp, c_int, c_stream]),
+    "caspr_cnf_act_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_long, c_int, c_int, c_long, c_fp, c_int, c_fp, c_fp, c_stream]),
+    "caspr_cnf_in_bwd_chunk": (c_int, [c_int]),
+    "caspr_cnf_in_bwd_splits": (c_int, [c_int, c_int]),
+    "caspr_cnf_in_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_long, c_fp, c_stream]),
+    "caspr_cnf_in_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_long, c_fp, c_fp, c_fp, c_fp, c_stream]),
     "caspr_gn_rows_bwd_ws_bytes": (c_long, [c_int]),
     "caspr_gn_rows_bwd_f32": (c_int, [c_fp, c_int, c_long, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_ip,
                                       c_fp, c_int, c_fp, c_fp, c_int, ctypes.c_void_p, c_long, c_stream]),

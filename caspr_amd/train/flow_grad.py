@@ -92,7 +92,7 @@ class CnfAct(torch.autograd.Function):
     z (2R,C) = layer product, b (C), gate / beta (frames, C), n points per frame -> h (2R,C)."""
 
     @staticmethod
-    def forward(ctx, z, b, gate, beta, n):
+    def forward(ctx, z, b, gate, beta, n, blk):
         from .. import lib as _lib
         from ..ops import _p, _stream
         R2, C = z.shape
@@ -101,9 +101,9 @@ class CnfAct(torch.autograd.Function):
             raise ValueError("CnfAct: z must be a GPU (2R,C) tensor with unit column stride")
         b, gate, beta = b.detach().contiguous(), gate.detach().contiguous(), beta.detach().contiguous()
         h = torch.empty(R2, C, device=z.device, dtype=torch.float32)
-        _lib.check(_lib.load().caspr_cnf_act_f32(_p(z), z.stride(0), _p(b), _p(gate), _p(beta), R, n, C, _p(h), C, _stream()), "caspr_cnf_act_f32")
+        _lib.check(_lib.load().caspr_cnf_act_f32(_p(z), z.stride(0), _p(b), _p(gate), _p(beta), R, n, C, blk, _p(h), C, _stream()), "caspr_cnf_act_f32")
         ctx.save_for_backward(z, b, gate, beta)
-        ctx.n = n
+        ctx.n, ctx.blk = n, blk
         return h
 
     @staticmethod
@@ -117,10 +117,10 @@ class CnfAct(torch.autograd.Function):
         dz = torch.empty(R2, C, device=z.device, dtype=torch.float32)
         dgate = torch.empty_like(gate)
         dbeta = torch.empty_like(beta)
-        _lib.check(_lib.load().caspr_cnf_act_bwd_f32(_p(z), z.stride(0), _p(b), _p(gate), _p(beta), _p(dh), C, R, ctx.n, C, _p(dz), C,
+        _lib.check(_lib.load().caspr_cnf_act_bwd_f32(_p(z), z.stride(0), _p(b), _p(gate), _p(beta), _p(dh), C, R, ctx.n, C, ctx.blk, _p(dz), C,
                                                      _p(dgate), _p(dbeta), _stream()), "caspr_cnf_act_bwd_f32")
         db = (gate * dbeta).sum(dim=0)                                    # d/db = sum_r da*g = sum_f g[f]*dbeta[f]
-        return dz, db, dgate, dbeta, None
+        return dz, db, dgate, dbeta, None, None
 
 
 class CnfIn(torch.autograd.Function):
@@ -128,7 +128,7 @@ class CnfIn(torch.autograd.Function):
     (caspr_cnf_in_f32 / caspr_cnf_in_bwd_f32).  y, e (R,3); w0 (C,3); b0 (C); gate / beta (frames, C) -> h (2R, C)."""
 
     @staticmethod
-    def forward(ctx, y, e, w0, b0, gate, beta, n):
+    def forward(ctx, y, e, w0, b0, gate, beta, n, blk):
         from .. import lib as _lib
         from ..ops import _p, _stream
         if not y.is_cuda:
@@ -137,9 +137,9 @@ class CnfIn(torch.autograd.Function):
         y, e = y.detach().contiguous(), e.detach().contiguous()
         w0, b0, gate, beta = w0.detach().contiguous(), b0.detach().contiguous(), gate.detach().contiguous(), beta.detach().contiguous()
         h = torch.empty(2 * R, C, device=y.device, dtype=torch.float32)
-        _lib.check(_lib.load().caspr_cnf_in_f32(_p(y), _p(e), _p(w0), _p(b0), _p(gate), _p(beta), R, n, C, _p(h), _stream()), "caspr_cnf_in_f32")
+        _lib.check(_lib.load().caspr_cnf_in_f32(_p(y), _p(e), _p(w0), _p(b0), _p(gate), _p(beta), R, n, C, blk, _p(h), _stream()), "caspr_cnf_in_f32")
         ctx.save_for_backward(y, e, w0, b0, gate, beta)
-        ctx.n = n
+        ctx.n, ctx.blk = n, blk
         return h
 
     @staticmethod
@@ -148,14 +148,21 @@ class CnfIn(torch.autograd.Function):
         from ..ops import _p, _stream
         y, e, w0, b0, gate, beta = ctx.saved_tensors
         R, C = y.shape[0], w0.shape[0]
-        frames, chunks = R // ctx.n, (C + 63) // 64
+        L = _lib.load()
+        ch, ns = L.caspr_cnf_in_bwd_chunk(C), L.caspr_cnf_in_bwd_splits(C, ctx.n)
+        frames, chunks = R // ctx.n, (C + ch - 1) // ch
         dh = dh.contiguous()
-        dgate, dbeta = torch.empty_like(gate), torch.empty_like(beta)
-        dw_part = torch.empty(frames, C, 3, device=y.device, dtype=torch.float32)
+        dgate = torch.empty(frames, ns, C, device=y.device, dtype=torch.float32)
+        dbeta = torch.empty(frames, ns, C, device=y.device, dtype=torch.float32)
+        dw_part = torch.empty(frames * ns, C, 3, device=y.device, dtype=torch.float32)
         dy_part = torch.empty(chunks, R, 3, device=y.device, dtype=torch.float32)
-        _lib.check(_lib.load().caspr_cnf_in_bwd_f32(_p(y), _p(e), _p(w0), _p(b0), _p(gate), _p(beta), _p(dh), R, ctx.n, C, _p(dgate), _p(dbeta),
-                                                    _p(dw_part), _p(dy_part), _stream()), "caspr_cnf_in_bwd_f32")
-        return dy_part.sum(dim=0), None, dw_part.sum(dim=0), (gate * dbeta).sum(dim=0), dgate, dbeta, None
+        _lib.check(L.caspr_cnf_in_bwd_f32(_p(y), _p(e), _p(w0), _p(b0), _p(gate), _p(beta), _p(dh), R, ctx.n, C, ctx.blk, _p(dgate), _p(dbeta),
+                                          _p(dw_part), _p(dy_part), _stream()), "caspr_cnf_in_bwd_f32")
+        if ns > 1:
+            dgate, dbeta = dgate.sum(dim=1), dbeta.sum(dim=1)
+        else:
+            dgate, dbeta = dgate[:, 0], dbeta[:, 0]
+        return dy_part.sum(dim=0), None, dw_part.sum(dim=0), (gate * dbeta).sum(dim=0), dgate, dbeta, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -213,6 +220,7 @@ def cnf_block_train(block, x, context, logpx, e):
     for w_ in widths:
         offs.append(offs[-1] + w_)
     e_rows = e.reshape(BT * n, 3)
+    blk = BT * n            # row layout of the (2R, C) tensors of this solve (include/caspr_hip_train.h): [values | tangents]
 
     def func(t, y, _lp):
         R = BT * n
@@ -222,15 +230,16 @@ def cnf_block_train(block, x, context, logpx, e):
         for i, l in enumerate(layers):
             gate, bias = gate_all[:, offs[i]:offs[i + 1]], bias_all[:, offs[i]:offs[i + 1]]
             if i == 0:                                                    # 3 -> C: fused product + gate + softplus, value | tangent rows
-                h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n)
+                h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n, blk)
                 continue
             z = linear_rows(h, l._layer.weight, None)
             if i < 3:
-                h = CnfAct.apply(z, l._layer.bias, gate, bias, n)         # fused gate + softplus on value / tangent rows
+                h = CnfAct.apply(z, l._layer.bias, gate, bias, n, blk)    # fused gate + softplus on value / tangent rows
             else:                                                         # 512 -> 3 output layer: (BT,n,3) tensors
                 cout = l._layer.weight.shape[0]
-                a = (z[:R].reshape(BT, n, cout) + l._layer.bias) * gate.unsqueeze(1) + bias.unsqueeze(1)
-                ad = z[R:].reshape(BT, n, cout) * gate.unsqueeze(1)
+                zz = z.view(R // blk, 2, blk, cout)                       # row layout: blocks of blk value rows | their tangent rows
+                a = (zz[:, 0].reshape(BT, n, cout) + l._layer.bias) * gate.unsqueeze(1) + bias.unsqueeze(1)
+                ad = zz[:, 1].reshape(BT, n, cout) * gate.unsqueeze(1)
         div = (ad * e).sum(dim=-1, keepdim=True)
         return a, -div
 

@@ -110,24 +110,30 @@ int caspr_gn_rows_bwd_f32(const float *Y, int ldy, long NB, int ns, int C, const
                           long ws_bytes, void *stream);
 
 /* Gated softplus layer of the CNF's ODE function (ConcatSquashLinear + Softplus, diffeq_layers.py:83-90,
- * odefunc.py:98-105) on value rows [0,R) and tangent rows [R,2R) of Z (2R, ldz) = the layer's matrix
- * product; frame f = r / n has its own gate / beta rows (hyper networks of the context).
- *   H[r] = softplus((Z[r]+b)*gate[f]+beta[f])     H[R+r] = sigmoid(same) * Z[R+r]*gate[f]
+ * odefunc.py:98-105) on value and tangent rows of Z (2R, ldz) = the layer's matrix product; frame f = p / n has its
+ * own gate / beta rows (hyper networks of the context).  Row layout: blk = R puts the value of point p in row p and its
+ * tangent (Hutchinson, odefunc.py:13-31) in row R + p; blk = a power of two dividing R (32: what the fused conv epilogue of
+ * caspr_conv1x1_cnf_act_bf16x6_f32 needs) interleaves blocks of blk value rows and the blk tangent rows of the same points:
+ * value row = (p / blk) 2 blk + p % blk, tangent row = value row + blk.
+ *   H[v(p)] = softplus((Z[v(p)]+b)*gate[f]+beta[f])     H[t(p)] = sigmoid(same) * Z[t(p)]*gate[f]
  * Backward: dZ (2R, lddz), dgate / dbeta (R/n, C) summed over each frame's points in a fixed order.   */
 int caspr_cnf_act_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
-                      long R, int n, int C, float *H, int ldh, void *stream);
+                      long R, int n, int C, long blk, float *H, int ldh, void *stream);
 int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
-                          const float *dH, int ldd, long R, int n, int C, float *dZ, int lddz,
+                          const float *dH, int ldd, long R, int n, int C, long blk, float *dZ, int lddz,
                           float *dgate, float *dbeta, void *stream);
 
 /* First layer of the ODE function (3 -> C) fused with its gate + softplus on value (y) and tangent (e) rows:
- * H (2R, C) as caspr_cnf_act_f32 with Z = [W0 y ; W0 e].  Y, E (R,3); W0 (C,3).  Backward: dgate / dbeta
- * (R/n, C); dW0_part (R/n, C, 3) = per-frame partial sums (sum over frames = dW0; db0 = sum_f gate*dbeta);
- * dY_part (ceil(C/64), R, 3) = per-64-channel partial sums of dL/dy.  All sums in a fixed order.      */
+ * H (2R, C) as caspr_cnf_act_f32 with Z = [W0 y ; W0 e] in the row layout `blk`.  Y, E (R,3) point-indexed; W0 (C,3).
+ * Backward, with ch = caspr_cnf_in_bwd_chunk(C) and ns = caspr_cnf_in_bwd_splits(C, n): dgate / dbeta (R/n, ns, C) and
+ * dW0_part (R/n * ns, C, 3) = partial sums per frame and point split (sum over frames and splits = dW0; db0 = sum_f
+ * gate*dbeta); dY_part (ceil(C/ch), R, 3) = per-chunk partial sums of dL/dy.  All sums in a fixed order.      */
+int caspr_cnf_in_bwd_chunk(int C);
+int caspr_cnf_in_bwd_splits(int C, int n);
 int caspr_cnf_in_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
-                     const float *beta, long R, int n, int C, float *H, void *stream);
+                     const float *beta, long R, int n, int C, long blk, float *H, void *stream);
 int caspr_cnf_in_bwd_f32(const float *Y, const float *E, const float *W0, const float *b, const float *gate,
-                         const float *beta, const float *dH, long R, int n, int C, float *dgate,
+                         const float *beta, const float *dH, long R, int n, int C, long blk, float *dgate,
                          float *dbeta, float *dW0_part, float *dY_part, void *stream);
 
 #ifdef __cplusplus
