@@ -104,13 +104,24 @@ __global__ void pack_weight_bf16x3_kernel(const float *__restrict__ w, int ldw, 
 // (f32; one float4 per (batch entry, point tile, channel) in `part`), conv_gn_finalize_kernel combines them pairwise in f64 in
 // a fixed order.  Y may then be NULL (only the statistics are wanted:
 // the global PointNet's last layer, whose output is max-pooled).
+// act mode 2 (training tier, caspr_conv1x1_cnf_act_bf16x6_f32): the gated softplus layer of the CNF's ODE function applied to value /
+// tangent row pairs in the epilogue.  Rows come in blocks of 64 = 32 value rows + the tangent rows of the same 32 points
+// (backward_flow.hip, blk = 32): a lane's column tiles 0, 1 are values, 2, 3 their tangents.  The raw product is stored too (the
+// backward pass recomputes the activation from it).
+struct X6Act {
+    const float *gate;   // (batch entries, cstride); the per-entry bias `bbias` is beta, `bias` the layer bias
+    float *z;            // raw product (rows as Y)
+    int ldz;
+};
+
 template <bool FUSED, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned char *__restrict__ wpk, const float *__restrict__ bias,
                                                                 const float *__restrict__ bbias, const float *__restrict__ X,
                                                                 int ldx, const float *__restrict__ in_scale,
                                                                 const float *__restrict__ in_shift, int in_relu, int relu_from,
                                                                 float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int act,
-                                                                int Mt, int Pt, f32x4 *__restrict__ part, int cstride, unsigned long long *trace)
+                                                                int Mt, int Pt, f32x4 *__restrict__ part, int cstride, unsigned long long *trace,
+                                                                X6Act ax)
 {
     // debug build (tools/conv_x6_trace.py): s_memtime stamps of workgroup 0, thread 0, five per K chunk
 #ifdef CASPR_DEBUG_HOOKS
@@ -282,6 +293,33 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     for (int mi = 0; mi < 8; ++mi) {
         const int co = co_w + mi * 16 + 4 * g;
         if (co >= Cout) continue;
+        if constexpr (!STATS) {
+            if ((act & 0xff) == 2) {
+                const f32x4 b4 = ld4(bias + co), g4 = ld4(ax.gate + (long)b * cstride + co), be4 = ld4(bb + co);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const long rv = (long)b * P + p0 + wn * 64 + ni * 16 + j, rt = rv + 32;
+                    const f32x4 zv = acc[mi][ni], zt = acc[mi][ni + 2];
+                    st4(ax.z + rv * ax.ldz + co, zv);
+                    st4(ax.z + rt * ax.ldz + co, zt);
+                    f32x4 hv, ht;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // softplus and sigmoid from ONE 2^(-|a| log2 e) on the hardware transcendentals (1 ulp each, as the sampling
+                        // kernel's softplus_fast): the libm forms of the stand-alone pass (~90 instructions per element, hidden there
+                        // behind its memory traffic) made this epilogue half as long as the tile's product loop
+                        const float a_ = (zv[r] + b4[r]) * g4[r] + be4[r];
+                        const float u = __builtin_amdgcn_exp2f(fabsf(a_) * -1.44269504088896341f);
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + u);
+                        hv[r] = fmaxf(a_, 0.0f) + 0.69314718055994531f * __builtin_amdgcn_logf(1.0f + u);
+                        ht[r] = (a_ >= 0.0f ? rc : u * rc) * (zt[r] * g4[r]);
+                    }
+                    st4(Y + rv * ldy + co, hv);
+                    st4(Y + rt * ldy + co, ht);
+                }
+                continue;
+            }
+        }
         f32x4 add = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (bias) add += ld4(bias + co);
         if (bb) add += ld4(bb + co);
@@ -433,7 +471,7 @@ extern "C" void caspr_debug_set_conv_x6_trace(unsigned long long *dev_buf) { g_c
 
 static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx, const float *in_scale,
                           const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout,
-                          int act, f32x4 *part, void *stream, int cstride = 0)
+                          int act, f32x4 *part, void *stream, int cstride = 0, X6Act ax = X6Act{nullptr, nullptr, 0})
 {
     if (cstride == 0) cstride = Cout;
     CASPR_REQUIRE(wpk && X && (Y || part) && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1_bf16x6: bad arguments");
@@ -462,7 +500,7 @@ static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias
     }
 #define X6_LAUNCH(F, S)                                                                                                          \
     conv1x1_bf16x6_kernel<F, S><<<dim3((unsigned)nblk), dim3(256), X6_LDS, (hipStream_t)stream>>>(                                \
-        (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt, part, cstride, trace)
+        (const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, P, Cin, Cout, act, Mt, Pt, part, cstride, trace, ax)
     if (which == 0) X6_LAUNCH(false, false);
     else if (which == 1) X6_LAUNCH(true, false);
     else if (which == 2) X6_LAUNCH(false, true);
@@ -470,6 +508,16 @@ static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias
 #undef X6_LAUNCH
     CASPR_CHECK_LAUNCH("conv1x1_bf16x6");
     return CASPR_OK;
+}
+
+extern "C" int caspr_conv1x1_cnf_act_bf16x6_f32(const void *wpk, const float *b, const float *gate, const float *beta, const float *X, int ldx,
+                                                float *Z, int ldz, float *H, int ldh, int frames, int n, int Cin, int Cout, void *stream)
+{
+    CASPR_REQUIRE(b && gate && beta && Z && H && frames > 0 && n > 0 && n % 64 == 0, "conv1x1_cnf_act: bad arguments (n=%d must be a multiple of 64)", n);
+    CASPR_REQUIRE(ldz % 4 == 0 && ldz >= Cout && ((uintptr_t)Z % 16) == 0 && ((uintptr_t)gate % 16) == 0 && ((uintptr_t)beta % 16) == 0 &&
+                      ((uintptr_t)b % 16) == 0,
+                  "conv1x1_cnf_act: Z / gate / beta / b must be 16-byte aligned, ldz a multiple of 4 and >= Cout");
+    return conv_x6_launch(wpk, b, beta, X, ldx, nullptr, nullptr, 0, 0, H, ldh, frames, 2 * n, Cin, Cout, 2, nullptr, stream, 0, X6Act{gate, Z, ldz});
 }
 
 extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,

@@ -123,6 +123,53 @@ class CnfAct(torch.autograd.Function):
         return dz, db, dgate, dbeta, None, None
 
 
+class CnfLayer(torch.autograd.Function):
+    """A hidden layer of the ODE function in ONE launch: z = x W^T on the bf16x6 conv kernel with the gated softplus of CnfAct in
+    its epilogue (caspr_conv1x1_cnf_act_bf16x6_f32; row layout blk = 32).  x (2R, Cin), W (Cout, Cin), b (Cout), gate / beta
+    (frames, Cout) -> h (2R, Cout).  Same values as linear_rows + CnfAct, one pass less over the (2R, Cout) product."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gate, beta, n):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        cout, cin = w.shape
+        R2 = x.shape[0]
+        xp = x.contiguous()
+        b, gate, beta = b.detach().contiguous(), gate.detach().contiguous(), beta.detach().contiguous()
+        z = torch.empty(R2, cout, device=x.device, dtype=torch.float32)
+        h = torch.empty(R2, cout, device=x.device, dtype=torch.float32)
+        pw = _packed(w, False)
+        with ops.timed("k:conv1x1_bf16x6:%d:%d:%d" % (cin, cout, R2), 2):
+            _lib.check(_lib.load().caspr_conv1x1_cnf_act_bf16x6_f32(_p(pw.x3()), _p(b), _p(gate), _p(beta), _p(xp), xp.stride(0), _p(z), cout, _p(h), cout,
+                                                                    R2 // (2 * n), n, cin, cout, _stream()), "caspr_conv1x1_cnf_act_bf16x6_f32")
+        ctx.save_for_backward(xp, w, z, b, gate, beta)
+        ctx.n = n
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        xp, w, z, b, gate, beta = ctx.saved_tensors
+        cout, cin = w.shape
+        R2 = xp.shape[0]
+        dh = dh.contiguous()
+        dz = torch.empty(R2, cout, device=z.device, dtype=torch.float32)
+        dgate, dbeta = torch.empty_like(gate), torch.empty_like(beta)
+        _lib.check(_lib.load().caspr_cnf_act_bwd_f32(_p(z), cout, _p(b), _p(gate), _p(beta), _p(dh), cout, R2 // 2, ctx.n, cout, 32, _p(dz), cout,
+                                                     _p(dgate), _p(dbeta), _stream()), "caspr_cnf_act_bwd_f32")
+        dzv = dz.view(1, R2, cout)
+        dx = ops.conv1x1(_packed(w, True), None, dzv).view(R2, -1) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(cout, cin, device=xp.device, dtype=torch.float32)
+        T.conv1x1_wgrad(dzv, xp.view(1, R2, cin), cin, cout, dw, None)
+        return dx, dw, (gate * dbeta).sum(dim=0), dgate, dbeta, None
+
+
+def _fused_layer_ok(l, n):
+    cout, cin = l._layer.weight.shape
+    return ops.CONV_BF16X6 and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and cout >= 128 and n % 64 == 0
+
+
 class CnfIn(torch.autograd.Function):
     """First ODE-function layer (3 -> C) fused with gate + softplus on value / tangent rows
     (caspr_cnf_in_f32 / caspr_cnf_in_bwd_f32).  y, e (R,3); w0 (C,3); b0 (C); gate / beta (frames, C) -> h (2R, C)."""
@@ -220,7 +267,10 @@ def cnf_block_train(block, x, context, logpx, e):
     for w_ in widths:
         offs.append(offs[-1] + w_)
     e_rows = e.reshape(BT * n, 3)
-    blk = BT * n            # row layout of the (2R, C) tensors of this solve (include/caspr_hip_train.h): [values | tangents]
+    # row layout of the (2R, C) tensors of this solve (include/caspr_hip_train.h): blocks of 32 value rows + the tangent rows of the
+    # same points when the hidden layers run with the activation in the conv's epilogue (CnfLayer), [values | tangents] otherwise
+    fused = all(_fused_layer_ok(l, n) for l in layers[1:3])
+    blk = 32 if fused else BT * n
 
     def func(t, y, _lp):
         R = BT * n
@@ -231,6 +281,9 @@ def cnf_block_train(block, x, context, logpx, e):
             gate, bias = gate_all[:, offs[i]:offs[i + 1]], bias_all[:, offs[i]:offs[i + 1]]
             if i == 0:                                                    # 3 -> C: fused product + gate + softplus, value | tangent rows
                 h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n, blk)
+                continue
+            if i < 3 and fused:
+                h = CnfLayer.apply(h, l._layer.weight, l._layer.bias, gate, bias, n)   # product + gate + softplus in one launch
                 continue
             z = linear_rows(h, l._layer.weight, None)
             if i < 3:

@@ -123,6 +123,15 @@ int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, const float *
                           const float *dH, int ldd, long R, int n, int C, long blk, float *dZ, int lddz,
                           float *dgate, float *dbeta, void *stream);
 
+/* A hidden layer of the ODE function in one launch (diffeq_layers.py:83-90 + odefunc.py:98-105 on value and tangent rows):
+ * Z = X W^T on the bf16x6 conv kernel (wpk: caspr_pack_weight_bf16x3 of W (Cout, Cin)), H = the gated softplus of
+ * caspr_cnf_act_f32 applied in the conv's epilogue.  X (2 frames n, ldx), Z, H in the row layout blk = 32; n % 64 == 0,
+ * Cin % 32 == 0, Cout % 4 == 0.  Same values as caspr_conv1x1_bf16x6_f32 followed by caspr_cnf_act_f32 (one pass less
+ * over Z).  Backward: caspr_cnf_act_bwd_f32 on (Z, dH), then the data / weight gradient convs as for any layer.          */
+int caspr_conv1x1_cnf_act_bf16x6_f32(const void *wpk, const float *b, const float *gate, const float *beta,
+                                     const float *X, int ldx, float *Z, int ldz, float *H, int ldh, int frames,
+                                     int n, int Cin, int Cout, void *stream);
+
 /* First layer of the ODE function (3 -> C) fused with its gate + softplus on value (y) and tangent (e) rows:
  * H (2R, C) as caspr_cnf_act_f32 with Z = [W0 y ; W0 e] in the row layout `blk`.  Y, E (R,3) point-indexed; W0 (C,3).
  * Backward, with ch = caspr_cnf_in_bwd_chunk(C) and ns = caspr_cnf_in_bwd_splits(C, n): dgate / dbeta (R/n, ns, C) and
