@@ -432,8 +432,7 @@ static int wgrad_impl(bool bf16x6, const float *dY, int lddy, const float *X, in
                   "conv1x1_wgrad: in_scale/in_shift must be given together and need Cin %% 4 == 0");
     const long R = (long)B * P;
     CASPR_REQUIRE(ws_bytes >= caspr_wgrad_ws_bytes(R, Cin, Cout), "conv1x1_wgrad: workspace too small");
-    const int S = pick_slabs(R, Cin, Cout);
-    const long rps = ((R + S - 1) / S + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+    int S = pick_slabs(R, Cin, Cout);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)ws;
     // bf16x6: the 256 x 256 tile where both widths fill it reasonably (padded area at most 20 % above the 128-tile's), else 128 x 128
@@ -446,7 +445,15 @@ static int wgrad_impl(bool bf16x6, const float *dY, int lddy, const float *X, in
         if (force == 128) kind = 1;
         if (force == 256) kind = 2;
         T = kind == 2 ? 256 : 128;
+        if (kind == 2) {
+            // one 512-thread workgroup per CU: ONE round of workgroups (tiles x slabs just under 256) instead of the 128-tile's
+            // 2048 -- half the partial sums to write and to reduce (64 instead of 128 slabs of 1 MB on the CNF's 512 x 512 layers)
+            const long t256 = (long)ceil_div(Cout, 256) * ceil_div(Cin, 256);
+            long s1 = t256 >= 256 ? 1 : 256 / t256;
+            if (s1 < S) S = (int)s1;
+        }
     }
+    const long rps = ((R + S - 1) / S + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
     wgrad_launch(kind, dim3(ceil_div(Cout, T), ceil_div(Cin, T), S), st, dY, lddy, X, ldx, in_scale, in_shift, in_relu, in_relu_from, R, P, Cin,
                  Cout, rps, part, dbias ? part + (long)S * ((long)Cout * Cin) : nullptr);
     const long n = (long)Cout * Cin;
