@@ -50,23 +50,38 @@ __global__ __launch_bounds__(256) void cnf_act_fwd_kernel(const float *__restric
     st4(H + (toff + r) * ldh + c, ht);
 }
 
+// dH == NULL: the layer feeds the 3-channel output layer directly (odefunc.py:103, no activation behind it) and its dH is that
+// layer's data gradient dH[r][c] = sum_j dZo[r][j] Wo[j][c] -- three FMAs per element, formed here instead of being written by a
+// K = 3 conv (335 MB per evaluation at cfg-3) and read back.
 __global__ __launch_bounds__(256) void cnf_act_bwd_kernel(const float *__restrict__ Z, int ldz, const float *__restrict__ b,
                                                           const float *__restrict__ gate, const float *__restrict__ beta,
                                                           const float *__restrict__ dH, int ldd, long R, int n, int C,
                                                           float *__restrict__ dZ, int lddz, float *__restrict__ dgate,
-                                                          float *__restrict__ dbeta, int shift, long toff)
+                                                          float *__restrict__ dbeta, int shift, long toff,
+                                                          const float *__restrict__ dZo, int ldo, const float *__restrict__ Wo, int ldw)
 {
     __shared__ float s_g[4][64], s_b[4][64];
-    const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + cl;
     const long f = blockIdx.y;
     float acc_g = 0.f, acc_b = 0.f;
     if (c < C) {
         const float bb = b[c], g = gate[f * C + c], be = beta[f * C + c];
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        if (!dH) { w0 = Wo[c]; w1 = Wo[ldw + c]; w2 = Wo[2 * ldw + c]; }
         for (int p = sub; p < n; p += 4) {
             const long r = cnf_vrow(f * n + p, shift);
             const float zv = Z[r * ldz + c], zt = Z[(toff + r) * ldz + c];
-            const float dhv = dH[r * ldd + c], dht = dH[(toff + r) * ldd + c];
+            float dhv, dht;
+            if (dH) {
+                dhv = dH[r * ldd + c];
+                dht = dH[(toff + r) * ldd + c];
+            } else {
+                const float *ov = dZo + r * ldo, *ot = dZo + (toff + r) * ldo;      // wave-uniform rows
+                dhv = (ov[0] * w0 + ov[1] * w1) + ov[2] * w2;
+                dht = (ot[0] * w0 + ot[1] * w1) + ot[2] * w2;
+            }
             const float a = (zv + bb) * g + be, ad = zt * g;
             const float s = sigmoid_f(a);
             const float da = dhv * s + dht * (s * (1.0f - s)) * ad;
@@ -100,21 +115,38 @@ extern "C" int caspr_cnf_act_f32(const float *Z, int ldz, const float *b, const 
     return CASPR_OK;
 }
 
+static int cnf_act_bwd_launch(const float *Z, int ldz, const float *b, const float *gate, const float *beta, const float *dH, int ldd,
+                              const float *dZo, int ldo, const float *Wo, int ldw, long R, int n, int C, long blk, float *dZ, int lddz,
+                              float *dgate, float *dbeta, void *stream)
+{
+    CASPR_REQUIRE(Z && b && gate && beta && (dH || (dZo && Wo)) && dZ && dgate && dbeta && R > 0 && n > 0 && R % n == 0 && C > 0 && ldz >= C &&
+                      (!dH || ldd >= C) && lddz >= C,
+                  "cnf_act_bwd: bad arguments");
+    const int shift = cnf_blk_shift(R, blk);
+    CASPR_REQUIRE(shift >= -1, "cnf_act_bwd: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
+    const long frames = R / n;
+    CASPR_REQUIRE(frames <= 65535, "cnf_act_bwd: %ld frames > 65535", frames);
+    cnf_act_bwd_kernel<<<dim3(ceil_div(C, 64), (unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(Z, ldz, b, gate, beta, dH, ldd, R, n, C, dZ,
+                                                                                                       lddz, dgate, dbeta, shift, blk, dZo, ldo, Wo, ldw);
+    CASPR_CHECK_LAUNCH("cnf_act_bwd");
+    return CASPR_OK;
+}
+
 extern "C" int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
                                      const float *dH, int ldd, long R, int n, int C, long blk, float *dZ, int lddz, float *dgate,
                                      float *dbeta, void *stream)
 {
-    const int shift = cnf_blk_shift(R, blk);
-    CASPR_REQUIRE(shift >= -1, "cnf_act_bwd: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
-    CASPR_REQUIRE(Z && b && gate && beta && dH && dZ && dgate && dbeta && R > 0 && n > 0 && R % n == 0 && C > 0 && ldz >= C && ldd >= C &&
-                      lddz >= C,
-                  "cnf_act_bwd: bad arguments");
-    const long frames = R / n;
-    CASPR_REQUIRE(frames <= 65535, "cnf_act_bwd: %ld frames > 65535", frames);
-    cnf_act_bwd_kernel<<<dim3(ceil_div(C, 64), (unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(Z, ldz, b, gate, beta, dH, ldd, R, n,
-                                                                                                       C, dZ, lddz, dgate, dbeta, shift, blk);
-    CASPR_CHECK_LAUNCH("cnf_act_bwd");
-    return CASPR_OK;
+    CASPR_REQUIRE(dH, "cnf_act_bwd: dH is NULL");
+    return cnf_act_bwd_launch(Z, ldz, b, gate, beta, dH, ldd, nullptr, 0, nullptr, 0, R, n, C, blk, dZ, lddz, dgate, dbeta, stream);
+}
+
+// the same for the layer in front of the 3-channel output layer: dH = dZo Wo formed on the fly (dZo (2R, ldo >= 3), Wo (3, ldw >= C))
+extern "C" int caspr_cnf_act_bwd_out_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
+                                         const float *dZo, int ldo, const float *Wo, int ldw, long R, int n, int C, long blk, float *dZ,
+                                         int lddz, float *dgate, float *dbeta, void *stream)
+{
+    CASPR_REQUIRE(dZo && Wo && ldo >= 3 && ldw >= C, "cnf_act_bwd_out: bad arguments");
+    return cnf_act_bwd_launch(Z, ldz, b, gate, beta, nullptr, 0, dZo, ldo, Wo, ldw, R, n, C, blk, dZ, lddz, dgate, dbeta, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

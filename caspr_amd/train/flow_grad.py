@@ -165,6 +165,52 @@ class CnfLayer(torch.autograd.Function):
         return dx, dw, (gate * dbeta).sum(dim=0), dgate, dbeta, None
 
 
+class CnfLayerOut(torch.autograd.Function):
+    """The last hidden layer AND the 3-channel output product behind it (odefunc.py:103: no activation there): h = CnfLayer(x),
+    zo = h Wo^T.  Backward: the output layer's data gradient dzo Wo is formed inside the activation's backward kernel
+    (caspr_cnf_act_bwd_out_f32) instead of being written by a K = 3 conv and read back.
+    x (2R, Cin), w (C, Cin), b (C), gate / beta (frames, C), wo (3, C) -> zo (2R, 3)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gate, beta, wo, n):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        cout, cin = w.shape
+        R2 = x.shape[0]
+        xp = x.contiguous()
+        b, gate, beta = b.detach().contiguous(), gate.detach().contiguous(), beta.detach().contiguous()
+        z = torch.empty(R2, cout, device=x.device, dtype=torch.float32)
+        h = torch.empty(R2, cout, device=x.device, dtype=torch.float32)
+        with ops.timed("k:conv1x1_bf16x6:%d:%d:%d" % (cin, cout, R2), 2):
+            _lib.check(_lib.load().caspr_conv1x1_cnf_act_bf16x6_f32(_p(_packed(w, False).x3()), _p(b), _p(gate), _p(beta), _p(xp), xp.stride(0), _p(z), cout,
+                                                                    _p(h), cout, R2 // (2 * n), n, cin, cout, _stream()), "caspr_conv1x1_cnf_act_bf16x6_f32")
+        zo = ops.conv1x1(_packed(wo, False), None, h.view(1, R2, cout)).view(R2, -1)
+        ctx.save_for_backward(xp, w, z, b, gate, beta, h, wo)
+        ctx.n = n
+        return zo[:, :wo.shape[0]]
+
+    @staticmethod
+    def backward(ctx, dzo):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        xp, w, z, b, gate, beta, h, wo = ctx.saved_tensors
+        cout, cin = w.shape
+        R2 = xp.shape[0]
+        dzop = _pad4(dzo)
+        dwo = torch.empty(wo.shape[0], cout, device=xp.device, dtype=torch.float32)
+        T.conv1x1_wgrad(dzop.view(1, R2, dzop.shape[1]), h.view(1, R2, cout), cout, wo.shape[0], dwo, None)
+        dz = torch.empty(R2, cout, device=z.device, dtype=torch.float32)
+        dgate, dbeta = torch.empty_like(gate), torch.empty_like(beta)
+        woc = wo.detach().contiguous()
+        _lib.check(_lib.load().caspr_cnf_act_bwd_out_f32(_p(z), cout, _p(b), _p(gate), _p(beta), _p(dzop), dzop.shape[1], _p(woc), cout, R2 // 2, ctx.n, cout,
+                                                         32, _p(dz), cout, _p(dgate), _p(dbeta), _stream()), "caspr_cnf_act_bwd_out_f32")
+        dzv = dz.view(1, R2, cout)
+        dx = ops.conv1x1(_packed(w, True), None, dzv).view(R2, -1) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(cout, cin, device=xp.device, dtype=torch.float32)
+        T.conv1x1_wgrad(dzv, xp.view(1, R2, cin), cin, cout, dw, None)
+        return dx, dw, (gate * dbeta).sum(dim=0), dgate, dbeta, dwo, None
+
+
 def _fused_layer_ok(l, n):
     cout, cin = l._layer.weight.shape
     return ops.CONV_BF16X6 and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and cout >= 128 and n % 64 == 0
@@ -282,10 +328,14 @@ def cnf_block_train(block, x, context, logpx, e):
             if i == 0:                                                    # 3 -> C: fused product + gate + softplus, value | tangent rows
                 h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n, blk)
                 continue
-            if i < 3 and fused:
+            if i == 1 and fused:
                 h = CnfLayer.apply(h, l._layer.weight, l._layer.bias, gate, bias, n)   # product + gate + softplus in one launch
                 continue
-            z = linear_rows(h, l._layer.weight, None)
+            if i == 2 and fused:                           # ... and the output product behind the last hidden layer
+                z = CnfLayerOut.apply(h, l._layer.weight, l._layer.bias, gate, bias, layers[3]._layer.weight, n)
+                continue
+            if not (i == 3 and fused):
+                z = linear_rows(h, l._layer.weight, None)
             if i < 3:
                 h = CnfAct.apply(z, l._layer.bias, gate, bias, n, blk)    # fused gate + softplus on value / tangent rows
             else:                                                         # 512 -> 3 output layer: (BT,n,3) tensors

@@ -122,6 +122,11 @@ int caspr_cnf_act_f32(const float *Z, int ldz, const float *b, const float *gate
 int caspr_cnf_act_bwd_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
                           const float *dH, int ldd, long R, int n, int C, long blk, float *dZ, int lddz,
                           float *dgate, float *dbeta, void *stream);
+/* ... for the hidden layer in front of the 3-channel output layer (odefunc.py:103: no activation behind it): dH is that layer's
+ * data gradient dZo Wo (dZo (2R, ldo >= 3) in the same row layout, Wo (3, ldw >= C)), formed on the fly.                  */
+int caspr_cnf_act_bwd_out_f32(const float *Z, int ldz, const float *b, const float *gate, const float *beta,
+                              const float *dZo, int ldo, const float *Wo, int ldw, long R, int n, int C, long blk,
+                              float *dZ, int lddz, float *dgate, float *dbeta, void *stream);
 
 /* A hidden layer of the ODE function in one launch (diffeq_layers.py:83-90 + odefunc.py:98-105 on value and tangent rows):
  * Z = X W^T on the bf16x6 conv kernel (wpk: caspr_pack_weight_bf16x3 of W (Cout, Cin)), H = the gated softplus of
