@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void cnf_act_bwd_kernel(const float *__restric
                 dht = (ot[0] * w0 + ot[1] * w1) + ot[2] * w2;
             }
             const float a = (zv + bb) * g + be, ad = zt * g;
-            const float s = sigmoid_f(a);
+            const float s = sigmoid_fast(a);
             const float da = dhv * s + dht * (s * (1.0f - s)) * ad;
             const float dad = dht * s;
             dZ[r * lddz + c] = da * g;
@@ -225,8 +225,12 @@ __global__ __launch_bounds__(256) void cnf_in_fwd_rows_kernel(const float *__res
             const float zv = (w[q][0] * y0 + w[q][1] * y1) + w[q][2] * y2;
             const float zt = (w[q][0] * e0 + w[q][1] * e1) + w[q][2] * e2;
             const float a = (zv + bb[q]) * g[q] + be[q];
-            hv[q] = softplus_f(a);
-            ht[q] = sigmoid_f(a) * (zt * g[q]);
+            // softplus and sigmoid from one 2^(-|a| log2 e) on the hardware transcendentals: with the libm forms (~90 instructions per
+            // element) this kernel was bound by its arithmetic, not by the 2R x C write
+            const float u = __builtin_amdgcn_exp2f(fabsf(a) * -1.44269504088896341f);
+            const float rc = __builtin_amdgcn_rcpf(1.0f + u);
+            hv[q] = fmaxf(a, 0.0f) + 0.69314718055994531f * __builtin_amdgcn_logf(1.0f + u);
+            ht[q] = (a >= 0.0f ? rc : u * rc) * (zt * g[q]);
         }
         st4(H + r * C + c, hv);
         st4(H + (toff + r) * C + c, ht);
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256) void cnf_in_bwd_rows_kernel(const float *__res
         for (int q = 0; q < 4; ++q) {
             const float zv = (w[q][0] * y0 + w[q][1] * y1) + w[q][2] * y2, zt = (w[q][0] * e0 + w[q][1] * e1) + w[q][2] * e2;
             const float a = (zv + bb[q]) * g[q] + be[q], ad = zt * g[q];
-            const float sg = sigmoid_f(a);
+            const float sg = sigmoid_fast(a);
             const float da = dhv[q] * sg + dht[q] * (sg * (1.0f - sg)) * ad;
             const float dad = dht[q] * sg;
             const float dzv = da * g[q], dzt = dad * g[q];
