@@ -388,6 +388,53 @@ static void launch_slab_reduce(const float *part, long n, int S, int accumulate,
         slab_reduce_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(part, n, S, accumulate, out);
 }
 
+// Weight gradient of a layer with up to four outputs (the CNF's 512 -> 3 output layer): dW[j][c] = sum_r dY[r][j] X[r][c] is one
+// pass over X -- a thread keeps four channels x four outputs, a wave reads whole rows (dY's row is a scalar load), the four waves
+// of a workgroup take every fourth row of the slab.  The 128 x 128 tile kernel spent a full tile of products on three live
+// rows (228 us per call at cfg-3; this one is bound by reading X).  Same slab partials, same fixed-order reduction.
+__global__ __launch_bounds__(256) void conv1x1_wgrad_skinny_kernel(const float *__restrict__ dY, int lddy, const float *__restrict__ X, int ldx,
+                                                                   long R, int Cin, int Cout, long rows_per_slab, float *__restrict__ part)
+{
+    __shared__ float s_red[3][64][16];
+    const int lane = threadIdx.x & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int slab = blockIdx.y;
+    const long r_beg = (long)slab * rows_per_slab;
+    const long r_end = (r_beg + rows_per_slab) < R ? (r_beg + rows_per_slab) : R;
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
+    const bool ok = c < Cin;             // Cin % 4 == 0
+#pragma unroll 4
+    for (long r = r_beg + sub; r < r_end; r += 4) {
+        const f32x4 d = ld4(dY + r * lddy);                                  // wave-uniform row (lddy >= 4, zero past Cout)
+        const f32x4 x = ok ? ld4(X + r * ldx + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[j][q] = fmaf(d[j], x[q], acc[j][q]);
+    }
+    if (sub > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_red[sub - 1][lane][4 * j + q] = acc[j][q];
+    }
+    __syncthreads();
+    if (sub == 0 && ok) {
+        float *pp = part + (long)slab * Cout * Cin;
+        for (int j = 0; j < Cout; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (acc[j][q] + s_red[0][lane][4 * j + q]) + (s_red[1][lane][4 * j + q] + s_red[2][lane][4 * j + q]);
+            st4(pp + (long)j * Cin + c, v);
+        }
+    }
+}
+
 // number of row slabs: enough workgroups (tiles x slabs ~ 2048) to fill 256 CUs even when the weight is one tile,
 // at least 512 rows per slab, at most 4096 slabs
 static int pick_slabs(long R, int Cin, int Cout)
@@ -435,6 +482,14 @@ static int wgrad_impl(bool bf16x6, const float *dY, int lddy, const float *X, in
     int S = pick_slabs(R, Cin, Cout);
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)ws;
+    if (Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && !in_scale && !dbias && lddy >= 4) {
+        // dY rows are read four wide: columns past Cout must be zero (the callers pad gradients with zeros, _pad4)
+        const long rps4 = ((R + S - 1) / S + 3) / 4 * 4;
+        conv1x1_wgrad_skinny_kernel<<<dim3(ceil_div(Cin, 256), S), dim3(256), 0, st>>>(dY, lddy, X, ldx, R, Cin, Cout, rps4, part);
+        launch_slab_reduce(part, (long)Cout * Cin, S, accumulate, dW, st);
+        CASPR_CHECK_LAUNCH("conv1x1_wgrad");
+        return CASPR_OK;
+    }
     // bf16x6: the 256 x 256 tile where both widths fill it reasonably (padded area at most 20 % above the 128-tile's), else 128 x 128
     int kind = 0, T = WG_T;
     if (bf16x6) {
