@@ -45,6 +45,11 @@ python $REPO/tools/rocprof_summary.py $(find /tmp/pt -name "*results.db" | head 
 (cd $REPO && bash tools/profile_cnf.sh ${TAG} > /dev/null 2>&1)
 [ -x $REPO/tools/micro/mfma_power ] && $REPO/tools/micro/mfma_power > $OUT/${TAG}_mfma_power.txt 2>&1
 [ -x $REPO/tools/micro/mfma_fillers ] && $REPO/tools/micro/mfma_fillers > $OUT/${TAG}_mfma_fillers.txt 2>&1
+[ -x $REPO/tools/micro/mfma_pipe ] && $REPO/tools/micro/mfma_pipe 800 > $OUT/${TAG}_mfma_pipe.txt 2>&1
+[ -x $REPO/tools/micro/mfma_dma ] && $REPO/tools/micro/mfma_dma > $OUT/${TAG}_mfma_dma.txt 2>&1
+python $REPO/tools/host_timeline.py > $OUT/${TAG}_host_timeline.txt 2>&1
+python $REPO/tools/train_host_probe.py > $OUT/${TAG}_train_host_probe.txt 2>&1
+python $REPO/tools/sa_mlp_phase_trace.py > $OUT/${TAG}_sa_mlp_phase_trace.txt 2>&1
 python $REPO/tools/conv_bench.py > $OUT/${TAG}_conv_bench.txt 2>&1
 # per-chunk phase cycles of the bf16x6 conv (debug flavour of the library, if it was built) and weight-gradient timings in both modes
 if [ -f $REPO/caspr_amd/csrc/libcaspr_hip_debug.so ]; then python $REPO/tools/conv_x6_trace.py > $OUT/${TAG}_conv_x6_trace.txt 2>&1; fi
