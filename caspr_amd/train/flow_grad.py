@@ -261,8 +261,87 @@ class CnfIn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # latent ODE (latent_ode_model.py:45-70,139-147): z' = MLP_tanh(z), classic RK4, `steps` per requested interval
 # ---------------------------------------------------------------------------------------------
-def latent_solve_train(lat, z0, times):
-    """z0 (B,D) differentiable, times (Tu,) ascending -> (B,Tu,D); first output is z0 itself."""
+class LatentSolve(torch.autograd.Function):
+    """The whole latent RK4 solve as ONE autograd node: a taped forward and a hand-written reverse sweep over the same kernels
+    (conv1x1 forward / transposed), with the WEIGHT gradients of all evaluations taken at the end as one product per layer over
+    the concatenated rows (the four layers are shared by every evaluation: dW = sum_e d_e^T x_e = [d_1; d_2; ...]^T [x_1; x_2; ...]).
+    Node per layer call (`linear_rows`) this was 288 eight-row weight-gradient launches with their slab reductions and 288
+    gradient accumulations per step (cfg-3: 72 evaluations x 4 layers); same arithmetic otherwise.
+    z0 (B,D), tt (Tu,) device times, steps, then w0, b0, ..., w3, b3 -> (B,Tu,D)."""
+
+    @staticmethod
+    def forward(ctx, z0, tt, steps, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        pk = [_packed(w, False) for w in ws]
+        bd = [b.detach().contiguous() for b in bs]
+        B = z0.shape[0]
+        tape = []
+
+        def f(z):
+            a = [z.contiguous()]
+            for i in range(4):
+                y = ops.conv1x1(pk[i], bd[i], a[-1].view(1, B, -1)).view(B, -1)[:, :ws[i].shape[0]]
+                a.append(torch.tanh(y) if i < 3 else y)
+            tape.append(a[:4])
+            return a[4]
+        outs, z, hs = [z0], z0.detach(), []
+        for k in range(1, tt.shape[0]):
+            h = (tt[k] - tt[k - 1]) / steps
+            for _ in range(steps):
+                k1 = f(z)
+                k2 = f(z + 0.5 * h * k1)
+                k3 = f(z + 0.5 * h * k2)
+                k4 = f(z + h * k3)
+                z = z + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+                hs.append(h)
+            outs.append(z)
+        ctx.tape, ctx.hs, ctx.steps, ctx.ws = tape, hs, steps, ws
+        ctx.has_b = [b is not None for b in bs]
+        return torch.stack(outs, dim=1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        tape, hs, steps, ws = ctx.tape, ctx.hs, ctx.steps, ctx.ws
+        pkt = [_packed(w, True) for w in ws]
+        B = gout.shape[0]
+        deltas, inputs = [[] for _ in range(4)], [[] for _ in range(4)]
+
+        def fb(a, g):                              # a = (x, h1, h2, h3) of one evaluation, g = dL/d f(x) -> dL/dx
+            for i in (3, 2, 1, 0):
+                d = g.contiguous() if i == 3 else g * (1.0 - a[i + 1] * a[i + 1])    # tanh' on the layer's stored output
+                deltas[i].append(d)
+                inputs[i].append(a[i])
+                g = ops.conv1x1(pkt[i], None, d.view(1, B, -1)).view(B, -1)[:, :ws[i].shape[1]]
+            return g
+        Tu = gout.shape[1]
+        gz = gout[:, Tu - 1].clone()
+        e = len(tape)
+        for k in range(Tu - 1, 0, -1):
+            for st in range(steps):
+                h = hs[(k - 1) * steps + (steps - 1 - st)]
+                a1, a2, a3, a4 = tape[e - 4], tape[e - 3], tape[e - 2], tape[e - 1]
+                e -= 4
+                g4 = fb(a4, (h / 6.0) * gz)
+                g3 = fb(a3, (h / 3.0) * gz + h * g4)
+                g2 = fb(a2, (h / 3.0) * gz + (0.5 * h) * g3)
+                g1 = fb(a1, (h / 6.0) * gz + (0.5 * h) * g2)
+                gz = gz + g4 + g3 + g2 + g1
+            gz = gz + gout[:, k - 1]
+        grads = []
+        for i in range(4):
+            d, x = torch.cat(deltas[i], dim=0), torch.cat(inputs[i], dim=0)
+            cout, cin = ws[i].shape
+            dw = torch.empty(cout, cin, device=d.device, dtype=torch.float32)
+            db = torch.empty(cout, device=d.device, dtype=torch.float32) if ctx.has_b[i] else None
+            T.conv1x1_wgrad(_pad4(d).view(1, d.shape[0], -1), _pad4(x).view(1, x.shape[0], -1), cin, cout, dw, db)
+            grads += [dw, db]
+        ctx.tape = None
+        return (gz, None, None) + tuple(grads)
+
+
+def latent_solve_layers(lat, z0, times):
+    """The same solve with one autograd node per layer call (`linear_rows`) and torch.autograd's own reverse sweep: what
+    LatentSolve is checked against (tests/test_hip_train.py)."""
     lin = [lat.ode_func.dynamics_net[i] for i in (0, 2, 4, 6)]
 
     def f(z):
@@ -272,9 +351,7 @@ def latent_solve_train(lat, z0, times):
             if i < 3:
                 h = torch.tanh(h)
         return h
-    outs = [z0]
-    z = z0
-    tt = times.detach().float()
+    outs, z, tt = [z0], z0, times.detach().float()
     for k in range(1, tt.shape[0]):
         h = (tt[k] - tt[k - 1]) / lat.rk4_steps
         for _ in range(lat.rk4_steps):
@@ -284,8 +361,25 @@ def latent_solve_train(lat, z0, times):
             k4 = f(z + h * k3)
             z = z + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
         outs.append(z)
-    lat.ode_func._num_evals.fill_(4 * lat.rk4_steps * max(tt.shape[0] - 1, 0))
     return torch.stack(outs, dim=1)
+
+
+LATENT_NODE = __import__("os").environ.get("CASPR_LATENT_NODE", "1") != "0"     # 0: the per-layer form (A/B timing, debugging)
+
+
+def latent_solve_train(lat, z0, times):
+    """z0 (B,D) differentiable, times (Tu,) ascending -> (B,Tu,D); first output is z0 itself."""
+    tt = times.detach().float()
+    if LATENT_NODE:
+        wb = []
+        for i in (0, 2, 4, 6):
+            l = lat.ode_func.dynamics_net[i]
+            wb += [l.weight, l.bias]
+        out = LatentSolve.apply(z0, tt, lat.rk4_steps, *wb)
+    else:
+        out = latent_solve_layers(lat, z0, times)
+    lat.ode_func._num_evals.fill_(4 * lat.rk4_steps * max(tt.shape[0] - 1, 0))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

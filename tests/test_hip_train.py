@@ -661,3 +661,60 @@ def test_eval_mode_forward_is_differentiable_and_cnf_forward_draws_fresh_noise(s
         with pytest.raises(ValueError):
             ops.cnf_rk4(xb, hyper, w["tcol"], w["w0"], w["b0"], w["w1p"], w["b1"], w["w2p"], w["b2"], w["w3"], w["b3"], 0.5, 2, False,
                         e=torch.randn(2, 8, 3, device=dev), logp=torch.zeros(2, 64, 1, device=dev))
+
+
+def test_latent_solve_single_node_matches_per_layer_autograd_and_f64():
+    """LatentSolve (one autograd node, hand-written reverse sweep, weight gradients of all evaluations as one product per layer)
+    against the per-layer form differentiated by torch.autograd on the same kernels, and against float64 autograd of the same
+    RK4 map on the CPU (latent_ode_model.py:45-70,139-147 with the fixed-step solver of DESIGN.md section 4)."""
+    from caspr_amd.models.latent_ode_model import LatentODE
+    from caspr_amd.train import flow_grad as FG
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    lat = LatentODE(input_size=64, hidden_size=512, num_layers=2).to(dev)
+    lat.rk4_steps = 2
+    z0 = rnd(1, 8, 64, scale=0.5).to(dev).requires_grad_(True)
+    times = torch.tensor([0.0, 0.2, 0.2, 0.55, 1.0], device=dev)          # a repeated stamp: a zero-length interval
+    wgt = rnd(2, 8, 5, 64).to(dev)
+    params = [p for p in lat.ode_func.parameters()]
+
+    def grads(fn):
+        for p in params:
+            p.grad = None
+        z0.grad = None
+        out = fn(lat, z0, times)
+        (out * wgt).sum().backward()
+        return out.detach(), z0.grad.clone(), [p.grad.clone() for p in params]
+    out_n, gz_n, gp_n = grads(lambda l, z, t: FG.LatentSolve.apply(z, t, l.rk4_steps, *[x for i in (0, 2, 4, 6) for x in (l.ode_func.dynamics_net[i].weight, l.ode_func.dynamics_net[i].bias)]))
+    out_l, gz_l, gp_l = grads(FG.latent_solve_layers)
+    rel("latent_node_vs_layers_out", out_n, out_l, 1e-6)
+    rel("latent_node_vs_layers_dz0", gz_n, gz_l, 2e-5)
+    for i, (a, b) in enumerate(zip(gp_n, gp_l)):
+        rel("latent_node_vs_layers_dp%d" % i, a, b, 2e-5)
+    # float64 autograd of the same map
+    lin = [lat.ode_func.dynamics_net[i] for i in (0, 2, 4, 6)]
+    W = [l.weight.detach().cpu().double().requires_grad_(True) for l in lin]
+    Bi = [l.bias.detach().cpu().double().requires_grad_(True) for l in lin]
+    z64 = z0.detach().cpu().double().requires_grad_(True)
+
+    def f(z):
+        h = z
+        for i in range(4):
+            h = h @ W[i].t() + Bi[i]
+            if i < 3:
+                h = torch.tanh(h)
+        return h
+    outs, z, tt = [z64], z64, times.cpu().double()
+    for k in range(1, tt.shape[0]):
+        h = (tt[k] - tt[k - 1]) / 2
+        for _ in range(2):
+            k1 = f(z); k2 = f(z + 0.5 * h * k1); k3 = f(z + 0.5 * h * k2); k4 = f(z + h * k3)
+            z = z + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        outs.append(z)
+    out64 = torch.stack(outs, dim=1)
+    (out64 * wgt.cpu().double()).sum().backward()
+    rel("latent_node_vs_f64_out", out_n, out64, 2e-6)
+    rel("latent_node_vs_f64_dz0", gz_n, z64.grad, 3e-5)
+    want = [g for pair in zip([w.grad for w in W], [b.grad for b in Bi]) for g in pair]
+    for i, (a, b) in enumerate(zip(gp_n, want)):
+        rel("latent_node_vs_f64_dp%d" % i, a, b, 3e-5)
