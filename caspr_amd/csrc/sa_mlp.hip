@@ -449,18 +449,21 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
 #pragma unroll
         for (int rt = 0; rt < C1 / 16; ++rt) af[rt] = ld4(a.L[0].wp + (((long)rt * KC0 + kc) * 64 + lane) * 4);
     };
-    {   // two register sets: chunk kc+1's gather + weights are in flight while chunk kc multiplies (KC0 is even)
+    {   // two register sets: chunk kc+1's gather + weights are in flight while chunk kc multiplies.  The pack holds an EVEN number
+        // of 16-wide chunks (KC0); only those that carry inputs are gathered and multiplied -- 1 of 2 at the first level (9 + 3
+        // inputs), 7 of 8 at the second (96 + 3): the all-zero chunk was a fifth of the first level's MFMAs
+        const int kcu = (C4 + 4 + 15) >> 4;
         f32x4 b0[CT], b1[CT], m0v, m1v, w0[C1 / 16], w1[C1 / 16];
         gather(b0, m0v, 0);
         load_a1(w0, 0);
-        for (int kc = 0; kc < KC0; kc += 2) {
+        for (int kc = 0; kc + 1 < kcu; kc += 2) {
             gather(b1, m1v, kc + 1);
             load_a1(w1, kc + 1);
             __builtin_amdgcn_sched_barrier(0);
             mask(b0, kc);
             mask1(m0v, kc);
             mma1(b0, m0v, w0);
-            if (kc + 2 < KC0) {
+            if (kc + 2 < kcu) {
                 gather(b0, m0v, kc + 2);
                 load_a1(w0, kc + 2);
             }
@@ -468,6 +471,11 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
             mask(b1, kc + 1);
             mask1(m1v, kc + 1);
             mma1(b1, m1v, w1);
+        }
+        if (kcu & 1) {            // the last chunk of an odd count sits in set 0
+            mask(b0, kcu - 1);
+            mask1(m0v, kcu - 1);
+            mma1(b0, m0v, w0);
         }
     }
     // mu[rt][cen] = (W x0 + bias) rows 4g..4g+3 of centre cen: lane (g, cen) of the mu tile, broadcast along the row
