@@ -390,59 +390,93 @@ __global__ __launch_bounds__(256) void conv_gn_finalize_kernel(const f32x4 *__re
                                                                float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ pmax,
                                                                float *__restrict__ mean_out, float *__restrict__ rstd_out)
 {
-    __shared__ double s_sum[256], s_sq[256];
+    __shared__ double s_sum[256], s_sq[256], s_m2[256];
+    __shared__ float s_mx[256], s_mn[256];
     const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, tid = threadIdx.x;
     const f32x4 *base = part + (long)b * PT * C + g * cpg;
-    // every element of `part` = {mean, M2, max, min} of one channel over one 128-point tile; the group's moments by the pairwise
-    // update in f64: mean = average of the tile means, M2 = sum of the tiles' M2 + 128 * sum (tile mean - mean)^2
-    const int total = PT * cpg;
-    double sum = 0.0;
-    for (int e = tid; e < total; e += 256) {
-        const int pt = e / cpg, cc = e - pt * cpg;
-        sum += (double)base[(long)pt * C + cc][0];
+    // every element of `part` = {mean, M2, max, min} of one channel over one 128-point tile.  ONE pass: a thread walks the tiles of
+    // ITS channel (cpg <= 256: 256 / cpg tile lanes per channel), summing the tile means, their squares and the tiles' M2 in f64 --
+    // group M2 = sum M2_t + 128 (sum m_t^2 - T mean^2), exact enough in f64 for any |mean| / sigma a float can hold -- and keeping
+    // the channel's max / min.  (Two passes plus a per-channel serial walk for the max took 70-105 us on the 1600-channel layers.)
+    const int lanes = cpg <= 256 ? 256 / cpg : 1;
+    double s1 = 0.0, s2 = 0.0, sm = 0.0;
+    for (int c0 = 0; c0 < cpg; c0 += 256) {                    // one round unless a group is wider than 256 channels
+        const int cc = c0 + (cpg <= 256 ? tid % cpg : tid), pl = cpg <= 256 ? tid / cpg : 0;
+        float m1 = -INFINITY, m0 = INFINITY;
+        if (cc < cpg && pl < lanes) {
+#pragma unroll 4
+            for (int pt = pl; pt < PT; pt += lanes) {
+                const f32x4 v = base[(long)pt * C + cc];
+                s1 += (double)v[0];
+                s2 += (double)v[0] * (double)v[0];
+                sm += (double)v[1];
+                m1 = fmaxf(m1, v[2]);
+                m0 = fminf(m0, v[3]);
+            }
+        }
+        if (pmax) {
+            __syncthreads();
+            s_mx[tid] = m1;
+            s_mn[tid] = m0;
+            __syncthreads();
+            if (cc < cpg && pl == 0) {
+                for (int l = 1; l < lanes; ++l) {
+                    m1 = fmaxf(m1, s_mx[l * cpg + cc]);
+                    m0 = fminf(m0, s_mn[l * cpg + cc]);
+                }
+                s_mx[tid] = m1;          // kept for the scale's sign below (this thread writes channel cc)
+                s_mn[tid] = m0;
+            }
+        }
     }
-    s_sum[tid] = sum;
+    s_sum[tid] = s1;
+    s_sq[tid] = s2;
+    s_m2[tid] = sm;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) s_sum[tid] += s_sum[tid + off];
+        if (tid < off) {
+            s_sum[tid] += s_sum[tid + off];
+            s_sq[tid] += s_sq[tid + off];
+            s_m2[tid] += s_m2[tid + off];
+        }
         __syncthreads();
     }
-    const double mean = s_sum[0] / (double)total;
-    double sq = 0.0;
-    for (int e = tid; e < total; e += 256) {
-        const int pt = e / cpg, cc = e - pt * cpg;
-        const f32x4 v = base[(long)pt * C + cc];
-        const double d = (double)v[0] - mean;
-        sq += (double)v[1] + 128.0 * d * d;
-    }
-    s_sq[tid] = sq;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) s_sq[tid] += s_sq[tid + off];
-        __syncthreads();
-    }
+    const double T = (double)PT * cpg;
+    const double mean = s_sum[0] / T;
+    double m2 = s_m2[0] + 128.0 * (s_sq[0] - T * mean * mean);
     const double cnt = (double)P * cpg;
-    double var = s_sq[0] / cnt;
+    double var = m2 / cnt;
     var = var < 0.0 ? 0.0 : var;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     if (mean_out && tid == 0) {
         mean_out[b * G + g] = (float)mean;
         rstd_out[b * G + g] = (float)rstd;
     }
-    for (int cc = tid; cc < cpg; cc += 256) {
-        const int c = g * cpg + cc;
-        const float sc = (float)((double)gamma[c] * rstd);
-        const float sf = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
-        scale[(long)b * C + c] = sc;
-        shift[(long)b * C + c] = sf;
-        if (pmax) {
-            float m1 = -INFINITY, m0 = INFINITY;
-            for (int pt = 0; pt < PT; ++pt) {
-                const f32x4 v = base[(long)pt * C + cc];
-                m1 = fmaxf(m1, v[2]);
-                m0 = fminf(m0, v[3]);
+    if (cpg <= 256) {
+        if (tid < cpg) {
+            const int c = g * cpg + tid;
+            const float sc = (float)((double)gamma[c] * rstd);
+            const float sf = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+            scale[(long)b * C + c] = sc;
+            shift[(long)b * C + c] = sf;
+            if (pmax) pmax[(long)b * C + c] = (sc >= 0.f ? s_mx[tid] : s_mn[tid]) * sc + sf;
+        }
+    } else {
+        for (int cc = tid; cc < cpg; cc += 256) {
+            const int c = g * cpg + cc;
+            const float sc = (float)((double)gamma[c] * rstd);
+            const float sf = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+            scale[(long)b * C + c] = sc;
+            shift[(long)b * C + c] = sf;
+            if (pmax) {
+                float m1 = -INFINITY, m0 = INFINITY;
+                for (int pt = 0; pt < PT; ++pt) {
+                    const f32x4 v = base[(long)pt * C + cc];
+                    m1 = fmaxf(m1, v[2]);
+                    m0 = fminf(m0, v[3]);
+                }
+                pmax[(long)b * C + c] = (sc >= 0.f ? m1 : m0) * sc + sf;
             }
-            pmax[(long)b * C + c] = (sc >= 0.f ? m1 : m0) * sc + sf;
         }
     }
 }
