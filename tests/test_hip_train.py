@@ -718,3 +718,49 @@ def test_latent_solve_single_node_matches_per_layer_autograd_and_f64():
     want = [g for pair in zip([w.grad for w in W], [b.grad for b in Bi]) for g in pair]
     for i, (a, b) in enumerate(zip(gp_n, want)):
         rel("latent_node_vs_f64_dp%d" % i, a, b, 3e-5)
+
+
+def test_cnf_fused_layers_match_the_separate_passes():
+    """The ODE function's hidden layers with the gated softplus in the conv's epilogue (CnfLayer / CnfLayerOut, row layout blk = 32)
+    against the separate passes (linear_rows + CnfAct in the [values | tangents] layout, blk = R), forward and every gradient, and
+    the first layer (CnfIn) in both layouts: same values up to the rounding of the hardware transcendentals."""
+    from caspr_amd.train import flow_grad as FG
+    dev = torch.device("cuda:0")
+    BT, n, C = 3, 128, 512
+    R = BT * n
+    y, e = rnd(1, R, 3).to(dev).requires_grad_(True), rnd(2, R, 3).to(dev)
+    w0, b0 = rnd(3, C, 3, scale=0.5).to(dev).requires_grad_(True), rnd(4, C, scale=0.2).to(dev).requires_grad_(True)
+    w1, b1 = rnd(5, C, C, scale=1.0 / np.sqrt(C)).to(dev).requires_grad_(True), rnd(6, C, scale=0.2).to(dev).requires_grad_(True)
+    w2, b2 = rnd(7, C, C, scale=1.0 / np.sqrt(C)).to(dev).requires_grad_(True), rnd(8, C, scale=0.2).to(dev).requires_grad_(True)
+    wo = rnd(9, 3, C, scale=1.0 / np.sqrt(C)).to(dev).requires_grad_(True)
+    gates = [torch.sigmoid(rnd(10 + i, BT, C)).to(dev).requires_grad_(True) for i in range(3)]
+    betas = [rnd(20 + i, BT, C, scale=0.3).to(dev).requires_grad_(True) for i in range(3)]
+    leaves = [y, w0, b0, w1, b1, w2, b2, wo] + gates + betas
+    wgt = rnd(30, 2 * R, 3).to(dev)
+
+    def to_pts(z, blk):                     # (2R, c) rows in layout blk -> (2, R, c): values, tangents by point
+        zz = z.view(R // blk, 2, blk, -1)
+        return torch.stack([zz[:, 0].reshape(R, -1), zz[:, 1].reshape(R, -1)])
+
+    def run(fused):
+        for t in leaves:
+            t.grad = None
+        blk = 32 if fused else R
+        h = FG.CnfIn.apply(y, e, w0, b0, gates[0], betas[0], n, blk)
+        if fused:
+            h1 = FG.CnfLayer.apply(h, w1, b1, gates[1], betas[1], n)
+            zo = FG.CnfLayerOut.apply(h1, w2, b2, gates[2], betas[2], wo, n)
+        else:
+            h1 = FG.CnfAct.apply(FG.linear_rows(h, w1, None), b1, gates[1], betas[1], n, blk)
+            h2 = FG.CnfAct.apply(FG.linear_rows(h1, w2, None), b2, gates[2], betas[2], n, blk)
+            zo = FG.linear_rows(h2, wo, None)
+        out = to_pts(zo, blk)
+        (out * wgt.view(2, R, 3)).sum().backward()
+        return out.detach(), to_pts(h.detach(), blk), [t.grad.clone() for t in leaves]
+    out_f, h_f, g_f = run(True)
+    out_s, h_s, g_s = run(False)
+    rel("cnf_fused_in_layer", h_f, h_s, 1e-6)
+    rel("cnf_fused_out", out_f, out_s, 3e-6)
+    names = ["y", "w0", "b0", "w1", "b1", "w2", "b2", "wo", "gate0", "gate1", "gate2", "beta0", "beta1", "beta2"]
+    for nm, a, b in zip(names, g_f, g_s):
+        rel("cnf_fused_grad_" + nm, a, b, 2e-5)
