@@ -108,10 +108,14 @@ __global__ void pack_weight_bf16x3_kernel(const float *__restrict__ w, int ldw, 
 // tangent row pairs in the epilogue.  Rows come in blocks of 64 = 32 value rows + the tangent rows of the same 32 points
 // (backward_flow.hip, blk = 32): a lane's column tiles 0, 1 are values, 2, 3 their tangents.  The raw product is stored too (the
 // backward pass recomputes the activation from it).
+// act mode 3 (caspr_conv1x1_cnf_act_bwd_bf16x6_f32): the BACKWARD of that layer in the epilogue of the data-gradient conv that
+// produces its dH (this launch multiplies the NEXT layer's dZ by its transposed weight): dZ = act'(Z) dH on the same row pairs, with
+// the raw product Z of the layer read back, and the per-frame gate / bias gradients as partial sums per (128-row tile, wave half).
 struct X6Act {
     const float *gate;   // (batch entries, cstride); the per-entry bias `bbias` is beta, `bias` the layer bias
-    float *z;            // raw product (rows as Y)
+    float *z;            // mode 2: raw product out (rows as Y);  mode 3: the layer's raw product in
     int ldz;
+    float *red;          // mode 3: [2][batch entries * Pt * 2][cstride] partial sums of dgate | dbeta
 };
 
 template <bool FUSED, bool STATS>
@@ -320,6 +324,46 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
                 continue;
             }
         }
+        if constexpr (!STATS) {
+            if ((act & 0xff) == 3) {
+                const f32x4 b4 = ld4(bias + co), g4 = ld4(ax.gate + (long)b * cstride + co), be4 = ld4(bb + co);
+                f32x4 pg = (f32x4){0.f, 0.f, 0.f, 0.f}, pb = pg;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const long rv = (long)b * P + p0 + wn * 64 + ni * 16 + j, rt = rv + 32;
+                    const f32x4 zv = ld4(ax.z + rv * ax.ldz + co), zt = ld4(ax.z + rt * ax.ldz + co);
+                    const f32x4 dhv = acc[mi][ni], dht = acc[mi][ni + 2];
+                    f32x4 dzv, dzt;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float zb = zv[r] + b4[r];
+                        const float a_ = zb * g4[r] + be4[r], ad = zt[r] * g4[r];
+                        const float u = __builtin_amdgcn_exp2f(fabsf(a_) * -1.44269504088896341f);
+                        const float rc = __builtin_amdgcn_rcpf(1.0f + u);
+                        const float sg = a_ >= 0.0f ? rc : u * rc;
+                        const float da = dhv[r] * sg + dht[r] * (sg * (1.0f - sg)) * ad;
+                        const float dad = dht[r] * sg;
+                        dzv[r] = da * g4[r];
+                        dzt[r] = dad * g4[r];
+                        pg[r] += da * zb + dad * zt[r];
+                        pb[r] += da;
+                    }
+                    st4(Y + rv * ldy + co, dzv);
+                    st4(Y + rt * ldy + co, dzt);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pg[r] = row_allreduce_add<16>(pg[r]);
+                    pb[r] = row_allreduce_add<16>(pb[r]);
+                }
+                if (j == 0) {
+                    const long entry = ((long)b * Pt + pt) * 2 + wn, nent = (long)gridDim.x / Mt * 2;
+                    st4(ax.red + entry * cstride + co, pg);
+                    st4(ax.red + (nent + entry) * cstride + co, pb);
+                }
+                continue;
+            }
+        }
         f32x4 add = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (bias) add += ld4(bias + co);
         if (bb) add += ld4(bb + co);
@@ -505,7 +549,7 @@ extern "C" void caspr_debug_set_conv_x6_trace(unsigned long long *dev_buf) { g_c
 
 static int conv_x6_launch(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx, const float *in_scale,
                           const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout,
-                          int act, f32x4 *part, void *stream, int cstride = 0, X6Act ax = X6Act{nullptr, nullptr, 0})
+                          int act, f32x4 *part, void *stream, int cstride = 0, X6Act ax = X6Act{nullptr, nullptr, 0, nullptr})
 {
     if (cstride == 0) cstride = Cout;
     CASPR_REQUIRE(wpk && X && (Y || part) && B > 0 && P > 0 && Cin > 0 && Cout > 0, "conv1x1_bf16x6: bad arguments");
@@ -551,7 +595,47 @@ extern "C" int caspr_conv1x1_cnf_act_bf16x6_f32(const void *wpk, const float *b,
     CASPR_REQUIRE(ldz % 4 == 0 && ldz >= Cout && ((uintptr_t)Z % 16) == 0 && ((uintptr_t)gate % 16) == 0 && ((uintptr_t)beta % 16) == 0 &&
                       ((uintptr_t)b % 16) == 0,
                   "conv1x1_cnf_act: Z / gate / beta / b must be 16-byte aligned, ldz a multiple of 4 and >= Cout");
-    return conv_x6_launch(wpk, b, beta, X, ldx, nullptr, nullptr, 0, 0, H, ldh, frames, 2 * n, Cin, Cout, 2, nullptr, stream, 0, X6Act{gate, Z, ldz});
+    return conv_x6_launch(wpk, b, beta, X, ldx, nullptr, nullptr, 0, 0, H, ldh, frames, 2 * n, Cin, Cout, 2, nullptr, stream, 0, X6Act{gate, Z, ldz, nullptr});
+}
+
+// sums the per-(tile, wave half) partials of act mode 3 in index order: one thread per (frame, channel)
+__global__ void cnf_act_bwd_reduce_kernel(const float *__restrict__ red, int frames, int per, int C, float *__restrict__ dgate,
+                                          float *__restrict__ dbeta)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)frames * C) return;
+    const long f = i / C;
+    const int c = (int)(i - f * C);
+    const long nent = (long)frames * per;
+    float sg = 0.f, sb = 0.f;
+    for (int e = 0; e < per; ++e) {
+        sg += red[(f * per + e) * C + c];
+        sb += red[(nent + f * per + e) * C + c];
+    }
+    dgate[i] = sg;
+    dbeta[i] = sb;
+}
+
+extern "C" long caspr_conv1x1_cnf_act_bwd_ws_bytes(int frames, int n, int Cout) { return (long)frames * (2 * n / X6_TP) * 2 * 2 * Cout * 4 + 256; }
+
+extern "C" int caspr_conv1x1_cnf_act_bwd_bf16x6_f32(const void *wpk, const float *X, int ldx, const float *Z, int ldz, const float *b,
+                                                    const float *gate, const float *beta, float *dZ, int lddz, float *dgate, float *dbeta,
+                                                    void *ws, long ws_bytes, int frames, int n, int Cin, int Cout, void *stream)
+{
+    CASPR_REQUIRE(Z && b && gate && beta && dZ && dgate && dbeta && ws && frames > 0 && n > 0 && n % 64 == 0,
+                  "conv1x1_cnf_act_bwd: bad arguments (n=%d must be a multiple of 64)", n);
+    CASPR_REQUIRE(ldz % 4 == 0 && ldz >= Cout && ((uintptr_t)Z % 16) == 0 && ((uintptr_t)gate % 16) == 0 && ((uintptr_t)beta % 16) == 0 &&
+                      ((uintptr_t)b % 16) == 0 && ((uintptr_t)ws % 16) == 0,
+                  "conv1x1_cnf_act_bwd: Z / gate / beta / b / ws must be 16-byte aligned, ldz a multiple of 4 and >= Cout");
+    CASPR_REQUIRE(ws_bytes >= caspr_conv1x1_cnf_act_bwd_ws_bytes(frames, n, Cout), "conv1x1_cnf_act_bwd: workspace too small");
+    const int rc = conv_x6_launch(wpk, b, beta, X, ldx, nullptr, nullptr, 0, 0, dZ, lddz, frames, 2 * n, Cin, Cout, 3, nullptr, stream, 0,
+                                  X6Act{gate, const_cast<float *>(Z), ldz, (float *)ws});
+    if (rc != CASPR_OK) return rc;
+    const long tot = (long)frames * Cout;
+    cnf_act_bwd_reduce_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>((const float *)ws, frames, 2 * n / X6_TP * 2, Cout,
+                                                                                                         dgate, dbeta);
+    CASPR_CHECK_LAUNCH("conv1x1_cnf_act_bwd");
+    return CASPR_OK;
 }
 
 extern "C" int caspr_conv1x1_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,

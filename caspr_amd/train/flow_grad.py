@@ -211,6 +211,74 @@ class CnfLayerOut(torch.autograd.Function):
         return dx, dw, (gate * dbeta).sum(dim=0), dgate, dbeta, dwo, None
 
 
+class CnfHidden(torch.autograd.Function):
+    """Both hidden layers of the ODE function and the 3-channel output product as ONE node: forward = two fused conv + activation
+    launches + the output conv; backward = the output layer's data gradient inside the last layer's activation backward (as
+    CnfLayerOut), and the FIRST hidden layer's activation backward in the epilogue of the data-gradient conv that produces its dH
+    (caspr_conv1x1_cnf_act_bwd_bf16x6_f32): that dH (2R x C) is never written, one 1 GB pass per evaluation less.
+    x (2R, C0), (w1, b1, gate1, beta1), (w2, b2, gate2, beta2), wo (3, C2) -> zo (2R, 3).  Row layout blk = 32."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, wo, n):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        L = _lib.load()
+        R2 = x.shape[0]
+        xp = x.contiguous()
+        b1, g1, be1, b2, g2, be2 = [t.detach().contiguous() for t in (b1, g1, be1, b2, g2, be2)]
+        zs, hs, cur = [], [], xp
+        for (w, b, g, be) in ((w1, b1, g1, be1), (w2, b2, g2, be2)):
+            cout, cin = w.shape
+            z = torch.empty(R2, cout, device=x.device, dtype=torch.float32)
+            h = torch.empty(R2, cout, device=x.device, dtype=torch.float32)
+            with ops.timed("k:conv1x1_bf16x6:%d:%d:%d" % (cin, cout, R2), 2):
+                _lib.check(L.caspr_conv1x1_cnf_act_bf16x6_f32(_p(_packed(w, False).x3()), _p(b), _p(g), _p(be), _p(cur), cur.stride(0), _p(z), cout, _p(h), cout,
+                                                              R2 // (2 * n), n, cin, cout, _stream()), "caspr_conv1x1_cnf_act_bf16x6_f32")
+            zs.append(z)
+            hs.append(h)
+            cur = h
+        zo = ops.conv1x1(_packed(wo, False), None, cur.view(1, R2, cur.shape[1])).view(R2, -1)
+        ctx.save_for_backward(xp, w1, b1, g1, be1, w2, b2, g2, be2, wo, zs[0], hs[0], zs[1], hs[1])
+        ctx.n = n
+        return zo[:, :wo.shape[0]]
+
+    @staticmethod
+    def backward(ctx, dzo):
+        from .. import lib as _lib
+        from ..ops import _p, _stream, _workspace
+        L = _lib.load()
+        xp, w1, b1, g1, be1, w2, b2, g2, be2, wo, z1, h1, z2, h2 = ctx.saved_tensors
+        n, R2 = ctx.n, xp.shape[0]
+        c1, c0 = w1.shape
+        c2 = w2.shape[0]
+        dev = xp.device
+        dzop = _pad4(dzo)
+        dwo = torch.empty(wo.shape[0], c2, device=dev, dtype=torch.float32)
+        T.conv1x1_wgrad(dzop.view(1, R2, dzop.shape[1]), h2.view(1, R2, c2), c2, wo.shape[0], dwo, None)
+        # last hidden layer: dH = dzo Wo formed inside the activation backward
+        dz2 = torch.empty(R2, c2, device=dev, dtype=torch.float32)
+        dg2, db2 = torch.empty_like(g2), torch.empty_like(be2)
+        woc = wo.detach().contiguous()
+        _lib.check(L.caspr_cnf_act_bwd_out_f32(_p(z2), c2, _p(b2), _p(g2), _p(be2), _p(dzop), dzop.shape[1], _p(woc), c2, R2 // 2, n, c2, 32, _p(dz2), c2,
+                                               _p(dg2), _p(db2), _stream()), "caspr_cnf_act_bwd_out_f32")
+        dw2 = torch.empty(c2, c1, device=dev, dtype=torch.float32)
+        T.conv1x1_wgrad(dz2.view(1, R2, c2), h1.view(1, R2, c1), c1, c2, dw2, None)
+        # first hidden layer: its activation backward in the epilogue of dz2 W2 (the product that is its dH)
+        dz1 = torch.empty(R2, c1, device=dev, dtype=torch.float32)
+        dg1, db1 = torch.empty_like(g1), torch.empty_like(be1)
+        frames = R2 // (2 * n)
+        nbytes = L.caspr_conv1x1_cnf_act_bwd_ws_bytes(frames, n, c1)
+        ws = _workspace(nbytes, dev)
+        with ops.timed("k:conv1x1_bf16x6:%d:%d:%d" % (c2, c1, R2), 2):
+            _lib.check(L.caspr_conv1x1_cnf_act_bwd_bf16x6_f32(_p(_packed(w2, True).x3()), _p(dz2), c2, _p(z1), c1, _p(b1), _p(g1), _p(be1), _p(dz1), c1,
+                                                              _p(dg1), _p(db1), _p(ws), ws.numel(), frames, n, c2, c1, _stream()),
+                       "caspr_conv1x1_cnf_act_bwd_bf16x6_f32")
+        dw1 = torch.empty(c1, c0, device=dev, dtype=torch.float32)
+        T.conv1x1_wgrad(dz1.view(1, R2, c1), xp.view(1, R2, c0), c0, c1, dw1, None)
+        dx = ops.conv1x1(_packed(w1, True), None, dz1.view(1, R2, c1)).view(R2, -1) if ctx.needs_input_grad[0] else None
+        return (dx, dw1, (g1 * db1).sum(dim=0), dg1, db1, dw2, (g2 * db2).sum(dim=0), dg2, db2, dwo, None)
+
+
 def _fused_layer_ok(l, n):
     cout, cin = l._layer.weight.shape
     return ops.CONV_BF16X6 and cin % 32 == 0 and cin >= 64 and cout % 4 == 0 and cout >= 128 and n % 64 == 0
@@ -364,6 +432,7 @@ def latent_solve_layers(lat, z0, times):
     return torch.stack(outs, dim=1)
 
 
+HIDDEN_NODE = __import__("os").environ.get("CASPR_CNF_NODE", "1") != "0"      # 0: CnfLayer + CnfLayerOut (A/B timing, debugging)
 LATENT_NODE = __import__("os").environ.get("CASPR_LATENT_NODE", "1") != "0"     # 0: the per-layer form (A/B timing, debugging)
 
 
@@ -422,11 +491,18 @@ def cnf_block_train(block, x, context, logpx, e):
             if i == 0:                                                    # 3 -> C: fused product + gate + softplus, value | tangent rows
                 h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n, blk)
                 continue
-            if i == 1 and fused:
+            if i == 1 and fused and not HIDDEN_NODE:
                 h = CnfLayer.apply(h, l._layer.weight, l._layer.bias, gate, bias, n)   # product + gate + softplus in one launch
                 continue
-            if i == 2 and fused:                           # ... and the output product behind the last hidden layer
+            if i == 2 and fused and not HIDDEN_NODE:                      # ... and the output product behind the last hidden layer
                 z = CnfLayerOut.apply(h, l._layer.weight, l._layer.bias, gate, bias, layers[3]._layer.weight, n)
+                continue
+            if i == 1 and fused:                                          # both hidden layers + the output product: one node
+                l2 = layers[2]
+                z = CnfHidden.apply(h, l._layer.weight, l._layer.bias, gate, bias, l2._layer.weight, l2._layer.bias,
+                                    gate_all[:, offs[2]:offs[3]], bias_all[:, offs[2]:offs[3]], layers[3]._layer.weight, n)
+                continue
+            if i == 2 and fused:
                 continue
             if not (i == 3 and fused):
                 z = linear_rows(h, l._layer.weight, None)

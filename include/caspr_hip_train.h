@@ -137,6 +137,17 @@ int caspr_conv1x1_cnf_act_bf16x6_f32(const void *wpk, const float *b, const floa
                                      const float *X, int ldx, float *Z, int ldz, float *H, int ldh, int frames,
                                      int n, int Cin, int Cout, void *stream);
 
+/* ... and its BACKWARD in the epilogue of the data-gradient conv that produces its dH: X = dZ of the NEXT layer (2 frames n, ldx),
+ * wpk = caspr_pack_weight_bf16x3 of that layer's TRANSPOSED weight (Cout = this layer's width, Cin = the next one's), Z = this
+ * layer's raw product, (b, gate, beta) its parameters -> dZ (2 frames n, lddz) = what caspr_cnf_act_bwd_f32 returns for
+ * dH = X W, and dgate / dbeta (frames, Cout) from per-tile partial sums in a fixed order (ws: caspr_conv1x1_cnf_act_bwd_ws_bytes).
+ * dH itself is never written.  Row layout blk = 32.                                                                       */
+long caspr_conv1x1_cnf_act_bwd_ws_bytes(int frames, int n, int Cout);
+int caspr_conv1x1_cnf_act_bwd_bf16x6_f32(const void *wpk, const float *X, int ldx, const float *Z, int ldz, const float *b,
+                                         const float *gate, const float *beta, float *dZ, int lddz, float *dgate,
+                                         float *dbeta, void *ws, long ws_bytes, int frames, int n, int Cin, int Cout,
+                                         void *stream);
+
 /* First layer of the ODE function (3 -> C) fused with its gate + softplus on value (y) and tangent (e) rows:
  * H (2R, C) as caspr_cnf_act_f32 with Z = [W0 y ; W0 e] in the row layout `blk`.  Y, E (R,3) point-indexed; W0 (C,3).
  * Backward, with ch = caspr_cnf_in_bwd_chunk(C) and ns = caspr_cnf_in_bwd_splits(C, n): dgate / dbeta (R/n, ns, C) and

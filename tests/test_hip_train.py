@@ -747,7 +747,9 @@ def test_cnf_fused_layers_match_the_separate_passes():
             t.grad = None
         blk = 32 if fused else R
         h = FG.CnfIn.apply(y, e, w0, b0, gates[0], betas[0], n, blk)
-        if fused:
+        if fused == "node":          # both hidden layers + output product as one node (first layer's backward in the dgrad epilogue)
+            zo = FG.CnfHidden.apply(h, w1, b1, gates[1], betas[1], w2, b2, gates[2], betas[2], wo, n)
+        elif fused:
             h1 = FG.CnfLayer.apply(h, w1, b1, gates[1], betas[1], n)
             zo = FG.CnfLayerOut.apply(h1, w2, b2, gates[2], betas[2], wo, n)
         else:
@@ -764,3 +766,7 @@ def test_cnf_fused_layers_match_the_separate_passes():
     names = ["y", "w0", "b0", "w1", "b1", "w2", "b2", "wo", "gate0", "gate1", "gate2", "beta0", "beta1", "beta2"]
     for nm, a, b in zip(names, g_f, g_s):
         rel("cnf_fused_grad_" + nm, a, b, 2e-5)
+    out_n, h_n, g_n = run("node")
+    rel("cnf_node_out", out_n, out_s, 3e-6)
+    for nm, a, b in zip(names, g_n, g_s):
+        rel("cnf_node_grad_" + nm, a, b, 2e-5)
