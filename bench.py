@@ -304,7 +304,8 @@ def cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, yb
     from oracle import model as O
     DENSE_TOL = 1e-5      # north_star tolerance as written (the well-conditioned input; direct difference against the f32 oracle)
     cpu_model, total_cores = cpu_description()
-    ncores = min(total_cores, 32)      # torch's intra-op pool stops scaling (and thrashes) far below 256 threads
+    ncores = min(total_cores, 16)      # measured on the GPU box's host (profiles/r03_cpu_threads_probe.txt): 8 / 16 / 32 / 64 / 128 / 256 threads ->
+                                       # 0.18 / 0.21 / 0.17 / 0.12 / 0.04 / 0.005 sequences/s: torch's intra-op pool peaks at 16 and thrashes beyond 32
     torch.set_num_threads(ncores)
     nb = x_all.shape[0]
     pick = [0, nb - 1] if nb > 1 else [0]

@@ -142,7 +142,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import model as O
-            ncores = min(os.cpu_count() or 1, 32)
+            ncores = min(os.cpu_count() or 1, 16)      # profiles/r03_cpu_threads_probe.txt: the intra-op pool peaks at 16 threads on this host
             torch.set_num_threads(ncores)
             s_ = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "step", "_num_evals")) else v)
                   for k, v in sd.items()}
