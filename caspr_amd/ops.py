@@ -19,6 +19,8 @@ from . import lib as _lib
 # Optional stage timing with HIP events recorded on the launch stream (bench.py's roofline numbers).
 TIMING = False
 TIMERS = {}
+TIMING_ONLY = None      # a set of names: at TIMING == True only these level-1 timers record (bench.py keeps the dominant kernel's
+                        # pair inside the timed region and takes the stage breakdown from its separate detail pass)
 
 
 class timed:
@@ -31,7 +33,7 @@ class timed:
         self.level = level
 
     def __enter__(self):
-        self.on = TIMING >= self.level
+        self.on = TIMING >= self.level and (TIMING_ONLY is None or TIMING != True or self.name in TIMING_ONLY)
         if self.on:
             self.t0 = torch.cuda.Event(enable_timing=True)
             self.t0.record(torch.cuda.current_stream())
