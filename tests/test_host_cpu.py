@@ -487,3 +487,44 @@ def test_conv_x6w_kernel_keeps_its_accumulator_file_to_itself():
         assert count(r"v_accvgpr_write_b32") == 256 and count(r"v_accvgpr_read_b32") == 256 and count(r"v_accvgpr_mov") == 0, (k, count(r"v_accvgpr_write_b32"), count(r"v_accvgpr_read_b32"))
         mfma = [i for i in ins if i.startswith("v_mfma")]
         assert len(mfma) == 2 * 192 and all(re.match(r"v_mfma_f32_32x32x16_bf16 a\[", i) for i in mfma), (k, len(mfma))
+
+
+def test_plan_times_is_the_sorted_unique_mapping_of_the_reference():
+    """LatentODE.plan_times (the time-stamp bookkeeping reconstruct() queues ahead of the encoder): solving at ALL B*T sorted stamps
+    and gathering (row b, position pos[b, t]) must pick, for every entry, the solution at ITS stamp -- what the reference gets
+    from torch.unique(sorted=True, return_inverse=True) (caspr.py:166-176) -- and count the evaluations of the distinct intervals."""
+    from caspr_amd.models.latent_ode_model import LatentODE
+    lat = LatentODE(input_size=64, hidden_size=512, num_layers=2)
+    lat.rk4_steps = 2
+    g = torch.Generator().manual_seed(3)
+    times = torch.rand(4, 6, generator=g)
+    times[1, 2] = times[0, 0]                     # repeats across and inside sequences
+    times[2, :] = times[2, 0]
+    plan = lat.plan_times(times)
+    B, T = times.shape
+    assert plan["shape"] == (B, T) and plan["sorted_t"].shape == (B * T,)
+    assert bool((plan["sorted_t"][1:] >= plan["sorted_t"][:-1]).all())
+    # a "solution" that is just the stamp itself: out[b, k] = sorted_t[k]
+    out = plan["sorted_t"].view(1, -1, 1).expand(B, B * T, 1)
+    picked = out[plan["rows"], plan["pos"], :][..., 0]
+    assert torch.equal(picked, times.float())
+    solve_t, time_map = torch.unique(times, sorted=True, return_inverse=True)
+    assert torch.equal(solve_t[time_map], picked)
+    assert int(plan["evals"]) == 4 * lat.rk4_steps * (solve_t.numel() - 1)
+
+
+def test_cnf_row_layout_views_match_the_kernel_formula():
+    """The (2R, C) tensors of a CNF training solve in the layout blk = 32 (include/caspr_hip_train.h): value row of point p =
+    (p / blk) 2 blk + p % blk, tangent row = value row + blk -- the views caspr_amd/train/flow_grad.py takes of them (frames in
+    front, blocks of blk value rows | blk tangent rows) address exactly those rows."""
+    BT, n, blk, c = 3, 128, 32, 4
+    R = BT * n
+    z = torch.arange(2 * R * c, dtype=torch.float32).view(2 * R, c)
+    zz = z.view(BT, n // blk, 2, blk, c)
+    zv, zt = zz[:, :, 0].reshape(R, c), zz[:, :, 1].reshape(R, c)
+    p = torch.arange(R)
+    vrow = (p // blk) * 2 * blk + p % blk
+    assert torch.equal(zv, z[vrow]) and torch.equal(zt, z[vrow + blk])
+    # a frame's rows are contiguous: frame f owns rows [2 n f, 2 n (f + 1)) -- what lets the conv treat a frame as a batch entry
+    f = p // n
+    assert bool(((vrow >= 2 * n * f) & (vrow + blk < 2 * n * (f + 1))).all())
