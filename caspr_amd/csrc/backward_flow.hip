@@ -408,3 +408,96 @@ extern "C" int caspr_cnf_in_bwd_f32(const float *Y, const float *E, const float 
     CASPR_CHECK_LAUNCH("cnf_in_bwd");
     return CASPR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue of the ODE function's 3-channel output layer on value / tangent rows (odefunc.py:103-105 + the Hutchinson contraction of
+// odefunc.py:13-31), forward and backward in one launch each -- as torch element-wise ops these were ~25 launches per evaluation:
+//   a[p][j]  = (Zo[v(p)][j] + b[j]) gate[f][j] + beta[f][j]            (dy/dt)
+//   nd[p]    = - sum_j Zo[t(p)][j] gate[f][j] e[p][j]                    (- e^T (df/dy) e)
+// backward: dZo (2R, 4; column 3 zero), dgate / dbeta (frames, 3) summed over each frame's points in a fixed order.
+// gate / beta are rows of a wider (frames, ldg) tensor (the hyper networks' outputs of all layers side by side).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cnf_out_fwd_kernel(const float *__restrict__ Zo, int ldo, const float *__restrict__ b,
+                                                          const float *__restrict__ gate, const float *__restrict__ beta, int ldg,
+                                                          const float *__restrict__ E, long R, int n, int shift, long toff,
+                                                          float *__restrict__ A, float *__restrict__ ND)
+{
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= R) return;
+    const long f = p / n, rv = cnf_vrow(p, shift), rt = rv + toff;
+    float nd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float g = gate[f * ldg + j];
+        A[p * 3 + j] = (Zo[rv * ldo + j] + b[j]) * g + beta[f * ldg + j];
+        nd += (Zo[rt * ldo + j] * g) * E[p * 3 + j];
+    }
+    ND[p] = -nd;
+}
+
+__global__ __launch_bounds__(256) void cnf_out_bwd_kernel(const float *__restrict__ dA, const float *__restrict__ dND,
+                                                          const float *__restrict__ Zo, int ldo, const float *__restrict__ b,
+                                                          const float *__restrict__ gate, int ldg, const float *__restrict__ E, long R, int n,
+                                                          int shift, long toff, float *__restrict__ dZo, float *__restrict__ dgate,
+                                                          float *__restrict__ dbeta)
+{
+    __shared__ float s_red[4][6];
+    const long f = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[3], bb[3], acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { g[j] = gate[f * ldg + j]; bb[j] = b[j]; }
+    for (int pi = threadIdx.x; pi < n; pi += 256) {
+        const long p = f * n + pi, rv = cnf_vrow(p, shift), rt = rv + toff;
+        const float dnd = dND[p];
+        f32x4 dv = (f32x4){0.f, 0.f, 0.f, 0.f}, dt = dv;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float da = dA[p * 3 + j], dad = -dnd * E[p * 3 + j];
+            dv[j] = da * g[j];
+            dt[j] = dad * g[j];
+            acc[j] += da * (Zo[rv * ldo + j] + bb[j]) + dad * Zo[rt * ldo + j];
+            acc[3 + j] += da;
+        }
+        st4(dZo + rv * 4, dv);
+        st4(dZo + rt * 4, dt);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = wave_sum_f(acc[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_red[wave][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const float t = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+        if (threadIdx.x < 3) dgate[f * 3 + threadIdx.x] = t;
+        else dbeta[f * 3 + threadIdx.x - 3] = t;
+    }
+}
+
+extern "C" int caspr_cnf_out_f32(const float *Zo, int ldo, const float *b, const float *gate, const float *beta, int ldg, const float *E, long R,
+                                 int n, long blk, float *A, float *ND, void *stream)
+{
+    CASPR_REQUIRE(Zo && b && gate && beta && E && A && ND && R > 0 && n > 0 && R % n == 0 && ldo >= 3 && ldg >= 3, "cnf_out: bad arguments");
+    const int shift = cnf_blk_shift(R, blk);
+    CASPR_REQUIRE(shift >= -1, "cnf_out: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
+    cnf_out_fwd_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(Zo, ldo, b, gate, beta, ldg, E, R, n, shift, blk, A, ND);
+    CASPR_CHECK_LAUNCH("cnf_out");
+    return CASPR_OK;
+}
+
+extern "C" int caspr_cnf_out_bwd_f32(const float *dA, const float *dND, const float *Zo, int ldo, const float *b, const float *gate, int ldg,
+                                     const float *E, long R, int n, long blk, float *dZo, float *dgate, float *dbeta, void *stream)
+{
+    CASPR_REQUIRE(dA && dND && Zo && b && gate && E && dZo && dgate && dbeta && R > 0 && n > 0 && R % n == 0 && ldo >= 3 && ldg >= 3 &&
+                      ((uintptr_t)dZo % 16) == 0,
+                  "cnf_out_bwd: bad arguments");
+    const int shift = cnf_blk_shift(R, blk);
+    CASPR_REQUIRE(shift >= -1, "cnf_out_bwd: blk=%ld must be R or a power of two that divides R=%ld", blk, R);
+    const long frames = R / n;
+    CASPR_REQUIRE(frames <= 2147483647L, "cnf_out_bwd: too many frames");
+    cnf_out_bwd_kernel<<<dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream>>>(dA, dND, Zo, ldo, b, gate, ldg, E, R, n, shift, blk, dZo, dgate,
+                                                                                     dbeta);
+    CASPR_CHECK_LAUNCH("cnf_out_bwd");
+    return CASPR_OK;
+}

@@ -83,6 +83,8 @@ SIGNATURES = {
                                   c_stream]),
     "caspr_cnf_act_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_long, c_int, c_int, c_long, c_fp, c_int, c_stream]),
     "caspr_cnf_act_bwd_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_long, c_int, c_int, c_long, c_fp, c_int, c_fp, c_fp, c_stream]),
+    "caspr_cnf_out_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_long, c_int, c_long, c_fp, c_fp, c_stream]),
+    "caspr_cnf_out_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_long, c_int, c_long, c_fp, c_fp, c_fp, c_stream]),
     "caspr_cnf_act_bwd_out_f32": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_long, c_int, c_int, c_long, c_fp, c_int, c_fp, c_fp, c_stream]),
     "caspr_conv1x1_cnf_act_bf16x6_f32": (c_int, [ctypes.c_void_p, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_stream]),
     "caspr_conv1x1_cnf_act_bwd_ws_bytes": (c_long, [c_int, c_int, c_int]),

@@ -211,6 +211,43 @@ class CnfLayerOut(torch.autograd.Function):
         return dx, dw, (gate * dbeta).sum(dim=0), dgate, dbeta, dwo, None
 
 
+class CnfOut(torch.autograd.Function):
+    """Epilogue of the 3-channel output layer (caspr_cnf_out_f32 / _bwd_f32): zo (2R, 3) [a view of the conv's 4-wide rows], b (3),
+    gate / beta (frames, 3) [column slices of the all-layer tensors: passed with their row stride], e (R, 3) ->
+    a (BT, n, 3) = dy/dt and nd (BT, n, 1) = - e^T (df/dy) e.  One launch each way instead of ~25 element-wise ones."""
+
+    @staticmethod
+    def forward(ctx, zo, b, gate, beta, e_rows, n, blk):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        R = e_rows.shape[0]
+        if zo.stride(1) != 1 or gate.stride(1) != 1 or beta.stride(1) != 1 or gate.stride(0) != beta.stride(0):
+            raise ValueError("CnfOut: unit column strides and a common row stride of gate / beta are required")
+        b = b.detach().contiguous()
+        a = torch.empty(R, 3, device=zo.device, dtype=torch.float32)
+        nd = torch.empty(R, 1, device=zo.device, dtype=torch.float32)
+        _lib.check(_lib.load().caspr_cnf_out_f32(_p(zo), zo.stride(0), _p(b), _p(gate), _p(beta), gate.stride(0), _p(e_rows), R, n, blk, _p(a), _p(nd),
+                                                 _stream()), "caspr_cnf_out_f32")
+        ctx.save_for_backward(zo, b, gate, e_rows)
+        ctx.n, ctx.blk = n, blk
+        return a.view(R // n, n, 3), nd.view(R // n, n, 1)
+
+    @staticmethod
+    def backward(ctx, da, dnd):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        zo, b, gate, e_rows = ctx.saved_tensors
+        R, n = e_rows.shape[0], ctx.n
+        frames = R // n
+        da, dnd = da.contiguous(), dnd.contiguous()
+        dzo = torch.empty(2 * R, 4, device=zo.device, dtype=torch.float32)
+        dgate = torch.empty(frames, 3, device=zo.device, dtype=torch.float32)
+        dbeta = torch.empty(frames, 3, device=zo.device, dtype=torch.float32)
+        _lib.check(_lib.load().caspr_cnf_out_bwd_f32(_p(da), _p(dnd), _p(zo), zo.stride(0), _p(b), _p(gate), gate.stride(0), _p(e_rows), R, n, ctx.blk,
+                                                     _p(dzo), _p(dgate), _p(dbeta), _stream()), "caspr_cnf_out_bwd_f32")
+        return dzo[:, :3], (gate * dbeta).sum(dim=0), dgate, dbeta, None, None, None
+
+
 class CnfHidden(torch.autograd.Function):
     """Both hidden layers of the ODE function and the 3-channel output product as ONE node: forward = two fused conv + activation
     launches + the output conv; backward = the output layer's data gradient inside the last layer's activation backward (as
@@ -432,6 +469,7 @@ def latent_solve_layers(lat, z0, times):
     return torch.stack(outs, dim=1)
 
 
+OUT_NODE = __import__("os").environ.get("CASPR_CNF_OUT_NODE", "1") != "0"      # 0: the output layer's epilogue in torch element-wise ops
 HIDDEN_NODE = __import__("os").environ.get("CASPR_CNF_NODE", "1") != "0"      # 0: CnfLayer + CnfLayerOut (A/B timing, debugging)
 LATENT_NODE = __import__("os").environ.get("CASPR_LATENT_NODE", "1") != "0"     # 0: the per-layer form (A/B timing, debugging)
 
@@ -509,12 +547,14 @@ def cnf_block_train(block, x, context, logpx, e):
             if i < 3:
                 h = CnfAct.apply(z, l._layer.bias, gate, bias, n, blk)    # fused gate + softplus on value / tangent rows
             else:                                                         # 512 -> 3 output layer: (BT,n,3) tensors
-                cout = l._layer.weight.shape[0]
-                zz = z.view(R // blk, 2, blk, cout)                       # row layout: blocks of blk value rows | their tangent rows
-                a = (zz[:, 0].reshape(BT, n, cout) + l._layer.bias) * gate.unsqueeze(1) + bias.unsqueeze(1)
-                ad = zz[:, 1].reshape(BT, n, cout) * gate.unsqueeze(1)
-        div = (ad * e).sum(dim=-1, keepdim=True)
-        return a, -div
+                if OUT_NODE:
+                    a, nd = CnfOut.apply(z, l._layer.bias, gate, bias, e_rows, n, blk)    # (zv + b) g + beta,  - sum_j zt_j g_j e_j
+                else:                                                     # the same in torch element-wise ops (A/B timing, debugging)
+                    cout = l._layer.weight.shape[0]
+                    zz = z.view(R // blk, 2, blk, cout)
+                    a = (zz[:, 0].reshape(BT, n, cout) + l._layer.bias) * gate.unsqueeze(1) + bias.unsqueeze(1)
+                    nd = -((zz[:, 1].reshape(BT, n, cout) * gate.unsqueeze(1)) * e).sum(dim=-1, keepdim=True)
+        return a, nd
 
     t_end = block.sqrt_end_time * block.sqrt_end_time if block.train_T else torch.tensor(float(block.T), device=x.device)
     steps = block.rk4_steps

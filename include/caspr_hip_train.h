@@ -128,6 +128,15 @@ int caspr_cnf_act_bwd_out_f32(const float *Z, int ldz, const float *b, const flo
                               const float *dZo, int ldo, const float *Wo, int ldw, long R, int n, int C, long blk,
                               float *dZ, int lddz, float *dgate, float *dbeta, void *stream);
 
+/* Epilogue of the ODE function's 3-channel output layer (odefunc.py:103-105 and the Hutchinson contraction of odefunc.py:13-31) on
+ * the rows of Zo (2R, ldo >= 3) in the row layout blk: a (R,3) = (Zo_value + b) gate[f] + beta[f], nd (R) = - sum_j Zo_tangent_j
+ * gate[f]_j e_j.  gate / beta: rows of a (frames, ldg) tensor.  Backward: dZo (2R, 4) (column 3 zero), dgate / dbeta (frames, 3).  */
+int caspr_cnf_out_f32(const float *Zo, int ldo, const float *b, const float *gate, const float *beta, int ldg,
+                      const float *E, long R, int n, long blk, float *A, float *ND, void *stream);
+int caspr_cnf_out_bwd_f32(const float *dA, const float *dND, const float *Zo, int ldo, const float *b, const float *gate,
+                          int ldg, const float *E, long R, int n, long blk, float *dZo, float *dgate, float *dbeta,
+                          void *stream);
+
 /* A hidden layer of the ODE function in one launch (diffeq_layers.py:83-90 + odefunc.py:98-105 on value and tangent rows):
  * Z = X W^T on the bf16x6 conv kernel (wpk: caspr_pack_weight_bf16x3 of W (Cout, Cin)), H = the gated softplus of
  * caspr_cnf_act_f32 applied in the conv's epilogue.  X (2 frames n, ldx), Z, H in the row layout blk = 32; n % 64 == 0,
