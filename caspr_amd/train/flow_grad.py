@@ -211,6 +211,35 @@ class CnfLayerOut(torch.autograd.Function):
         return dx, dw, (gate * dbeta).sum(dim=0), dgate, dbeta, dwo, None
 
 
+class SplitLayers(torch.autograd.Function):
+    """(gate, bias) of all layers of one evaluation, stored LAYER-MAJOR in two 1-D tensors ([layer][frame][channel]) -> the per-layer
+    (frames, C_l) tensors as contiguous VIEWS.  The gradient comes back as ONE concatenation per tensor.  (Column slices of a
+    (frames, sum C) tensor cost a copy per layer and tensor on the way in and a zero-fill + copy each on the way back: 22
+    launches per evaluation.)"""
+
+    @staticmethod
+    def forward(ctx, gate_lm, bias_lm, BT, widths):
+        outs, off = [], 0
+        for w in widths:
+            outs.append(gate_lm[off:off + BT * w].view(BT, w))
+            off += BT * w
+        off = 0
+        for w in widths:
+            outs.append(bias_lm[off:off + BT * w].view(BT, w))
+            off += BT * w
+        ctx.BT, ctx.widths = BT, widths
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        L = len(ctx.widths)
+        def cat(gs):
+            gs = [g.reshape(-1) if g is not None else torch.zeros(ctx.BT * w, device=ref.device, dtype=ref.dtype) for g, w in zip(gs, ctx.widths)]
+            return torch.cat(gs)
+        ref = next(g for g in grads if g is not None)
+        return cat(grads[:L]), cat(grads[L:]), None, None
+
+
 class CnfOut(torch.autograd.Function):
     """Epilogue of the 3-channel output layer (caspr_cnf_out_f32 / _bwd_f32): zo (2R, 3) [a view of the conv's 4-wide rows], b (3),
     gate / beta (frames, 3) [column slices of the all-layer tensors: passed with their row stride], e (R, 3) ->
@@ -509,10 +538,11 @@ def cnf_block_train(block, x, context, logpx, e):
         tg.append(wg[:, 0])
         tb.append(wb[:, 0])
         widths.append(wg.shape[0])
-    G_all, Bb_all, tg_all, tb_all = torch.cat(G, dim=1), torch.cat(Bb, dim=1), torch.cat(tg), torch.cat(tb)
-    offs = [0]
-    for w_ in widths:
-        offs.append(offs[-1] + w_)
+    # layer-major 1-D tensors ([layer][frame][channel]): one element-wise update per evaluation for all layers, per-layer contiguous views
+    G_lm, Bb_lm = torch.cat([g.reshape(-1) for g in G]), torch.cat([b_.reshape(-1) for b_ in Bb])
+    tg_lm = torch.cat([v.unsqueeze(0).expand(BT, -1).reshape(-1) for v in tg])
+    tb_lm = torch.cat([v.unsqueeze(0).expand(BT, -1).reshape(-1) for v in tb])
+    widths = tuple(widths)
     e_rows = e.reshape(BT * n, 3)
     # row layout of the (2R, C) tensors of this solve (include/caspr_hip_train.h): blocks of 32 value rows + the tangent rows of the
     # same points when the hidden layers run with the activation in the conv's epilogue (CnfLayer), [values | tangents] otherwise
@@ -522,10 +552,9 @@ def cnf_block_train(block, x, context, logpx, e):
     def func(t, y, _lp):
         R = BT * n
         h = None
-        gate_all = torch.sigmoid(G_all + t * tg_all)                      # (BT, sum C): context part + time column
-        bias_all = Bb_all + t * tb_all
+        parts = SplitLayers.apply(torch.sigmoid(G_lm + t * tg_lm), Bb_lm + t * tb_lm, BT, widths)   # context part + time column
         for i, l in enumerate(layers):
-            gate, bias = gate_all[:, offs[i]:offs[i + 1]], bias_all[:, offs[i]:offs[i + 1]]
+            gate, bias = parts[i], parts[len(layers) + i]
             if i == 0:                                                    # 3 -> C: fused product + gate + softplus, value | tangent rows
                 h = CnfIn.apply(y.reshape(R, 3), e_rows, l._layer.weight, l._layer.bias, gate, bias, n, blk)
                 continue
@@ -538,7 +567,7 @@ def cnf_block_train(block, x, context, logpx, e):
             if i == 1 and fused:                                          # both hidden layers + the output product: one node
                 l2 = layers[2]
                 z = CnfHidden.apply(h, l._layer.weight, l._layer.bias, gate, bias, l2._layer.weight, l2._layer.bias,
-                                    gate_all[:, offs[2]:offs[3]], bias_all[:, offs[2]:offs[3]], layers[3]._layer.weight, n)
+                                    parts[2], parts[len(layers) + 2], layers[3]._layer.weight, n)
                 continue
             if i == 2 and fused:
                 continue
