@@ -421,13 +421,14 @@ class LatentSolve(torch.autograd.Function):
         outs, z, hs = [z0], z0.detach(), []
         for k in range(1, tt.shape[0]):
             h = (tt[k] - tt[k - 1]) / steps
+            hh = (h, 0.5 * h, h / 3.0, h / 6.0)         # 0-dim device tensors, made once per interval: one fused launch per RK4 combination
             for _ in range(steps):
                 k1 = f(z)
-                k2 = f(z + 0.5 * h * k1)
-                k3 = f(z + 0.5 * h * k2)
-                k4 = f(z + h * k3)
-                z = z + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
-                hs.append(h)
+                k2 = f(torch.addcmul(z, k1, hh[1]))
+                k3 = f(torch.addcmul(z, k2, hh[1]))
+                k4 = f(torch.addcmul(z, k3, hh[0]))
+                z = torch.addcmul(z, torch.add(k1 + k4, k2 + k3, alpha=2.0), hh[3])
+                hs.append(hh)
             outs.append(z)
         ctx.tape, ctx.hs, ctx.steps, ctx.ws = tape, hs, steps, ws
         ctx.has_b = [b is not None for b in bs]
@@ -442,7 +443,7 @@ class LatentSolve(torch.autograd.Function):
 
         def fb(a, g):                              # a = (x, h1, h2, h3) of one evaluation, g = dL/d f(x) -> dL/dx
             for i in (3, 2, 1, 0):
-                d = g.contiguous() if i == 3 else g * (1.0 - a[i + 1] * a[i + 1])    # tanh' on the layer's stored output
+                d = g.contiguous() if i == 3 else torch.ops.aten.tanh_backward(g, a[i + 1])    # tanh' from the layer's stored output: one launch
                 deltas[i].append(d)
                 inputs[i].append(a[i])
                 g = ops.conv1x1(pkt[i], None, d.view(1, B, -1)).view(B, -1)[:, :ws[i].shape[1]]
@@ -452,14 +453,15 @@ class LatentSolve(torch.autograd.Function):
         e = len(tape)
         for k in range(Tu - 1, 0, -1):
             for st in range(steps):
-                h = hs[(k - 1) * steps + (steps - 1 - st)]
+                h, h2, h3, h6 = hs[(k - 1) * steps + (steps - 1 - st)]
                 a1, a2, a3, a4 = tape[e - 4], tape[e - 3], tape[e - 2], tape[e - 1]
                 e -= 4
-                g4 = fb(a4, (h / 6.0) * gz)
-                g3 = fb(a3, (h / 3.0) * gz + h * g4)
-                g2 = fb(a2, (h / 3.0) * gz + (0.5 * h) * g3)
-                g1 = fb(a1, (h / 6.0) * gz + (0.5 * h) * g2)
-                gz = gz + g4 + g3 + g2 + g1
+                g6, g3z = h6 * gz, h3 * gz
+                g4 = fb(a4, g6)
+                g3 = fb(a3, torch.addcmul(g3z, g4, h))
+                g2 = fb(a2, torch.addcmul(g3z, g3, h2))
+                g1 = fb(a1, torch.addcmul(g6, g2, h2))
+                gz = gz + (g4 + g3) + (g2 + g1)
             gz = gz + gout[:, k - 1]
         grads = []
         for i in range(4):
