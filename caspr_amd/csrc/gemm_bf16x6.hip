@@ -652,25 +652,50 @@ extern "C" long caspr_conv_gn_ws_bytes(int B, int P, int Cout)
     return (long)B * (P / X6_TP) * Cout * 16;
 }
 
+// pool: consecutive batch entries whose GroupNorm statistics are taken TOGETHER (1 = per entry).  The conv sees B entries -- each
+// with its own in_scale / in_shift / bbias row -- the statistics B / pool groups of pool x P points: the head's first layer reads
+// per-FRAME normalised PointNet++ features but normalises its own output per SEQUENCE (tpointnet2.py:96-99).  The per-tile
+// partials of consecutive entries are contiguous, so the pooled finalize is the plain one over (B / pool, pool x P / 128 tiles).
+static int conv_gn_x6_impl(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx, const float *in_scale,
+                           const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout, int G,
+                           int pool, const float *gamma, const float *beta, float eps, float *scale, float *shift, float *pmax, float *mean,
+                           float *rstd, void *ws, long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(gamma && beta && scale && shift && ws && G > 0, "conv1x1_gn_bf16x6: bad arguments");
+    CASPR_REQUIRE(Cout % G == 0, "conv1x1_gn_bf16x6: Cout=%d is not a multiple of the %d groups", Cout, G);
+    CASPR_REQUIRE((mean == nullptr) == (rstd == nullptr), "conv1x1_gn_bf16x6: mean / rstd must be given together");
+    CASPR_REQUIRE(pool >= 1 && B % pool == 0, "conv1x1_gn_bf16x6: pool=%d must divide B=%d", pool, B);
+    CASPR_REQUIRE(B <= 65535 * (long)pool, "conv1x1_gn_bf16x6: B too large");
+    CASPR_REQUIRE(P % X6_TP == 0 && ws_bytes >= caspr_conv_gn_ws_bytes(B, P, Cout) && ((uintptr_t)ws % 16) == 0,
+                  "conv1x1_gn_bf16x6: workspace too small or misaligned (%ld < %ld)", ws_bytes, caspr_conv_gn_ws_bytes(B, P, Cout));
+    const int rc = conv_x6_launch(wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, 0,
+                                  (f32x4 *)ws, stream);
+    if (rc != CASPR_OK) return rc;
+    conv_gn_finalize_kernel<<<dim3(G, B / pool), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, pool * (P / X6_TP), pool * P, Cout, G, gamma,
+                                                                                      beta, eps, scale, shift, pmax, mean, rstd);
+    CASPR_CHECK_LAUNCH("conv1x1_gn_bf16x6");
+    return CASPR_OK;
+}
+
 extern "C" int caspr_conv1x1_gn_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
                                            const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
                                            int ldy, int B, int P, int Cin, int Cout, int G, const float *gamma, const float *beta,
                                            float eps, float *scale, float *shift, float *pmax, float *mean, float *rstd, void *ws,
                                            long ws_bytes, void *stream)
 {
-    CASPR_REQUIRE(gamma && beta && scale && shift && ws && G > 0, "conv1x1_gn_bf16x6: bad arguments");
-    CASPR_REQUIRE(Cout % G == 0, "conv1x1_gn_bf16x6: Cout=%d is not a multiple of the %d groups", Cout, G);
-    CASPR_REQUIRE((mean == nullptr) == (rstd == nullptr), "conv1x1_gn_bf16x6: mean / rstd must be given together");
-    CASPR_REQUIRE(B <= 65535, "conv1x1_gn_bf16x6: B too large");
-    CASPR_REQUIRE(P % X6_TP == 0 && ws_bytes >= caspr_conv_gn_ws_bytes(B, P, Cout) && ((uintptr_t)ws % 16) == 0,
-                  "conv1x1_gn_bf16x6: workspace too small or misaligned (%ld < %ld)", ws_bytes, caspr_conv_gn_ws_bytes(B, P, Cout));
-    const int rc = conv_x6_launch(wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, 0,
-                                  (f32x4 *)ws, stream);
-    if (rc != CASPR_OK) return rc;
-    conv_gn_finalize_kernel<<<dim3(G, B), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, P / X6_TP, P, Cout, G, gamma, beta, eps,
-                                                                               scale, shift, pmax, mean, rstd);
-    CASPR_CHECK_LAUNCH("conv1x1_gn_bf16x6");
-    return CASPR_OK;
+    return conv_gn_x6_impl(wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, G, 1, gamma, beta, eps, scale,
+                           shift, pmax, mean, rstd, ws, ws_bytes, stream);
+}
+
+// ... with the statistics pooled over `pool` consecutive batch entries: scale / shift / pmax (B / pool, Cout), mean / rstd (B / pool, G)
+extern "C" int caspr_conv1x1_gn_pooled_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
+                                                  const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y,
+                                                  int ldy, int B, int P, int Cin, int Cout, int G, int pool, const float *gamma,
+                                                  const float *beta, float eps, float *scale, float *shift, float *pmax, float *mean,
+                                                  float *rstd, void *ws, long ws_bytes, void *stream)
+{
+    return conv_gn_x6_impl(wpk, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, G, pool, gamma, beta, eps,
+                           scale, shift, pmax, mean, rstd, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

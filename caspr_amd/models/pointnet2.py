@@ -388,10 +388,12 @@ class PointNet2feat(nn.Module):
             out["nn_ready"].record()
         return out
 
-    def run(self, xyz, feat, C, out=None, record=None, idx=None, feat_kind=0):
+    def run(self, xyz, feat, C, out=None, record=None, idx=None, feat_kind=0, stop_before_last=False):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels.  -> (B,n,num_classes)
         written into `out` (may be a column slice of a wider buffer) if given.  `idx` = precomputed self.indices(xyz);
-        feat_kind: what the input features of the FIRST level are (ops.FEAT_QUAD | ops.FEAT_PAIRS), see ops.sa_mlp_max."""
+        feat_kind: what the input features of the FIRST level are (ops.FEAT_QUAD | ops.FEAT_PAIRS), see ops.sa_mlp_max.
+        stop_before_last: return (raw output of final_layers[0] [in `out`], its GroupNorm scale, shift) -- the operand of the last,
+        purely linear layer (pointnet2.py:247), for a caller that folds that layer into its own first layer (TPointNet2)."""
         if idx is None:
             idx = self.indices(xyz)
         xyz_list, feat_list, ch_list = [xyz], [feat], [C]
@@ -410,7 +412,9 @@ class PointNet2feat(nn.Module):
             target -= 1
         c0, gn, c3 = self.final_layers[0], self.final_layers[1], self.final_layers[3]
         y, s, t = ops.conv1x1_gn(self._packed_final(0), c0.bias, prev.raw, gn.weight, gn.bias, in_scale=prev.scale, in_shift=prev.shift,
-                                 in_relu=prev.relu)
+                                 in_relu=prev.relu, out=out if stop_before_last else None)
+        if stop_before_last:
+            return y, s, t
         return ops.conv1x1(self._packed_final(3), c3.bias, y, in_scale=s, in_shift=t, in_relu=True, out=out)  # :247
 
     def forward(self, points):

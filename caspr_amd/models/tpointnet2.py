@@ -80,8 +80,16 @@ class TPointNet2(nn.Module):
             w = self.conv1.weight.detach()[:, :, 0]
             w_pt = torch.cat([w[:, :L], w[:, L + G:]], dim=1).contiguous()       # columns of [local | point feature]
             w_g = w[:, L:L + G].contiguous()                                     # columns of the tiled global feature
-            return ops.PackedWeight(w_pt), ops.PackedWeight(w_g)
-        p1 = self._cache.get("conv1", [self.conv1.weight], build)
+            # PointNet++'s last layer is a plain conv (pointnet2.py:247: no norm, no activation behind it) and conv1 is linear in
+            # it: conv1(W_f h + b_f) = (W1_local W_f) h + W1_local b_f.  Folded weight (f64 product, rounded once) + bias term: the
+            # 512 -> 512 layer over all B T N points (0.9 ms of the cfg-2 step) is never run
+            f3 = self.local_extract.final_layers[3]
+            wl = w[:, :L].double()
+            w_fold = torch.cat([(wl @ f3.weight.detach()[:, :, 0].double()).float(), w[:, L + G:]], dim=1).contiguous()
+            b_fold = (wl @ f3.bias.detach().double()).float().contiguous()
+            return ops.PackedWeight(w_pt), ops.PackedWeight(w_g), ops.PackedWeight(w_fold), b_fold
+        f3_ = self.local_extract.final_layers[3]
+        p1 = self._cache.get("conv1", [self.conv1.weight, f3_.weight, f3_.bias], build)
         p2 = self._cache.get("conv2", [self.conv2.weight],
                              lambda: ops.PackedWeight(self.conv2.weight.detach()[:, :, 0].contiguous()))
         p3 = None
@@ -135,18 +143,34 @@ class TPointNet2(nn.Module):
         # local spatial feature per time step (tpointnet2.py:79-93)
         with ops.timed("enc_local_pointnet2"):
             kind = (ops.FEAT_QUAD if self.augment_quad else 0) | (ops.FEAT_PAIRS if self.augment_pairs else 0)
-            self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record, idx=idx, feat_kind=kind)
+            # fold: PointNet++'s last (purely linear) layer lives inside conv1's weight (_head_weights), so the local branch stops at
+            # that layer's operand -- the raw output of final_layers[0] with its per-FRAME GroupNorm + ReLU still to be applied
+            fold = self.record is None
+            loc = self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record, idx=idx, feat_kind=kind,
+                                         stop_before_last=fold)
         t_head = ops.timed("enc_head")
         t_head.__enter__()
 
-        (w_pt, w_g), p2, p3 = self._head_weights()
+        (w_pt, w_g, w_fold, b_fold), p2, p3 = self._head_weights()
         # conv1 over [local | global max (tiled) | point feature]  (tpointnet2.py:96-99)
         bbias = ops.conv1x1(w_g, self.conv1.bias, gmax.view(B, 1, -1))                        # (B,1,1600)
-        ones = torch.ones(B, L, device=x.device, dtype=torch.float32)
-        in_scale = torch.cat([ones, pf.scale], dim=1).contiguous()
-        in_shift = torch.cat([torch.zeros_like(ones), pf.shift], dim=1).contiguous()
-        y1, s1, t1 = ops.conv1x1_gn(w_pt, None, X1, self.bn1.weight, self.bn1.bias, bbias=bbias.view(B, -1), in_scale=in_scale,
-                                    in_shift=in_shift, in_relu=True, in_relu_from=L)
+        if fold:
+            # the conv runs over FRAMES (its local operand is normalised per frame), its own statistics pool the T frames of a
+            # sequence (bn1 normalises over all T N points); the per-sequence rows are repeated per frame (small (B T, .) tensors)
+            _, s_f, t_f = loc
+            rep = lambda v: v.repeat_interleave(T, dim=0)
+            in_scale = torch.cat([s_f, rep(pf.scale)], dim=1).contiguous()
+            in_shift = torch.cat([t_f, rep(pf.shift)], dim=1).contiguous()
+            bb = rep(bbias.view(B, -1)[:, :self.conv1.out_channels] + b_fold).contiguous()
+            y1, s1, t1 = ops.conv1x1_gn(w_fold, None, X1.view(B * T, N, L + S), self.bn1.weight, self.bn1.bias, bbias=bb, in_scale=in_scale,
+                                        in_shift=in_shift, in_relu=True, in_relu_from=0, pool=T)
+            y1 = y1.view(B, P, y1.shape[2])
+        else:
+            ones = torch.ones(B, L, device=x.device, dtype=torch.float32)
+            in_scale = torch.cat([ones, pf.scale], dim=1).contiguous()
+            in_shift = torch.cat([torch.zeros_like(ones), pf.shift], dim=1).contiguous()
+            y1, s1, t1 = ops.conv1x1_gn(w_pt, None, X1, self.bn1.weight, self.bn1.bias, bbias=bbias.view(B, -1), in_scale=in_scale,
+                                        in_shift=in_shift, in_relu=True, in_relu_from=L)
         y2, s2, t2, z0 = ops.conv1x1_gn(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, want_max=True,
                                         in_scale=s1, in_shift=t1, in_relu=True)               # :99-100, 111
         del y1

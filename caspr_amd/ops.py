@@ -355,7 +355,7 @@ def gn_stats(y, C, gamma, beta, groups=16, eps=1e-5, want_max=False):
 
 
 def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, want_moments=False, write=True, bbias=None,
-               in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, out=None):
+               in_scale=None, in_shift=None, in_relu=False, in_relu_from=0, out=None, pool=1):
     """conv1x1 followed by the statistics of the GroupNorm on its output (the model's conv -> GroupNorm -> ReLU block):
     -> (y | None, scale (B,C), shift (B,C)[, mean (B,G), rstd (B,G)][, pmax (B,C)]).  On the bf16x6 path the statistics come
     out of the conv's epilogue (caspr_conv1x1_gn_bf16x6_f32) and `write=False` skips the output altogether; otherwise this is
@@ -363,12 +363,17 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
     _chk_f32(bias, bbias, in_scale, in_shift, gamma, beta)
     B, P, _ = x.shape
     C = pw.cout
+    # pool: the statistics are taken over `pool` consecutive batch entries together (-> (B / pool, C) outputs) while in_scale /
+    # in_shift / bbias stay per entry (caspr_conv1x1_gn_pooled_bf16x6_f32)
+    if pool < 1 or B % pool:
+        raise ValueError("conv1x1_gn: pool=%d must divide the %d batch entries" % (pool, B))
     if not (CONV_BF16X6 and pw.x6_gn_ok and P % 128 == 0 and C % groups == 0 and in_relu_from % 8 == 0):
         y = conv1x1(pw, bias, x, bbias=bbias, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, in_relu_from=in_relu_from, out=out)
+        yg = y.view(B // pool, pool * P, y.shape[2]) if pool > 1 else y
         if want_moments:
             from . import train_ops
-            return (y,) + tuple(train_ops.gn_stats_train(y, C, gamma, beta, groups, eps, want_max))
-        return (y,) + tuple(gn_stats(y, C, gamma, beta, groups, eps, want_max))
+            return (y,) + tuple(train_ops.gn_stats_train(yg, C, gamma, beta, groups, eps, want_max))
+        return (y,) + tuple(gn_stats(yg, C, gamma, beta, groups, eps, want_max))
     ldx = _chk_rows(x)
     if x.shape[2] < pw.cin and ldx < (pw.cin + 3) // 4 * 4:
         raise ValueError("conv1x1_gn: input rows hold %d channels, weight needs %d" % (x.shape[2], pw.cin))
@@ -377,13 +382,26 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
     if write or out is not None:
         y = out if out is not None else torch.empty(B, P, (C + 3) // 4 * 4, device=dev, dtype=torch.float32)
     ldy = _chk_rows(y) if y is not None else 0
-    scale = torch.empty(B, C, device=dev, dtype=torch.float32)
-    shift = torch.empty(B, C, device=dev, dtype=torch.float32)
-    mean = torch.empty(B, groups, device=dev, dtype=torch.float32) if want_moments else None
-    rstd = torch.empty(B, groups, device=dev, dtype=torch.float32) if want_moments else None
-    pmax = torch.empty(B, C, device=dev, dtype=torch.float32) if want_max else None
+    Bs = B // pool
+    scale = torch.empty(Bs, C, device=dev, dtype=torch.float32)
+    shift = torch.empty(Bs, C, device=dev, dtype=torch.float32)
+    mean = torch.empty(Bs, groups, device=dev, dtype=torch.float32) if want_moments else None
+    rstd = torch.empty(Bs, groups, device=dev, dtype=torch.float32) if want_moments else None
+    pmax = torch.empty(Bs, C, device=dev, dtype=torch.float32) if want_max else None
     L = _lib.load()
     ws = _workspace(L.caspr_conv_gn_ws_bytes(B, P, C), dev)
+    if pool > 1:
+        with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):
+            _lib.check(L.caspr_conv1x1_gn_pooled_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                                            int(in_relu_from), _p(y), ldy, B, P, pw.cin, C, groups, int(pool), _p(gamma), _p(beta),
+                                                            float(eps), _p(scale), _p(shift), _p(pmax), _p(mean), _p(rstd), _p(ws), ws.numel(),
+                                                            _stream()), "caspr_conv1x1_gn_pooled_bf16x6_f32")
+        res = (y, scale, shift)
+        if want_moments:
+            res += (mean, rstd)
+        if want_max:
+            res += (pmax,)
+        return res
     if CONV_X6W and pw.x6w_ok:
         main, tail = pw.xw()
         with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):

@@ -153,6 +153,16 @@ int caspr_conv1x1_gn_bf16x6_f32(const void *wpk, const float *bias, const float 
                                 float *Y, int ldy, int B, int P, int Cin, int Cout, int G, const float *gamma,
                                 const float *beta, float eps, float *scale, float *shift, float *pmax, float *mean,
                                 float *rstd, void *ws, long ws_bytes, void *stream);
+/* ... with the statistics POOLED over `pool` consecutive batch entries (scale / shift / pmax (B / pool, Cout), mean / rstd
+ * (B / pool, G)) while in_scale / in_shift / bbias stay per entry: the head's first layer (tpointnet2.py:96-99) normalises its
+ * output per SEQUENCE but reads PointNet++ features whose GroupNorm (pointnet2.py:247) is per FRAME -- with the last, purely
+ * linear PointNet++ layer folded into this layer's weight (caspr_amd/models/tpointnet2.py), its input is that GroupNorm's raw
+ * operand, so the conv runs over frames (B = frames, P = points per frame) and pools T frames per statistic.            */
+int caspr_conv1x1_gn_pooled_bf16x6_f32(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx,
+                                       const float *in_scale, const float *in_shift, int in_relu, int in_relu_from,
+                                       float *Y, int ldy, int B, int P, int Cin, int Cout, int G, int pool,
+                                       const float *gamma, const float *beta, float eps, float *scale, float *shift,
+                                       float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream);
 
 /* The same two contracts for the LARGE layers (>= 512 output channels: the 1600-wide head convs of tpointnet2.py:96-105, the
  * 512-wide feature-propagation / final layers of pointnet2.py:525,247), csrc/gemm_bf16x6w.hip: workgroup tile 128 points x

@@ -189,14 +189,18 @@ def _budget(seeded_sd, ops, CaSPR, Lazy, dev):
     def head_with_local(local_feat):
         orig = le.run
 
-        def fake_run(xyz_, feat_, C_, out=None, record=None, idx=None, feat_kind=0):
+        def fake_run(xyz_, feat_, C_, out=None, record=None, idx=None, feat_kind=0, stop_before_last=False):
+            assert not stop_before_last
             out.copy_(local_feat.view(out.shape))
             return out
         le.run = fake_run
-        try:
+        rec = enc.record
+        enc.record = []        # the recording path keeps PointNet++'s last layer apart from the head's first (no weight fold): the local
+        try:                   # features given here ARE that layer's output
             return enc(xd)
         finally:
             le.run = orig
+            enc.record = rec
     z0_loc, tn_loc = head_with_local(f32d(t64["local"]))
     z0_acc, tn_acc = enc(xd)
     put("z0", err(z0_loc, t64["z0"]), err(z0_acc, t64["z0"]), 1e-5, t64["z0"])
@@ -212,7 +216,7 @@ def _budget(seeded_sd, ops, CaSPR, Lazy, dev):
     x_acc = m.decode(lat_acc, NS, y=yb)[2]
     put("cnf_x", err(x_loc, t64["cnf_x"]), err(x_acc, t64["cnf_x"]), 3e-6, t64["cnf_x"])
     # the raw 1600-wide head convolutions (not asserted: reported to size the accumulation error of K = 1600 sums)
-    (w_pt, w_g), p2, _ = enc._head_weights()
+    (w_pt, w_g, _w_fold, _b_fold), p2, _ = enc._head_weights()
     for name in ("head_conv1_raw", "head_conv2_raw"):
         out[name] = {"local": None, "local_bound": None, "accumulated": None, "oracle32_accumulated": err(t32[name], t64[name]),
                      "absmax": float(t64[name].abs().max())}

@@ -708,6 +708,35 @@ def test_encode_parity_cars(dev, seeded_sd, sd64, model):
 
 
 @pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+@pytest.mark.parametrize("B,T,N", [(2, 3, 1024), (1, 2, 1000)])
+def test_head_fold_matches_the_separate_last_layer(dev, seeded_sd, sd64, model, mode, B, T, N):
+    """The encoder with PointNet++'s last (purely linear) layer folded into the head's first conv (conv over frames, statistics
+    pooled per sequence: the default path) against the same encoder with the two layers apart (the recording path), and both
+    against the f64 evaluation: z0 and T-NOCS.  N = 1000 takes the conv + separate-statistics fallback of the pooled call."""
+    from caspr_amd import ops
+    prev = ops.set_matmul_mode(mode)
+    try:
+        x, _ = car_sequences(B, T, N, seed=77)
+        z64, t64 = O.encode(sd64, x.double())
+        gz0, gt = model.encode(x.to(dev))
+        model.encoder.record = []
+        sz0, st = model.encode(x.to(dev))
+        model.encoder.record = None
+    finally:
+        ops.set_matmul_mode(conv=prev[0], cnf=prev[1])
+    scale = float(z64.abs().max())
+    record("head_fold_vs_separate_z0_%s_%d" % (mode, N), gz0, sz0, 2e-5 * max(1.0, scale))
+    record("head_fold_vs_separate_tnocs_%s_%d" % (mode, N), gt, st, 5e-6)
+    # ... and the fold is no further from the f64 evaluation than the separate layers are (the input's own conditioning is the
+    # business of test_encode_parity_*: the default path there IS the folded one)
+    for nm, g, sref, w64 in (("tnocs", gt, st, t64), ("z0", gz0, sz0, z64)):
+        e_fold = float((g.cpu().double() - w64).abs().max())
+        e_sep = float((sref.cpu().double() - w64).abs().max())
+        REPORT["head_fold_vs_f64_%s_%s_%d" % (nm, mode, N)] = {"fold": e_fold, "separate": e_sep}
+        assert e_fold <= e_sep + 3e-6 * max(1.0, float(w64.abs().max())), (nm, e_fold, e_sep)
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
 def test_reconstruct_dense_vs_oracle(dev, seeded_sd, model, mode):
     """encode -> advect -> sample on the well-conditioned input: T-NOCS and sampled xyz within 1e-5 of the oracle, with the
     matrix products on the default bf16x6 kernels and on the f32 MFMA kernels (ops.set_matmul_mode)."""
