@@ -246,6 +246,7 @@ def main():
                                  "library": collective_library() if world > 1 else None},
                        "base_samples": "drawn in-step (CPU generator, models/utils.py:25), pinned buffer + async copy under the encoder",
                        "matrix_products": mode, "calibration": calibration,
+                       "box": box_calibration() if (world == 1 and not args.no_cpu_baseline) else None,
                        "nfe": [int(v) for v in model.get_nfe()]},
             "roofline": roofline, "f32_mfma_path": f32_block, "cpu_baseline": cpu, "parity_ok": parity_ok, "stage_ms_per_step": breakdown,
         }))
@@ -295,6 +296,29 @@ def kernel_rooflines(cnf, detail, traffic_table, shape):
                     "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(a_sa / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
                     "launches_per_step": sum(len(ms) for _, ms in sa) // 2, "ms_per_step": round(ms_all / 2, 3)})
     return out
+
+
+def box_calibration():
+    """Bare v_mfma_f32_32x32x16_bf16 rate of THIS box on the operand mix of the bf16x6 scheme (tools/micro/mfma_power, ~100 ms per
+    variant, built by __graft_entry__.build()): the boxes of the pool differ by 3-5 % in what their matrix pipes sustain under the
+    power cap, and the headline moves with it.  None if the binary is not there."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "micro", "mfma_power")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout
+        rate = {}
+        for line in out.splitlines():
+            p = line.split()
+            if len(p) >= 6 and p[0] == "data":
+                rate[p[1].rstrip(":")] = max(rate.get(p[1].rstrip(":"), 0.0), float(p[4]))
+        if "7" not in rate:
+            return None
+        return {"bare_mfma_bf16_tflops": {"zeros": rate.get("0"), "random_sign_exponent_mantissa": rate.get("3"), "bf16x6_operand_planes": rate.get("7")},
+                "note": "register-only MFMA loop, one wave per SIMD, ~100 ms per variant (tools/micro/mfma_power.hip); the nominal peak is 2500"}
+    except Exception:
+        return None
 
 
 def cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, ybase, times_cpu, ts, T, N, dense_sequences):
