@@ -18,7 +18,7 @@ template <int FLAGS, int FILL>
 __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc, const unsigned char *w, int rounds)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    constexpr bool DMA = FLAGS & 1, BAR = FLAGS & 2, RD = FLAGS & 4, SPREAD = FLAGS & 8, NOWAIT = FLAGS & 16, NOBAR = FLAGS & 32, QUIET = FLAGS & 64, PAIRS = FLAGS & 128;
+    constexpr bool DMA = FLAGS & 1, BAR = FLAGS & 2, RD = FLAGS & 4, SPREAD = FLAGS & 8, NOWAIT = FLAGS & 16, NOBAR = FLAGS & 32, QUIET = FLAGS & 64, PAIRS = FLAGS & 128, AMAJOR = FLAGS & 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     f32x16 c[4] = {};
@@ -90,8 +90,14 @@ __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc,
                     if (r == 3 && i == 5) dma1(s + 4, 0);
                     if (r == 3 && i == 9) dma1(s + 4, 1);
                 }
+                // product order: the kernel's (smallest terms first, the two row tiles alternating) or, flag 256, A-major: the three products
+                // of one weight fragment back to back (same A operand in consecutive MFMAs), one row tile after the other
                 constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-                c[(i & 1) + 2 * (r & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r & 1][i & 1][TA[i >> 1]], b[TB[i >> 1]], c[(i & 1) + 2 * (r & 1)], 0, 0, 0);
+                constexpr int MA[6] = {2, 1, 1, 0, 0, 0}, MB[6] = {0, 0, 1, 0, 1, 2};
+                if (AMAJOR)
+                    c[(i / 6) + 2 * (r & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r & 1][i / 6][MA[i % 6]], b[MB[i % 6]], c[(i / 6) + 2 * (r & 1)], 0, 0, 0);
+                else
+                    c[(i & 1) + 2 * (r & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r & 1][i & 1][TA[i >> 1]], b[TB[i >> 1]], c[(i & 1) + 2 * (r & 1)], 0, 0, 0);
                 FENCE;
                 if (RD) {
                     if (r < 3 && i < 6) f[(r + 1) & 1][i / 3][i % 3] = *(const bf16x8 *)(A + ((r + 1) * 6 + i) * 1024);
@@ -166,6 +172,9 @@ int main(int argc, char **argv)
     run<64 | 4 | 2 | 1, 5>("  ... fill in slots 1,3,4,6,7,9,10 only", out, cyc, w);
     run<128 | 64 | 4 | 2 | 1, 0>("skeleton, DMA in three pairs (slots 7 / 8 / 9 of regions 0 / 1 / 3)", out, cyc, w);
     run<128 | 64 | 4 | 2 | 1, 3>("  ... fill in slots 1,3,4,6,7,9,10 only", out, cyc, w);
+    run<256 | 64 | 4 | 2 | 1, 0>("quiet-slot skeleton, A-major product order", out, cyc, w);
+    run<256 | 64 | 4 | 2 | 1, 3>("  ... fill in slots 1,3,4,6,7,9,10 only", out, cyc, w);
+    run<256 | 0, 0>("MFMA only, A-major product order", out, cyc, w);
     run<64 | 4, 4>("no DMA, no barrier, fill in slots 1,3,4,6,7,9,10", out, cyc, w);
     run<64 | 4, 5>("no DMA, no barrier, fill in slots 1,3,4,6,7,9,10", out, cyc, w);
     run<4 | 2 | 1, 1>("skeleton", out, cyc, w);
