@@ -528,3 +528,26 @@ def test_cnf_row_layout_views_match_the_kernel_formula():
     # a frame's rows are contiguous: frame f owns rows [2 n f, 2 n (f + 1)) -- what lets the conv treat a frame as a batch entry
     f = p // n
     assert bool(((vrow >= 2 * n * f) & (vrow + blk < 2 * n * (f + 1))).all())
+
+
+def test_bench_box_calibration_is_optional_and_parses_the_micro_benchmark(tmp_path, monkeypatch):
+    """bench.py's config.box: None when tools/micro/mfma_power is not built or fails; otherwise the best rate per operand kind."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    real_exists = os.path.exists
+    monkeypatch.setattr(os.path, "exists", lambda p: False if p.endswith("mfma_power") else real_exists(p))
+    assert bench.box_calibration() is None
+    monkeypatch.setattr(os.path, "exists", lambda p: True if p.endswith("mfma_power") else real_exists(p))
+
+    class R:
+        stdout = "\n".join(["data 0:    88.44 ms   2428.2 TFLOP/s  (= 2.316 GHz effective at 32 cycles / MFMA)",
+                            "data 3:   121.16 ms   1772.4 TFLOP/s  (= 1.690 GHz)", "data 3:   121.77 ms   1763.6 TFLOP/s  (= 1.682 GHz)",
+                            "data 7:   117.52 ms   1827.3 TFLOP/s  (= 1.743 GHz)"]) + "\n"
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    box = bench.box_calibration()
+    assert box["bare_mfma_bf16_tflops"] == {"zeros": 2428.2, "random_sign_exponent_mantissa": 1772.4, "bf16x6_operand_planes": 1827.3}
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(OSError("no such binary")))
+    assert bench.box_calibration() is None
