@@ -5,6 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
 SOURCES = ["point_ops.hip", "gemm.hip", "gemm_bf16x6.hip", "gemm_bf16x6w.hip", "sa_mlp.hip", "ode.hip", "ode_bf16x6.hip", "ode_bf16x6w.hip", "backward.hip", "backward_points.hip", "backward_flow.hip", "emd.hip"]
 EXTRA = {"point_ops.hip": ["-ffp-contract=off"], "emd.hip": ["-ffp-contract=off"],
          # the 64-piece product loop of the bf16x6 CNF kernel must unroll completely (static register indices)
@@ -35,12 +36,14 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     inc = os.path.join(HERE, "..", "..", "include")
     hdrs = [os.path.join(HERE, h) for h in ("common.h", "ode_x6.h", "ode_x6w_agprs.h", "x6w_common.h")] + sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
-    objs, jobs = [], []
+    objs, jobs, by_src = [], [], {}
     for s in SOURCES:
         src = os.path.join(HERE, s)
         xw = XW_EXP if (XW_EXP and s in ("ode_bf16x6w.hip", "gemm_bf16x6w.hip")) else ""
         obj = os.path.join(HERE, s.replace(".hip", (".dbg_xw%s.o" % xw) if xw else (".dbg.o" if DEBUG else ".o")))
         objs.append(obj)
+        if not xw:
+            by_src[s] = obj
         if force or _stale(obj, [src] + hdrs):
             jobs.append([HIPCC] + FLAGS + (["-DCASPR_DEBUG_HOOKS"] if DEBUG else []) + (["-DXW_EXP=%s" % xw] if xw else []) + EXTRA.get(s, []) + ["-c", src, "-o", obj])
     def run(cmd):
@@ -50,6 +53,11 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
+        # the two kernels with a hand-managed accumulator file are checked on the code object BEFORE linking: a compiler that parks
+        # values in a0..a255 or spills there would corrupt them silently (audit.py); the debug / experiment flavours carry trace hooks and switches that change the counts
+        if not DEBUG:
+            from caspr_amd.csrc import audit
+            audit.audit_objects(by_src)
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     return OUT
 

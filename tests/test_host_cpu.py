@@ -419,74 +419,44 @@ def test_bf16x6_split_is_exact_and_six_products_are_f32_accurate():
     assert float((three.double() - ref).abs().max()) > 3.0 * e32
 
 
+def _audit(src):
+    from caspr_amd.csrc import audit
+    obj = os.path.join(ROOT, "caspr_amd", "csrc", src.replace(".hip", ".o"))
+    if not (os.path.exists(obj) and audit.tools_present()):
+        pytest.skip("needs the in-tree object and the ROCm LLVM tools")
+    return audit, obj
+
+
 def test_cnf_x6w_kernel_keeps_its_accumulator_file_to_itself():
     """cnf_rk4_x6w_kernel (csrc/ode_bf16x6w.hip) manages a0..a255 by hand through inline asm; hipcc must keep out of them and
-    must not spill (a scratch reload would also drain the LDS-DMA queue with vmcnt(0)).  Checked on the code object that was
-    linked into libcaspr_hip.so: no scratch, no spills, exactly the accumulator moves the source writes (256 zeroing writes +
-    256 in-place activation writes, 256 + 256 reads in pass 0 / passes 1-3), layer 1's MFMAs on a[..] and every other MFMA in
-    the VGPR form, M0 written once per LDS-DMA statement and by nothing else."""
-    llvm = "/opt/rocm/lib/llvm/bin"
-    obj = os.path.join(ROOT, "caspr_amd", "csrc", "ode_bf16x6w.o")
-    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
-        pytest.skip("needs the in-tree object and the ROCm LLVM tools")
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        fat, elf = os.path.join(d, "w.fatbin"), os.path.join(d, "w.elf")
-        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")])
-        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
-        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", elf], text=True)
-        dis = subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", elf], text=True)
-    meta = notes[notes.index("_Z18cnf_rk4_x6w_kernel9CnfX6Args") - 400:]
-    meta = meta[:meta.index("_Z18cnf_rk4_x6w_kernel9CnfX6Args") + 600]
-    assert re.search(r"\.private_segment_fixed_size:\s+0\b", meta) and re.search(r"\.vgpr_spill_count:\s+0\b", meta), meta
-    assert re.search(r"\.agpr_count:\s+256\b", meta), meta
-    body = dis[dis.index("<_Z18cnf_rk4_x6w_kernel9CnfX6Args>:"):]
-    body = body[:body.index("s_endpgm")]
-    ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.startswith("\t")]
-    count = lambda pat: sum(1 for i in ins if re.match(pat, i))
-    assert count(r"scratch_") == 0
-    assert count(r"v_accvgpr_read_b32") == 512 and count(r"v_accvgpr_write_b32") == 512, (count(r"v_accvgpr_read_b32"), count(r"v_accvgpr_write_b32"))
-    assert count(r"v_accvgpr_mov") == 0
-    mfma = [i for i in ins if i.startswith("v_mfma")]
-    on_acc = [i for i in mfma if re.match(r"v_mfma_f32_32x32x16_bf16 a\[", i)]
-    assert len(on_acc) == 8 * 4 * 12 and all(" a[" not in i for i in mfma if i not in on_acc), (len(mfma), len(on_acc))
-    # M0 is written by the LDS-DMA statements only: one write per instruction inside the product stream (one instruction per
-    # scheduling slot), one per PAIR in the prologue (ten pairs: three whole pieces and a third of the fourth)
-    dma = count(r"global_load_lds_dwordx4")
-    m0 = sum(1 for i in ins if re.search(r"\bm0\b", i))
-    assert dma > 20 and m0 == dma - 10, (dma, m0)
+    must not spill (a scratch reload would also drain the LDS-DMA queue with vmcnt(0)).  The check itself lives in
+    caspr_amd/csrc/audit.py and ALSO runs inside build() before the library is linked; here it runs on the in-tree object."""
+    audit, obj = _audit("ode_bf16x6w.hip")
+    r = audit.audit_cnf_x6w(obj)
+    assert r["accvgpr_reads"] == 512 and r["accvgpr_writes"] == 512 and r["mfma_on_acc"] == 384, r
 
 
 def test_conv_x6w_kernel_keeps_its_accumulator_file_to_itself():
-    """The same audit for conv1x1_x6w_kernel (csrc/gemm_bf16x6w.hip, four instantiations): no scratch, no spills, every MFMA on
-    the hand-managed a[..] tiles, 256 zeroing writes and 256 epilogue reads of the accumulator file and nothing else."""
-    llvm = "/opt/rocm/lib/llvm/bin"
-    obj = os.path.join(ROOT, "caspr_amd", "csrc", "gemm_bf16x6w.o")
-    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "llvm-objdump"))):
-        pytest.skip("needs the in-tree object and the ROCm LLVM tools")
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        fat, elf = os.path.join(d, "w.fatbin"), os.path.join(d, "w.elf")
-        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")])
-        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])
-        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", elf], text=True)
-        dis = subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", elf], text=True)
-    kernels = re.findall(r"<(_Z18conv1x1_x6w_kernelILb[01]ELb[01]EEv9ConvWArgsPKfS2_)>:", dis)
-    assert len(kernels) == 4, kernels
-    for k in kernels:
-        meta = notes[notes.index(k) - 400:]
-        meta = meta[:meta.index(k) + 600]
-        assert re.search(r"\.private_segment_fixed_size:\s+0\b", meta) and re.search(r"\.vgpr_spill_count:\s+0\b", meta), (k, meta)
-        body = dis[dis.index("<%s>:" % k):]
-        body = body[:body.index("s_endpgm")]
-        ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.startswith("\t")]
-        count = lambda pat: sum(1 for i in ins if re.match(pat, i))
-        assert count(r"scratch_") == 0, k
-        assert count(r"v_accvgpr_write_b32") == 256 and count(r"v_accvgpr_read_b32") == 256 and count(r"v_accvgpr_mov") == 0, (k, count(r"v_accvgpr_write_b32"), count(r"v_accvgpr_read_b32"))
-        mfma = [i for i in ins if i.startswith("v_mfma")]
-        assert len(mfma) == 2 * 192 and all(re.match(r"v_mfma_f32_32x32x16_bf16 a\[", i) for i in mfma), (k, len(mfma))
+    """The same audit for conv1x1_x6w_kernel (csrc/gemm_bf16x6w.hip, every instantiation)."""
+    audit, obj = _audit("gemm_bf16x6w.hip")
+    r = audit.audit_conv_x6w(obj)
+    assert len(r) >= 4 and all(k["mfma"] == 384 for k in r), r
+
+
+def test_build_refuses_a_code_object_whose_accumulator_file_the_compiler_touched(tmp_path):
+    """The build-time gate: the same kernel compiled WITHOUT -amdgpu-mfma-vgpr-form (hipcc then parks layer 2's accumulators on top of
+    the hand-managed ones) must be rejected by audit_objects -- i.e. build() would not link it."""
+    audit, _ = _audit("ode_bf16x6w.hip")
+    from caspr_amd.csrc import build as B
+    src = os.path.join(ROOT, "caspr_amd", "csrc", "ode_bf16x6w.hip")
+    obj = str(tmp_path / "bad.o")
+    flags = [f for f in B.EXTRA["ode_bf16x6w.hip"] if f != "-amdgpu-mfma-vgpr-form"]
+    flags = [f for i, f in enumerate(flags) if not (f == "-mllvm" and (i + 1 >= len(flags) or flags[i + 1] == "-mllvm" or not flags[i + 1].startswith("-")))]
+    r = subprocess.run([B.HIPCC] + B.FLAGS + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        return          # does not even compile without the flag (register budget): equally not linked
+    with pytest.raises(audit.AuditError):
+        audit.audit_objects({"ode_bf16x6w.hip": obj})
 
 
 def test_plan_times_is_the_sorted_unique_mapping_of_the_reference():
