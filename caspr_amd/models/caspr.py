@@ -227,29 +227,55 @@ class CaSPR(nn.Module):
                 y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y, _early=early)
             return y, logp_y, x, tnocs_pred
 
-    def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16), num_points=512, timestamps=None, max_timestamp=5.0):
+    def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16, 32, 64, 128), num_points=512, timestamps=None, max_timestamp=5.0,
+                            latent_tol=None, latent_candidates=(1, 2, 4, 8, 16, 32)):
         """Pick the CNF's fixed RK4 step count the way an adaptive solver picks its step: by an error estimate on the
         actual weights and input.  Decodes the first sequence of `x` with S and 2S steps (same base samples) for each
-        candidate S and keeps the smallest S whose step-doubling difference max|x_S - x_2S| (= 15/16 of the S-step
-        error for a 4th-order method) is <= tol.  Sets `rk4_steps` on every CNF block; returns (S, {S: difference}).
-        The reference's dopri5 runs at atol = rtol = 1e-5 (flow.py:96-99); the default of this build (8 steps) is kept
-        unless this is called."""
+        candidate S in ascending order and keeps the first S whose step-doubling difference max|x_S - x_2S| (= 15/16 of the
+        S-step error for a 4th-order method) is <= tol.  Sets `rk4_steps` on every CNF block; returns (S, {S: difference}) with the
+        differences of the candidates that were tried.  With `latent_tol` the latent ODE's steps per interval are chosen FIRST, the
+        same way (max|z_L - z_2L| <= latent_tol over the requested stamps), and installed on `latent_ode.rk4_steps`; the return
+        value then is (S, diffs, L, latent_diffs).
+        The reference's dopri5 runs at atol = rtol = 1e-5 (flow.py:96-99; 1e-3 for the latent ODE, latent_ode_model.py:38,83);
+        the defaults of this build (8 steps, 2 per interval) are kept unless this is called."""
         from .cnf import CNF
         blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
         with torch.no_grad():
             xs = x[:1]
             z0, _ = self.encode(xs)
             times = xs[:, :, 0, 3] / max_timestamp if timestamps is None else timestamps.view(1, -1).to(xs)
+            lat = None
+            if latent_tol is not None:
+                zs, ldiffs, lchosen = {}, {}, max(latent_candidates)
+
+                def zsol(L):
+                    if L not in zs:
+                        self.latent_ode.rk4_steps = L
+                        zs[L] = self.aggregate_and_solve_latent(z0, times)
+                    return zs[L]
+                for L in sorted(latent_candidates):
+                    ldiffs[L] = float((zsol(L) - zsol(2 * L)).abs().max())
+                    if ldiffs[L] <= latent_tol:
+                        lchosen = L
+                        break
+                self.latent_ode.rk4_steps = lchosen
+                lat = (lchosen, ldiffs)
             z = self.aggregate_and_solve_latent(z0, times)
             y = torch.randn(1, z.shape[1], num_points, self.cnf_args.input_dim, device=x.device)
-            sols = {}
-            for S in sorted(set(candidates) | {2 * c for c in candidates}):
-                for b in blocks:
-                    b.rk4_steps = S
-                sols[S] = self.decode(z, num_points, y=y)[2]
-            diffs = {S: float((sols[S] - sols[2 * S]).abs().max()) for S in candidates}
-        chosen = next((S for S in sorted(candidates) if diffs[S] <= tol), max(candidates))
+            sols, diffs, chosen = {}, {}, max(candidates)
+
+            def sol(S):
+                if S not in sols:
+                    for b in blocks:
+                        b.rk4_steps = S
+                    sols[S] = self.decode(z, num_points, y=y)[2]
+                return sols[S]
+            for S in sorted(candidates):
+                diffs[S] = float((sol(S) - sol(2 * S)).abs().max())
+                if diffs[S] <= tol:
+                    chosen = S
+                    break
         for b in blocks:
             b.rk4_steps = chosen
         self.cnf_args.rk4_steps = chosen
-        return chosen, diffs
+        return (chosen, diffs) if lat is None else (chosen, diffs, lat[0], lat[1])

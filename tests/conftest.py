@@ -24,3 +24,12 @@ def seeded_sd():
     from caspr_amd.models import CaSPR
     from caspr_amd.utils.synthetic import seeded_state_dict
     return seeded_state_dict(CaSPR().state_dict(), 0)
+
+
+@pytest.fixture(scope="session")
+def stress_sd():
+    """The same key surface with dynamics that are HARD to integrate (synthetic.stress_state_dict): time-switching gates, saturated
+    softplus tails, T = 1, a latent field that moves."""
+    from caspr_amd.models import CaSPR
+    from caspr_amd.utils.synthetic import stress_state_dict
+    return stress_state_dict(CaSPR().state_dict(), 0)

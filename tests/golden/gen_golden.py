@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import point_ops as P          # noqa: E402
 from oracle import model as O              # noqa: E402
-from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences  # noqa: E402
+from caspr_amd.utils.synthetic import seeded_state_dict, stress_state_dict, car_sequences  # noqa: E402
 
 REF = "/root/reference/caspr"
 CNF_STEPS, LATENT_STEPS = 8, 4
@@ -95,6 +95,7 @@ def rnd(seed, *shape, scale=1.0):
 
 
 def main():
+    global CNF_STEPS, LATENT_STEPS
     torch.set_grad_enabled(True)
     install_shims()
     import warnings
@@ -341,6 +342,43 @@ def main():
         np.random.seed(6)
         (a, b), mid, sid = ds[0]
         g["ds_perstep_in"], g["ds_perstep_out"] = a.numpy(), b.numpy()
+
+    # ---- 7. the STRESS weights (caspr_amd.utils.synthetic.stress_state_dict: a flow whose gates switch in time, saturated softplus
+    # tails, T = 1, a latent field that moves) through the reference's own ODEfunc / CNF / SequentialFlow / DynamicsNet / reconstruct
+    # code: odefunc.py:98-142 (autograd Hutchinson divergence), cnf.py:70-128, flow.py:86-100, latent_ode_model.py:38-147.  The
+    # integrator is the RK4 shim at STRESS_CNF_STEPS / STRESS_LATENT_STEPS (torchdiffeq is not installed; dopri5 on these weights is
+    # the oracle's restatement, parity unpinned). ------------------------------------------------------------------------------------
+    ref.load_state_dict(stress_state_dict(ref.state_dict(), SEED))
+    ref.eval()
+    odef = ref.point_cnf.chain[1].odefunc
+    orig = odef.before_odeint
+    CNF_STEPS, LATENT_STEPS = 32, 8
+    g["stress_cnf_steps"], g["stress_latent_steps"] = CNF_STEPS, LATENT_STEPS
+    y, c, e, lp = rnd(51, 2, 48, 3), rnd(52, 2, 1600), rnd(53, 2, 48, 3), torch.zeros(2, 48, 1)
+    odef.before_odeint(e=e)
+    for ti, tt in enumerate([0.02, 0.31, 0.77, 0.99]):
+        dy, ndiv, _ = odef(torch.tensor(tt), (y, lp, c))
+        g["stress_odefunc_dy_%d" % ti], g["stress_odefunc_negdiv_%d" % ti] = dy.detach().numpy(), ndiv.detach().numpy()
+    g["stress_odefunc_times"] = np.array([0.02, 0.31, 0.77, 0.99])
+    with torch.no_grad():
+        g["stress_dynamics"] = ref.latent_ode.ode_func(torch.tensor(0.0), rnd(54, 4, 64)).numpy()
+    # the whole flow (MovingBatchNorm -> CNF -> MovingBatchNorm, flow.py:68-72) forward with the divergence, then sampling direction
+    xs, lp0 = rnd(55, 2, 48, 3, scale=0.5), rnd(56, 2, 48, 1)
+    odef.before_odeint = lambda e_=None: orig(e=e)
+    with torch.no_grad():
+        yv, lpv = ref.point_cnf(xs, c, lp0)
+        g["stress_flow_fwd_y"], g["stress_flow_fwd_logp"] = yv.numpy(), lpv.numpy()
+        g["stress_flow_rev_x"] = ref.point_cnf(y, c, reverse=True).numpy()
+    odef.before_odeint = orig
+    # reconstruct on a dense sequence (latent field moving over three distinct stamps)
+    from caspr_amd.utils.synthetic import dense_sequences as _dense
+    with torch.no_grad():
+        x, sp = _dense(1, 3, 1024, seed=41)
+        torch.manual_seed(11)
+        yy, _, xr, tn = ref.reconstruct(x, num_points=96, timestamps=sp[0, :, 0, 3])
+        g["stress_pipe_ybase"], g["stress_pipe_recon_x"], g["stress_pipe_tnocs"] = yy.numpy(), xr.numpy(), tn.numpy()
+        z0, _ = ref.encode(x)
+        g["stress_pipe_latent"] = ref.aggregate_and_solve_latent(z0, sp[:, :, 0, 3])[:, :, :64].numpy()
 
     out_path = os.path.join(HERE, "reference_golden.npz")
     np.savez_compressed(out_path, **g)
