@@ -35,32 +35,9 @@ ENC_GFLOP_PER_SEQ = {(10, 1024): 176.6, (10, 2048): 306.0, (20, 4096): 1129.6, (
 CNF_FLOP_PER_POINT_EVAL_DIV = 2 * 2 * (3 * 512 + 512 * 512 + 512 * 512 + 512 * 3)               # value + tangent
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
-    ap.add_argument("--seq-len", type=int, default=10)
-    ap.add_argument("--num-pts", type=int, default=1024)
-    ap.add_argument("--cnf-steps", type=int, default=8)
-    ap.add_argument("--latent-steps", type=int, default=2)
-    ap.add_argument("--mode", choices=["full", "pretrain"], default="full")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    # one process per GPU: a plain `python bench_train.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1);
-    # under an external launcher WORLD_SIZE must equal --gpus
-    from caspr_amd.utils.launch import ensure_ranks
-    rank, local_rank, world = ensure_ranks(args.gpus, __file__, sys.argv[1:], device_count=torch.cuda.device_count)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")   # RCCL on ROCm
-    assert torch.cuda.is_available(), "bench_train.py needs a ROCm GPU (there is no CPU execution path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
+def measure(args, dev, rank=0, world=1):
+    """The timed training steps + the per-pipe detail pass; also called by bench.py for its `train_cfg3` sub-block (world = 1).
+    -> dict with elapsed (max over ranks), per_rank_ms, losses, pipes, and what the CPU baseline needs."""
     from caspr_amd.models import CaSPR
     from caspr_amd.train.loop import GradBucket, train_step
     from caspr_amd.utils.sharding import max_over_ranks, per_rank_values, collective_library
@@ -113,32 +90,75 @@ def main():
         acc = pipes["bf16x6" if p[1].endswith("bf16x6") else "f32_mfma"]
         acc[0] += fl; acc[1] += ms_k; acc[2] += len(ev)
 
+    return {"elapsed": elapsed, "per_rank_ms": per_rank_ms, "losses": losses, "pipes": pipes, "sd": sd, "x_all": x_all, "sp_all": sp_all, "e": e,
+            "full": full, "collective_library": collective_library() if world > 1 else None}
+
+
+def summarize(args, m, world=1):
+    """roofline (per pipe) of measure()'s result -> (ms_per_step, roofline dict)."""
+    B, T, N = args.batch, args.seq_len, args.num_pts
+    full, pipes = m["full"], m["pipes"]
+    ms = 1e3 * m["elapsed"] / args.steps
+    enc = ENC_GFLOP_PER_SEQ.get((T, N))
+    flop = None
+    if enc is not None:
+        flop = 3.0 * B * enc * 1e9
+        if full:
+            flop += 3.0 * B * T * N * 4 * args.cnf_steps * CNF_FLOP_PER_POINT_EVAL_DIV
+    # priced PER PIPE: the matrix products of the step run on two kernel families with different ceilings -- the bf16x6 kernels
+    # (2500 / 6 = 416.7 f32-equivalent TFLOP/s) and the f32-MFMA kernels (157.3) -- so the step's roofline time is
+    # FLOP_x6 / 416.7 + FLOP_f32 / 157.3 (measured per launch in the detail pass) and `frac` = that time / the step time
+    PEAK_X6 = 2500.0 / 6.0
+    fx, ff = pipes["bf16x6"], pipes["f32_mfma"]
+    roof_ms = fx[0] / (PEAK_X6 * 1e12) * 1e3 + ff[0] / (PEAK_MFMA_F32_TFLOPS * 1e12) * 1e3
+
+    def pipe(v, peak):
+        return {"flop_per_step": v[0], "launches_per_step": v[2], "kernel_ms_per_step": round(v[1], 3),
+                "achieved": round(v[0] / (v[1] * 1e-3) / 1e12, 3) if v[1] > 0 else None, "peak": round(peak, 1),
+                "frac_while_running": round(v[0] / (v[1] * 1e-3) / 1e12 / peak, 4) if v[1] > 0 else None}
+    roofline = {"kernel": "every matrix kernel of the step (conv1x1 forward / data gradient, conv1x1_wgrad, fused set abstraction), per pipe",
+                "bound": "mfma", "achieved": round((fx[0] + ff[0]) / (ms * 1e-3) / 1e12, 3), "peak": round(PEAK_X6, 1), "unit": "TFLOP/s",
+                "frac": round(roof_ms / ms, 4),
+                "frac_note": "(FLOP_bf16x6 / 416.7 + FLOP_f32 / 157.3 TFLOP/s) / step time: the share of the step the matrix pipes would need at their peaks",
+                "pipes": {"bf16x6": pipe(fx, PEAK_X6), "f32_mfma": pipe(ff, PEAK_MFMA_F32_TFLOPS)},
+                "matrix_kernel_ms_per_step": round(fx[1] + ff[1], 3), "traffic": None,
+                "flop_per_step_model": flop}
+    return ms, roofline
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
+    ap.add_argument("--seq-len", type=int, default=10)
+    ap.add_argument("--num-pts", type=int, default=1024)
+    ap.add_argument("--cnf-steps", type=int, default=8)
+    ap.add_argument("--latent-steps", type=int, default=2)
+    ap.add_argument("--mode", choices=["full", "pretrain"], default="full")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    # one process per GPU: a plain `python bench_train.py --gpus N` starts its own N ranks (torch.distributed.run on 127.0.0.1);
+    # under an external launcher WORLD_SIZE must equal --gpus
+    from caspr_amd.utils.launch import ensure_ranks
+    rank, local_rank, world = ensure_ranks(args.gpus, __file__, sys.argv[1:], device_count=torch.cuda.device_count)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")   # RCCL on ROCm
+    assert torch.cuda.is_available(), "bench_train.py needs a ROCm GPU (there is no CPU execution path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    m = measure(args, dev, rank, world)
+    B, T, N = args.batch, args.seq_len, args.num_pts
+    full, elapsed, per_rank_ms, losses = m["full"], m["elapsed"], m["per_rank_ms"], m["losses"]
+    sd, x_all, sp_all, e = m["sd"], m["x_all"], m["sp_all"], m["e"]
+    collective_library = lambda: m["collective_library"]
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        enc = ENC_GFLOP_PER_SEQ.get((T, N))
-        flop = None
-        if enc is not None:
-            flop = 3.0 * B * enc * 1e9
-            if full:
-                flop += 3.0 * B * T * N * 4 * args.cnf_steps * CNF_FLOP_PER_POINT_EVAL_DIV
-        achieved = flop / (ms * 1e-3) / 1e12 if flop else None
-        # priced PER PIPE: the matrix products of the step run on two kernel families with different ceilings -- the bf16x6 kernels
-        # (2500 / 6 = 416.7 f32-equivalent TFLOP/s) and the f32-MFMA kernels (157.3) -- so the step's roofline time is
-        # FLOP_x6 / 416.7 + FLOP_f32 / 157.3 (measured per launch in the detail pass above) and `frac` = that time / the step time
-        PEAK_X6 = 2500.0 / 6.0
-        fx, ff = pipes["bf16x6"], pipes["f32_mfma"]
-        roof_ms = fx[0] / (PEAK_X6 * 1e12) * 1e3 + ff[0] / (PEAK_MFMA_F32_TFLOPS * 1e12) * 1e3
-        def pipe(v, peak):
-            return {"flop_per_step": v[0], "launches_per_step": v[2], "kernel_ms_per_step": round(v[1], 3),
-                    "achieved": round(v[0] / (v[1] * 1e-3) / 1e12, 3) if v[1] > 0 else None, "peak": round(peak, 1),
-                    "frac_while_running": round(v[0] / (v[1] * 1e-3) / 1e12 / peak, 4) if v[1] > 0 else None}
-        roofline = {"kernel": "every matrix kernel of the step (conv1x1 forward / data gradient, conv1x1_wgrad, fused set abstraction), per pipe",
-                    "bound": "mfma", "achieved": round((fx[0] + ff[0]) / (ms * 1e-3) / 1e12, 3), "peak": round(PEAK_X6, 1), "unit": "TFLOP/s",
-                    "frac": round(roof_ms / ms, 4),
-                    "frac_note": "(FLOP_bf16x6 / 416.7 + FLOP_f32 / 157.3 TFLOP/s) / step time: the share of the step the matrix pipes would need at their peaks",
-                    "pipes": {"bf16x6": pipe(fx, PEAK_X6), "f32_mfma": pipe(ff, PEAK_MFMA_F32_TFLOPS)},
-                    "matrix_kernel_ms_per_step": round(fx[1] + ff[1], 3), "traffic": None,
-                    "flop_per_step_model": flop}
+        ms, roofline = summarize(args, m, world)
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import model as O

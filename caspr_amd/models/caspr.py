@@ -10,6 +10,8 @@ Training: in train() mode with grad enabled `forward` is differentiable end to e
 with a HIP backward (caspr_amd/train/encoder_grad.py), the latent ODE and the CNF through the discrete RK4 map with
 every matrix product on the HIP kernels (caspr_amd/train/flow_grad.py).
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -19,6 +21,14 @@ from .tpointnet2 import TPointNet2
 from .latent_ode_model import LatentODE
 from .flow import get_point_cnf, count_nfe, PointCNFArgs
 from .utils import standard_normal_logprob, sample_gaussian, sphere_surface_points, truncated_normal
+
+
+_EARLY_DRAW = {}      # (id(model), device, sample size) -> pinned buffer, copy stream, last copy's event (CaSPR._draw_early)
+
+
+def _drop_early_draw(owner):
+    for k in [k for k in _EARLY_DRAW if k[0] == owner]:
+        _EARLY_DRAW.pop(k, None)
 
 
 class CaSPR(nn.Module):
@@ -147,10 +157,18 @@ class CaSPR(nn.Module):
         in between).  -> (device tensor, event the consuming stream must wait for)."""
         samp_batch = B if constant_in_time else B * T
         size = (samp_batch, num_points, self.cnf_args.input_dim)
-        st = self.__dict__.setdefault("_early_draw_state", {})
-        ent = st.get(size)
+        # pinned buffer + copy stream per (device, size), at most two entries (evicting the oldest releases its pinned memory); kept in a
+        # module-level table, not on the module: streams / events must not end up in copy.deepcopy(model) or torch.save(model)
+        key = (id(self), str(device), size)
+        ent = _EARLY_DRAW.get(key)
         if ent is None:
-            ent = st[size] = {"buf": torch.empty(size, dtype=torch.float32, pin_memory=True), "ev": None, "stream": torch.cuda.Stream(device=device)}
+            mine = [k for k in _EARLY_DRAW if k[0] == id(self)]
+            for k in mine[:max(0, len(mine) - 1)]:
+                old = _EARLY_DRAW.pop(k)
+                if old["ev"] is not None:
+                    old["ev"].synchronize()
+            ent = _EARLY_DRAW[key] = {"buf": torch.empty(size, dtype=torch.float32, pin_memory=True), "ev": None, "stream": torch.cuda.Stream(device=device)}
+            weakref.finalize(self, _drop_early_draw, id(self))
         if ent["ev"] is not None:
             ent["ev"].synchronize()          # the previous call's copy out of the pinned buffer (a whole step ago)
         torch.randn(*size, out=ent["buf"])   # == torch.randn(*size): same generator, same stream position
