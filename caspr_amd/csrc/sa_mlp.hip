@@ -296,15 +296,18 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
 //   * GroupNorm groups are 1, 2 or 4 channels wide = registers of one lane; their statistics reduce over the
 //     16 lanes (x 1 or 2 column tiles) of the neighbourhood with xor-shuffles, in f64 (one pass: sum, sum of squares);
 //   * max over the neighbourhood = the same shuffle pattern; lanes j == 0 store 4 channels (16 bytes) each.
-// Layer 1 runs on CENTRED inputs.  The first level's features are absolute coordinates squared (x^2 ... yz at depth ~2:
-// values ~5 that vary by ~1e-2 inside an r = 0.02 ball), so W x = (large constant) + (small variation) and the
-// per-neighbourhood GroupNorm, which keeps only the variation, would inherit the f32 rounding of the constant amplified
-// by 1/sigma: 1.9e-4 on the level's output (profiles/r02_error_budget.json), the largest error of the whole path.
-// Instead every sample's input has the neighbourhood's sample 0 subtracted (exact in f32: the values are within a factor
-// of two), y = W (x - x0) is accurate to its own magnitude, and the constant mu = W x0 + bias -- one extra column tile of
-// the same MFMAs -- is carried separately and added back in f64 inside the statistics, where it cancels exactly for
-// one-channel groups and supplies the between-channel offsets of wider groups.  An exact reformulation of
-// pointnet2.py:677-689, not an approximation.
+// EVERY layer runs on CENTRED activations (round 4; round 2 centred layer 1 only).  A neighbourhood is carried as one REFERENCE
+// column -- its sample 0, absolute values -- and the DEVIATIONS d_s = a_s - a_0 of the other samples; sample 0's own deviation is
+// zero, so the reference rides in ITS column of the MFMA B operand: no extra tile, and y_s = W a_s + b = (W a_0 + b) + W d_s comes
+// out of the same products (column 0: mu = W a_0, the others W d_s, each accurate to ITS OWN magnitude).  Why: on sparse clouds
+// most neighbourhoods are padded with copies of the first hit plus a few near-duplicates, the per-neighbourhood GroupNorm keeps only
+// the variation inside the neighbourhood and scales it by 1 / sqrt(var + 1e-5) <= 316 -- three times in a row.  In the plain form
+// W a_s = (large common part) + (small variation) carries the f32 rounding of the common part, which every GroupNorm then amplifies:
+// 2.7e-4 / 6.2e-4 on the outputs of the two 16-sample scales (round 3: the f32 CPU reference is 4.7e-4 / 6.2e-4 from f64 itself).
+// In the centred form the error of every quantity is relative to the VARIATION: the first level's quadratic features are formed from
+// exact coordinate differences (a b - a0 b0 = (a - a0) b + a0 (b - b0)), the statistics add mu back in f64, the normalised deviation is
+// d_s * rstd * gamma (no subtraction), ReLU acts on (n_0, n_0 + delta_s) and returns a deviation again, the final max is n_0 + max(0,
+// max_s delta_s).  An exact reformulation of pointnet2.py:677-698, not an approximation; exact duplicates stay exactly zero throughout.
 // ---------------------------------------------------------------------------------------------
 template <int NS, int C1, int C2, int C3>
 __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
@@ -344,15 +347,7 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     int rrow[NCEN];
 #pragma unroll
     for (int cen = 0; cen < NCEN; ++cen) rrow[cen] = __builtin_amdgcn_readlane(nrow[cen * TPC], 0);
-    const int cj = j & (NCEN - 1);              // mu tile: column j carries the reference vector of centre j % NCEN
-    int myr = rrow[0];
-    float mcx = cx[0], mcy = cy[0], mcz = cz[0];
-#pragma unroll
-    for (int cen = 1; cen < NCEN; ++cen)
-        if (cj == cen) {
-            myr = rrow[cen];
-            mcx = cx[cen * TPC]; mcy = cy[cen * TPC]; mcz = cz[cen * TPC];
-        }
+    const bool refl = j == 0;                   // column 0 of a neighbourhood's first tile carries its reference (sample 0, absolute)
     SA_STAMP(1)
 
     // ---- layer 1: K order = [feat (C, padded to C4) | dx dy dz 0 | zeros]
@@ -361,9 +356,6 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     for (int rt = 0; rt < C1 / 16; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 hmu[C1 / 16];                              // W x0 of the mu tile (column j <-> centre j % NCEN)
-#pragma unroll
-    for (int rt = 0; rt < C1 / 16; ++rt) hmu[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int KC0 = a.L[0].kc;
     // input quad k..k+3 of cloud row `row` as layer 1 sees it: [feat | p - centre | 0]
     auto in_quad = [&](int row, int k, float ccx, float ccy, float ccz) -> f32x4 {
@@ -402,20 +394,23 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
         if (k == C4) return (f32x4){dx, dy, dz, 0.f};
         return k == 0 ? (f32x4){f[0], f[1], f[2], f[3]} : (k == 4 ? (f32x4){f[4], f[5], f[6], f[7]} : (f32x4){0.f, 0.f, 0.f, 0.f});
     };
-    // B fragments of chunk kc straight from global memory, centred on the neighbourhood's sample 0; bmu = the mu tile
-    auto gather = [&](f32x4(&bf)[CT], f32x4 &bmu, int kc) {
+    // B fragments of chunk kc straight from global memory: deviations from the neighbourhood's sample 0, and in sample 0's own column
+    // (lane j = 0 of the neighbourhood's first tile, whose deviation is zero) the reference itself
+    auto gather = [&](f32x4(&bf)[CT], int kc) {
         const int k = kc * 16 + 4 * g;
+        f32x4 ref[NCEN];
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen) ref[cen] = in_quad(rrow[cen], k, cx[cen * TPC], cy[cen * TPC], cz[cen * TPC]);
         if (a.feat_kind) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) bf[ct] = aug_quad(nrow[ct], rrow[ct / TPC], k);
         } else {
-            f32x4 ref[NCEN];
-#pragma unroll
-            for (int cen = 0; cen < NCEN; ++cen) ref[cen] = in_quad(rrow[cen], k, cx[cen * TPC], cy[cen * TPC], cz[cen * TPC]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) bf[ct] = in_quad(nrow[ct], k, cx[ct], cy[ct], cz[ct]) - ref[ct / TPC];
         }
-        bmu = in_quad(myr, k, mcx, mcy, mcz);
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen)
+            if (refl) bf[cen * TPC] = ref[cen];
     };
     auto mask = [&](f32x4(&bf)[CT], int kc) {       // zero the padding lanes of the feature quad that straddles C
         const int k = kc * 16 + 4 * g;
@@ -427,23 +422,14 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
                     if (k + q >= a.C) bf[ct][q] = 0.f;
         }
     };
-    auto mma1 = [&](const f32x4(&bf)[CT], const f32x4 &bmu, const f32x4(&af)[C1 / 16]) {
+    auto mma1 = [&](const f32x4(&bf)[CT], const f32x4(&af)[C1 / 16]) {
 #pragma unroll
         for (int rt = 0; rt < C1 / 16; ++rt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = mfma16(af[rt][q], bf[ct][q], h1[rt][ct]);
-                hmu[rt] = mfma16(af[rt][q], bmu[q], hmu[rt]);
             }
-    };
-    auto mask1 = [&](f32x4 &v, int kc) {            // the mu tile's padding lanes
-        const int k = kc * 16 + 4 * g;
-        if (k < C4 && k + 3 >= a.C) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (k + q >= a.C) v[q] = 0.f;
-        }
     };
     auto load_a1 = [&](f32x4(&af)[C1 / 16], int kc) {
 #pragma unroll
@@ -453,58 +439,51 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
         // of 16-wide chunks (KC0); only those that carry inputs are gathered and multiplied -- 1 of 2 at the first level (9 + 3
         // inputs), 7 of 8 at the second (96 + 3): the all-zero chunk was a fifth of the first level's MFMAs
         const int kcu = (C4 + 4 + 15) >> 4;
-        f32x4 b0[CT], b1[CT], m0v, m1v, w0[C1 / 16], w1[C1 / 16];
-        gather(b0, m0v, 0);
+        f32x4 b0[CT], b1[CT], w0[C1 / 16], w1[C1 / 16];
+        gather(b0, 0);
         load_a1(w0, 0);
         for (int kc = 0; kc + 1 < kcu; kc += 2) {
-            gather(b1, m1v, kc + 1);
+            gather(b1, kc + 1);
             load_a1(w1, kc + 1);
             __builtin_amdgcn_sched_barrier(0);
             mask(b0, kc);
-            mask1(m0v, kc);
-            mma1(b0, m0v, w0);
+            mma1(b0, w0);
             if (kc + 2 < kcu) {
-                gather(b0, m0v, kc + 2);
+                gather(b0, kc + 2);
                 load_a1(w0, kc + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
             mask(b1, kc + 1);
-            mask1(m1v, kc + 1);
-            mma1(b1, m1v, w1);
+            mma1(b1, w1);
         }
         if (kcu & 1) {            // the last chunk of an odd count sits in set 0
             mask(b0, kcu - 1);
-            mask1(m0v, kcu - 1);
-            mma1(b0, m0v, w0);
+            mma1(b0, w0);
         }
     }
-    // mu[rt][cen] = (W x0 + bias) rows 4g..4g+3 of centre cen: lane (g, cen) of the mu tile, broadcast along the row
-    f32x4 mu[C1 / 16][NCEN];
-#pragma unroll
-    for (int rt = 0; rt < C1 / 16; ++rt) {
-        const f32x4 bias4 = ld4(a.L[0].bias + rt * 16 + 4 * g);
-#pragma unroll
-        for (int cen = 0; cen < NCEN; ++cen)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mu[rt][cen][e] = __shfl(hmu[rt][e], (lane & 48) + cen) + bias4[e];
-    }
 
-    // bias + GroupNorm(16) per neighbourhood (+ ReLU) on a register-resident layer output
-    // `off` (layer 1): per-(row tile, centre) constants added in f64 (h holds W (x - x0) without bias); nullptr: h + bias
-    auto norm = [&](auto &h, auto RTc, const SaLayer &L, bool relu, const f32x4 (*off)[NCEN]) {
+    // bias + GroupNorm(16) per neighbourhood on a register-resident layer output in the centred form: on entry column 0 of the
+    // neighbourhood's first tile holds W a_0 (lane j = 0), every other column W d_s.  FINAL = false: ReLU, and the output is written back
+    // in the same form (a_0 | a_s - a_0); FINAL = true (no activation, pointnet2.py:686-698): the max over the samples is stored.
+    auto norm = [&](auto &h, auto RTc, const SaLayer &L, auto FINALc) {
         constexpr int RT = decltype(RTc)::value;
+        constexpr bool FINAL = decltype(FINALc)::value;
         constexpr int CPG = RT;            // channels per group = (16*RT)/16
         static_assert(CPG == 1 || CPG == 2 || CPG == 4, "register GroupNorm handles widths 16, 32, 64");
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const f32x4 bias4 = ld4(L.bias + rt * 16 + 4 * g);
             const f32x4 ga = ld4(L.gamma + rt * 16 + 4 * g), be = ld4(L.beta + rt * 16 + 4 * g);
-            if (!off) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) h[rt][ct] += bias4;
-            }
+            for (int cen = 0; cen < NCEN; ++cen) {
+                // mu = W a_0 + bias of this neighbourhood (rows 4g..4g+3), to all 16 lanes of the row; sample 0's deviation is zero
+                f32x4 mu;
 #pragma unroll
-            for (int cen = 0; cen < NCEN; ++cen)
+                for (int e = 0; e < 4; ++e) {
+                    mu[e] = dpp_mov<0x150>(h[rt][cen * TPC][e]) + bias4[e];        // row_newbcast:0
+                    if (refl) h[rt][cen * TPC][e] = 0.f;
+                }
+                f32x4 mx = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sg = 0; sg < 4 / CPG; ++sg) {
                     double s1 = 0.0, s2 = 0.0;
@@ -513,7 +492,7 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
 #pragma unroll
                         for (int r = 0; r < CPG; ++r) {
                             // one-channel groups: the constant cancels exactly, leave it out (sigma can be ~1e-2 of it)
-                            const double o = (off && CPG > 1) ? (double)off[rt][cen][sg * CPG + r] : 0.0;
+                            const double o = CPG > 1 ? (double)mu[sg * CPG + r] : 0.0;
                             const double x = (double)h[rt][cen * TPC + t][sg * CPG + r] + o;
                             s1 += x;
                             s2 += x * x;
@@ -526,15 +505,31 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
                     var = var < 0.0 ? 0.0 : var;
                     const float rstd = __builtin_amdgcn_rsqf((float)var + 1e-5f);
 #pragma unroll
-                    for (int t = 0; t < TPC; ++t)
+                    for (int r = 0; r < CPG; ++r) {
+                        const int e = sg * CPG + r;
+                        const float sc = rstd * ga[e];
+                        const float n0 = (float)((CPG > 1 ? (double)mu[e] : 0.0) - mean) * sc + be[e];      // the reference, normalised
+                        if (FINAL) {
+                            float dm = 0.f;
 #pragma unroll
-                        for (int r = 0; r < CPG; ++r) {
-                            const int e = sg * CPG + r;
-                            const double o = (off && CPG > 1) ? (double)off[rt][cen][e] : 0.0;
-                            const float y = (float)(((double)h[rt][cen * TPC + t][e] + o) - mean) * (rstd * ga[e]) + be[e];
-                            h[rt][cen * TPC + t][e] = relu ? (y > 0.f ? y : 0.f) : y;
+                            for (int t = 0; t < TPC; ++t) dm = fmaxf(dm, h[rt][cen * TPC + t][e] * sc);
+                            mx[e] = n0 + row_allreduce_max<16>(dm);
+                        } else {
+                            const float a0 = n0 > 0.f ? n0 : 0.f;
+#pragma unroll
+                            for (int t = 0; t < TPC; ++t) {
+                                const float dl = h[rt][cen * TPC + t][e] * sc;       // normalised deviation: no subtraction
+                                const float ns_ = n0 + dl;
+                                float d = n0 > 0.f ? (ns_ > 0.f ? dl : -n0) : (ns_ > 0.f ? ns_ : 0.f);
+                                if (t == 0 && refl) d = a0;
+                                h[rt][cen * TPC + t][e] = d;
+                            }
                         }
+                    }
                 }
+                if (FINAL && refl && cval[cen * TPC])
+                    st4(a.out + ((long)b * a.M + m0 + cen) * a.ldo + a.out_off + rt * 16 + 4 * g, mx);
+            }
         }
     };
     // next layer from a register-resident input: chunk kc of the K loop = row tile kc of the input
@@ -562,34 +557,18 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     using I2 = std::integral_constant<int, C2 / 16>;
     using I3 = std::integral_constant<int, C3 / 16>;
     SA_STAMP(2)
-    norm(h1, I1{}, a.L[0], true, mu);
+    norm(h1, I1{}, a.L[0], std::false_type{});
     SA_STAMP(3)
     f32x4 h2[C2 / 16][CT];
     layer(h2, I2{}, h1, I1{}, a.L[1]);
     SA_STAMP(4)
-    norm(h2, I2{}, a.L[1], true, nullptr);
+    norm(h2, I2{}, a.L[1], std::false_type{});
     SA_STAMP(5)
     f32x4 h3[C3 / 16][CT];
     layer(h3, I3{}, h2, I2{}, a.L[2]);
     SA_STAMP(6)
-    norm(h3, I3{}, a.L[2], false, nullptr);
+    norm(h3, I3{}, a.L[2], std::true_type{});      // + max over the NS samples of each centre (pointnet2.py:690-698), stored
     SA_STAMP(7)
-
-    // ---- max over the NS samples of each centre (pointnet2.py:690-698)
-#pragma unroll
-    for (int rt = 0; rt < C3 / 16; ++rt)
-#pragma unroll
-        for (int cen = 0; cen < NCEN; ++cen) {
-            f32x4 mx = h3[rt][cen * TPC];
-#pragma unroll
-            for (int t = 1; t < TPC; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], h3[rt][cen * TPC + t][e]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mx[e] = row_allreduce_max<16>(mx[e]);
-            if (j == 0 && cval[cen * TPC])
-                st4(a.out + ((long)b * a.M + m0 + cen) * a.ldo + a.out_off + rt * 16 + 4 * g, mx);
-        }
     SA_STAMP(8)
 }
 
