@@ -707,10 +707,10 @@ int caspr_conv_x6w_launch(const void *wpk, const float *bias, const float *bbias
                           const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout, void *part,
                           int part_stride, hipStream_t stream) __attribute__((visibility("hidden")));
 
-extern "C" int caspr_conv1x1_x6w_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
-                                     const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
-                                     int P, int Cin, int Cout, int G, const float *gamma, const float *beta, float eps, float *scale,
-                                     float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream)
+static int conv_x6w_impl(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                         const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                         int P, int Cin, int Cout, int G, int pool, const float *gamma, const float *beta, float eps, float *scale,
+                         float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream)
 {
     const int Cmain = Cout - Cout % 512, Ctail = Cout - Cmain;
     CASPR_REQUIRE(wpk_main && X && B > 0 && P > 0 && Cmain >= 512 && (Ctail == 0 || wpk_tail), "conv1x1_x6w: bad arguments (Cout=%d needs >= 512 channels%s)", Cout,
@@ -721,10 +721,11 @@ extern "C" int caspr_conv1x1_x6w_f32(const void *wpk_main, const void *wpk_tail,
     CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wpk_main % 16) == 0 && ((uintptr_t)wpk_tail % 16) == 0 &&
                   ((uintptr_t)bias % 16) == 0 && ((uintptr_t)bbias % 16) == 0, "conv1x1_x6w: pointers must be 16-byte aligned");
     CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 8 == 0, "conv1x1_x6w: in_relu_from=%d must be a non-negative multiple of 8", in_relu_from);
-    CASPR_REQUIRE((long)B * (P / 128) * (Cmain / 512) < (1L << 31) && B <= 65535, "conv1x1_x6w: too many tiles");
+    CASPR_REQUIRE((long)B * (P / 128) * (Cmain / 512) < (1L << 31) && B <= 65535 * (long)(pool > 0 ? pool : 1), "conv1x1_x6w: too many tiles");
     f32x4 *part = nullptr;
     if (G > 0) {
         CASPR_REQUIRE(gamma && beta && scale && shift && ws && Cout % G == 0 && (mean == nullptr) == (rstd == nullptr), "conv1x1_x6w: bad GroupNorm arguments");
+        CASPR_REQUIRE(pool >= 1 && B % pool == 0, "conv1x1_x6w: pool=%d must divide B=%d", pool, B);
         CASPR_REQUIRE(ws_bytes >= caspr_conv_gn_ws_bytes(B, P, Cout) && ((uintptr_t)ws % 16) == 0, "conv1x1_x6w: workspace too small or misaligned");
         part = (f32x4 *)ws;
     } else {
@@ -740,9 +741,30 @@ extern "C" int caspr_conv1x1_x6w_f32(const void *wpk_main, const void *wpk_tail,
         if (rc != CASPR_OK) return rc;
     }
     if (G > 0) {
-        conv_gn_finalize_kernel<<<dim3(G, B), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, P / X6_TP, P, Cout, G, gamma, beta, eps, scale, shift,
-                                                                                   pmax, mean, rstd);
+        // pooled statistics (pool consecutive batch entries together): the per-tile partials of consecutive entries are contiguous
+        conv_gn_finalize_kernel<<<dim3(G, B / pool), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, pool * (P / X6_TP), pool * P, Cout, G, gamma, beta,
+                                                                                          eps, scale, shift, pmax, mean, rstd);
         CASPR_CHECK_LAUNCH("conv1x1_x6w (GroupNorm statistics)");
     }
     return CASPR_OK;
+}
+
+extern "C" int caspr_conv1x1_x6w_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                                     const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                                     int P, int Cin, int Cout, int G, const float *gamma, const float *beta, float eps, float *scale,
+                                     float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream)
+{
+    return conv_x6w_impl(wpk_main, wpk_tail, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, G, 1, gamma, beta,
+                         eps, scale, shift, pmax, mean, rstd, ws, ws_bytes, stream);
+}
+
+// ... with the GroupNorm statistics pooled over `pool` consecutive batch entries (as caspr_conv1x1_gn_pooled_bf16x6_f32; G > 0)
+extern "C" int caspr_conv1x1_x6w_pooled_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                                            const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                                            int P, int Cin, int Cout, int G, int pool, const float *gamma, const float *beta, float eps,
+                                            float *scale, float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(G > 0, "conv1x1_x6w_pooled: needs the GroupNorm statistics (G > 0)");
+    return conv_x6w_impl(wpk_main, wpk_tail, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, G, pool, gamma,
+                         beta, eps, scale, shift, pmax, mean, rstd, ws, ws_bytes, stream);
 }

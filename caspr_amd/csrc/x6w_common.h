@@ -116,3 +116,69 @@ __device__ __forceinline__ void xw_split3(const XwPair &p, u32x4 (&bw)[3], int q
     bw[2][q] = xw_cvt_pk(p.r0, p.r1);
 }
 
+
+// ---- cross-lane reductions over the 32 columns of a 32 x 32 accumulator tile, for 16 values per lane at once ---------------------------
+// In the D layout a lane (j = lane & 31, h = lane >> 5) holds, per tile, 16 rows (r & 3) + 8 (r >> 2) + 4 h of ONE column j: a per-row
+// statistic over the columns is a reduction over the 32 lanes of a half-wave for each of the 16 registers.  Done value by value that is
+// 5 cross-lane steps x 16 (and the 16-lane -> 32-lane step was a ds_bpermute).  Here the 16 values are reduced TOGETHER, the register
+// count halving at every level -- a transposition folded into the reduction:
+//   S   v_permlane16_swap (gfx950) of the pair (x[2i], x[2i+1]): afterwards one register holds both 16-lane rows of x[2i] in row 0 and of
+//       x[2i+1] in row 1 (vdst | src), so vdst (+) src is the 2-row combination of x[2i] in the even rows and of x[2i+1] in the odd ones;
+//   R8  y (+) row_ror:8 of itself for both registers, then banks 0,1 of a row keep y[2i]'s, banks 2,3 take y[2i+1]'s (masked DPP move);
+//   R4  z[2i] (+) its lane + 4 in banks 0,2, z[2i+1] (+) its lane - 4 in banks 1,3;
+//   Q   two quad_perm steps.
+// 38 instructions instead of 80 + 16 LDS crossbar operations.  Result: two registers w[0], w[1]; lane 32 h + 16 p + 4 b + q (q: four
+// copies) of w[i] holds the statistic of register index r = 8 i + 4 (b & 1) + 2 (b >> 1) + p, i.e. of row (r & 3) + 8 (r >> 2) + 4 h.
+__device__ __forceinline__ void xw_swap16(float &a, float &b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+template <int BANKS>
+__device__ __forceinline__ float xw_bank_sel(float keep, float take)      // `take` in the banks of BANKS, `keep` elsewhere
+{
+    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(keep), __float_as_uint(take), 0xE4, 0xf, BANKS, false));
+}
+struct XwAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct XwMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+struct XwMin { __device__ __forceinline__ float operator()(float a, float b) const { return fminf(a, b); } };
+struct XwFirst { __device__ __forceinline__ float operator()(float a, float) const { return a; } };      // values already equal in all lanes: transposition only
+template <class OP>
+__device__ __forceinline__ void xw_treduce16(float (&x)[16], float (&w)[2], OP op)
+{
+    constexpr bool PICK = std::is_same<OP, XwFirst>::value;
+    float y[8], z[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float a = x[2 * i], b = x[2 * i + 1];
+        xw_swap16(a, b);
+        y[i] = op(a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (PICK)
+            z[i] = xw_bank_sel<0xC>(y[2 * i], y[2 * i + 1]);
+        else         // each register with its own lane + 8 first (row_ror:8), THEN banks 0,1 from y[2i], banks 2,3 from y[2i+1]
+            z[i] = xw_bank_sel<0xC>(op(y[2 * i], dpp_mov<0x128>(y[2 * i])), op(y[2 * i + 1], dpp_mov<0x128>(y[2 * i + 1])));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (PICK) {
+            w[i] = xw_bank_sel<0xA>(z[2 * i], z[2 * i + 1]);
+        } else {
+            const float t0 = op(z[2 * i], dpp_mov<0x12C>(z[2 * i]));             // row_ror:12: lane L reads lane L + 4 (valid in banks 0, 2)
+            const float t1 = op(z[2 * i + 1], dpp_mov<0x124>(z[2 * i + 1]));     // row_ror:4:  lane L reads lane L - 4 (valid in banks 1, 3)
+            float t = xw_bank_sel<0xA>(t0, t1);
+            t = op(t, dpp_mov<0x4E>(t));
+            w[i] = op(t, dpp_mov<0xB1>(t));
+        }
+    }
+}
+// x (+) the same lane of the other 16-lane row of its half-wave, in both rows (after a 16-lane all-reduce: the 32-lane total everywhere)
+__device__ __forceinline__ float xw_rows_add(float x)
+{
+    float a = x, b = x;
+    xw_swap16(a, b);
+    return a + b;
+}

@@ -208,9 +208,22 @@ CONV_BF16X6 = _mode == "bf16x6"      # pointwise convs (conv1x1) on the bf16x6 k
 CONV_X6W = os.environ.get("CASPR_CONV_X6W", "1") != "0"     # ... and the layers with >= 512 output channels on the 512-channel kernel
 CNF_BF16X6 = _mode == "bf16x6"       # point-CNF solves on the bf16x6 kernel
 _X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstraction / input layers)
-_X6W_MIN_CIN = 1024   # the 512-channel kernel (gemm_bf16x6w.hip) runs one workgroup per CU: its prologue / epilogue are exposed, and only the
-                      # 1600-wide head layer's K loop (50 chunks) amortises them -- measured: 8.03 vs 8.50 ms there, 0.95 vs 0.91 ms at 512 -> 512
+# the 512-channel kernel (gemm_bf16x6w.hip) from this many input channels.  Round 3: 1024 (one workgroup per tile, prologue / epilogue
+# exposed: only the 1600-wide head layer's 50-chunk K loop amortised them).  Round 4: the kernel is persistent and its statistics
+# epilogue shorter (6.8 vs 7.07 ms on the head layer), so the layers with >= 512 output channels, >= 512 input channels and >= 1024 rows
+# per batch entry (_X6W_MIN_ROWS: the coarse levels -- 640 tiles at cfg-2 -- quantise badly onto a persistent grid of 256 workgroups) take it:
+# in-step at cfg-2 576 -> 1600: 3.40 -> 3.24 ms, 512 -> 512: 0.92 -> 0.87, 544 -> 512: 0.89 -> 0.84; the 128 -> 1024 layer (4 k-chunks per
+# tile) and the 81,920-row levels are faster on the 256-channel kernel.  (CASPR_X6W_MIN_CIN: debugging knob of the Python host)
+_X6W_MIN_CIN = int(os.environ.get("CASPR_X6W_MIN_CIN", "512"))
+_X6W_MIN_ROWS = 1024
 _X6_GN_MIN_CIN = 64   # conv + GroupNorm statistics in one pass (conv1x1_gn): pays from a smaller width (no second pass over the output)
+
+
+def _x6w_fills(pw, B, P):
+    """Rows per batch entry from which the persistent 512-channel kernel is chosen.  By the entry's shape only, NEVER by the number of
+    entries: a sequence's result must not depend on the batch around it (bitwise sharding invariance), and the two kernels round
+    differently."""
+    return P >= _X6W_MIN_ROWS
 
 
 def set_matmul_mode(mode=None, conv=None, cnf=None):
@@ -308,7 +321,7 @@ def conv1x1(pw, bias, x, bbias=None, in_scale=None, in_shift=None, in_relu=False
     if out is None:
         out = torch.empty(B, P, (pw.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
     ldy = _chk_rows(out)
-    if CONV_BF16X6 and CONV_X6W and pw.x6w_ok and P % 128 == 0 and not row_invariant and in_relu_from % 8 == 0 and act == 0:
+    if CONV_BF16X6 and CONV_X6W and pw.x6w_ok and P % 128 == 0 and not row_invariant and in_relu_from % 8 == 0 and act == 0 and _x6w_fills(pw, B, P):
         main, tail = pw.xw()
         with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, pw.cout, B * P), 2):
             _lib.check(_lib.load().caspr_conv1x1_x6w_f32(_p(main), _p(tail), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
@@ -390,6 +403,19 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
     pmax = torch.empty(Bs, C, device=dev, dtype=torch.float32) if want_max else None
     L = _lib.load()
     ws = _workspace(L.caspr_conv_gn_ws_bytes(B, P, C), dev)
+    if pool > 1 and CONV_X6W and pw.x6w_ok and _x6w_fills(pw, B, P):
+        main, tail = pw.xw()
+        with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):
+            _lib.check(L.caspr_conv1x1_x6w_pooled_f32(_p(main), _p(tail), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
+                                                      int(in_relu_from), _p(y), ldy, B, P, pw.cin, C, groups, int(pool), _p(gamma), _p(beta), float(eps),
+                                                      _p(scale), _p(shift), _p(pmax), _p(mean), _p(rstd), _p(ws), ws.numel(), _stream()),
+                       "caspr_conv1x1_x6w_pooled_f32")
+        res = (y, scale, shift)
+        if want_moments:
+            res += (mean, rstd)
+        if want_max:
+            res += (pmax,)
+        return res
     if pool > 1:
         with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):
             _lib.check(L.caspr_conv1x1_gn_pooled_bf16x6_f32(_p(pw.x3()), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),
@@ -402,7 +428,7 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
         if want_max:
             res += (pmax,)
         return res
-    if CONV_X6W and pw.x6w_ok:
+    if CONV_X6W and pw.x6w_ok and _x6w_fills(pw, B, P):
         main, tail = pw.xw()
         with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):
             _lib.check(L.caspr_conv1x1_x6w_f32(_p(main), _p(tail), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu),

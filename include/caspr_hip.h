@@ -179,6 +179,12 @@ int caspr_conv1x1_x6w_f32(const void *wpk_main, const void *wpk_tail, const floa
                           const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
                           int P, int Cin, int Cout, int G, const float *gamma, const float *beta, float eps, float *scale,
                           float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream);
+/* ... with the statistics pooled over `pool` consecutive batch entries (G > 0), as caspr_conv1x1_gn_pooled_bf16x6_f32: the head's first
+ * layer reads per-FRAME normalised features but normalises its own output per SEQUENCE (tpointnet2.py:96-99).                       */
+int caspr_conv1x1_x6w_pooled_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                                 const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                                 int P, int Cin, int Cout, int G, int pool, const float *gamma, const float *beta, float eps, float *scale,
+                                 float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream);
 
 /* GroupNorm statistics of Y (B,P,C) (nn.GroupNorm(G,C), biased variance, eps):
  *   scale[b,c] = gamma[c]*rstd[b,g(c)] ; shift[b,c] = beta[c] - mean[b,g(c)]*scale[b,c]

@@ -413,7 +413,8 @@ def test_conv1x1_x6w_kernel(ops, dev, B, P_, Cin, Cout):
     x = rnd(Cin + Cout, B, P_, Cin)
     sc_in, sh_in = rnd(4, B, Cin).abs() + 0.5, rnd(5, B, Cin)
     gamma, beta = rnd(6, Cout) * 0.2 + 1.0, rnd(7, Cout) * 0.1
-    min_cin, ops._X6W_MIN_CIN = ops._X6W_MIN_CIN, 256       # the host sends only the 1600-wide head layer there by default
+    min_cin, ops._X6W_MIN_CIN = ops._X6W_MIN_CIN, 256       # by default the host sends layers with >= 512 input channels and >= 1024 rows there
+    min_rows, ops._X6W_MIN_ROWS = ops._X6W_MIN_ROWS, 128
     try:
         pw = ops.PackedWeight(w.to(dev))
     finally:
@@ -435,6 +436,13 @@ def test_conv1x1_x6w_kernel(ops, dev, B, P_, Cin, Cout):
     finally:
         ops.CONV_X6W = prev
     tol = 2e-6 * max(1.0, float(y64.abs().max()))
+    try:
+        _x6w_rest(ops, dev, B, P_, Cin, Cout, pw, w, b, bb, x, sc_in, sh_in, y, yp, y_old, res, res_old, y64, tol)
+    finally:
+        ops._X6W_MIN_ROWS = min_rows
+
+
+def _x6w_rest(ops, dev, B, P_, Cin, Cout, pw, w, b, bb, x, sc_in, sh_in, y, yp, y_old, res, res_old, y64, tol):
     record("conv_x6w_fused_%dx%d" % (Cin, Cout), y[:, :, :Cout], y64, tol)
     record("conv_x6w_plain_%dx%d" % (Cin, Cout), yp[:, :, :Cout], x.double() @ w.double().t() + b.double(), tol)
     assert not torch.equal(y, y_old), "both settings ran the same kernel"
