@@ -77,6 +77,12 @@ class _Group(torch.autograd.Function):
     def backward(ctx, g):            # (B,M,3+C,ns) -> d features (B,C,n); xyz carries no gradient in the reference's use
         (idx,) = ctx.saved_tensors
         C = ctx.C
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # Kaolin's grouper is differentiable in the coordinates (scatter of the first three rows, minus their sum for new_xyz);
+            # the reference never asks for that (its clouds are data) and this build has no kernel for it: refuse rather than
+            # hand back a silent None
+            raise NotImplementedError("PointNet2GroupingLayer: the gradient with respect to xyz / new_xyz is not built "
+                                      "(detach the coordinates; the reference's inputs do not require grad)")
         if C == 0 or not ctx.needs_input_grad[2]:
             return None, None, None, None
         B, M, _, ns = g.shape

@@ -55,6 +55,14 @@ class GradBucket:
         self.sizes = [p.numel() for p in self.params]
         self.flat = None
         self.views = None
+        # Which parameters the loss reaches.  With .grad bound to a zeroed view EVERY parameter has a gradient tensor, also the
+        # ones no loss term touches; the reference (optimizer.zero_grad(): set_to_none) leaves those at None and Adam skips them
+        # -- no state, no weight decay.  A post-accumulate hook marks the parameters autograd wrote to; drop_untouched() gives the
+        # others their None back before the optimizer step.  The set is a property of the model configuration, so it is
+        # agreed between the ranks ONCE (one small collective, at the first step) and re-checked locally afterwards.
+        self._touched = set()
+        self._mask = None
+        self._hooks = [p.register_post_accumulate_grad_hook(lambda t, i=i: self._touched.add(i)) for i, p in enumerate(self.params)]
 
     def attach(self):
         """(Re)bind every .grad to its slice of the flat buffer; gradient values already present are kept."""
@@ -78,6 +86,23 @@ class GradBucket:
     def zero(self):
         self.attach()
         self.flat.zero_()
+        self._touched.clear()
+
+    def drop_untouched(self):
+        """After backward (and the all-reduce): parameters no rank's loss reached get .grad = None, as in the reference, so that
+        the optimizer skips them (zero() re-binds the views).  A rank without data this step contributes nothing to the set."""
+        local = torch.zeros(len(self.params), dtype=torch.float32)
+        local[list(self._touched)] = 1.0
+        if self._mask is None or bool((local > self._mask).any()):
+            mask = local.clone()
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                m = mask.to(self.params[0].device)
+                dist.all_reduce(m, op=dist.ReduceOp.MAX)
+                mask = m.cpu()
+            self._mask = mask if self._mask is None else torch.maximum(self._mask, mask)
+        for p, keep in zip(self.params, self._mask.tolist()):
+            if not keep:
+                p.grad = None
 
     def all_reduce_mean(self, weight=1.0):
         """Weighted average of the gradients over the ranks: sum_r weight_r * grad_r / sum_r weight_r, with weight = the
@@ -134,6 +159,7 @@ def train_step(model, optimizer, pcl_in, nocs_out, cnf_loss_weight=0.01, tnocs_l
         if bucket is None:
             return float('nan'), float('nan'), float('nan')
         bucket.all_reduce_mean(weight=0)
+        bucket.drop_untouched()
         optimizer.step()
         return float('nan'), float('nan'), float('nan')
     losses = model(pcl_in, nocs_out, e=e) if e is not None else model(pcl_in, nocs_out)
@@ -141,6 +167,7 @@ def train_step(model, optimizer, pcl_in, nocs_out, cnf_loss_weight=0.01, tnocs_l
     loss.backward()
     if bucket is not None:
         bucket.all_reduce_mean(weight=n_local)
+        bucket.drop_untouched()
     optimizer.step()
     return float(loss.detach()), float(cnf_loss.detach()), float(tnocs_loss.detach())
 
@@ -162,7 +189,7 @@ def run_one_epoch(model, data_loader, device, optimizer, cnf_loss_weight, tnocs_
     if mode not in ['train', 'val', 'test']:
         raise ValueError('mode must be train, val or test')
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    out, wsum, nsum = [], 0.0, 0
+    out, wsum, nsum, bsum, bnum = [], 0.0, 0, 0.0, 0
     for i, data in enumerate(data_loader):
         pcl_in, nocs_out = data[0]
         pcl_in, nocs_out = shard_batch(pcl_in.to(device), nocs_out.to(device))
@@ -178,16 +205,19 @@ def run_one_epoch(model, data_loader, device, optimizer, cnf_loss_weight, tnocs_
             with torch.no_grad():
                 loss, cnf_l, tnocs_l = (float(v) for v in training_loss(model(pcl_in, nocs_out), cnf_loss_weight, tnocs_loss_weight))
             wsum, nsum = wsum + loss * n_local, nsum + n_local
+            bsum, bnum = bsum + loss, bnum + 1
         if n_local:
             out.append(loss)
             if i % print_stats_every == 0:
                 log('%s epoch %d batch %d/%d: loss %.6f (cnf %.6f, tnocs %.6f)' % (mode, epoch, i, len(data_loader), loss, cnf_l, tnocs_l))
     if mode == 'train':
         return out
-    # validation loss = mean over every SEQUENCE of every rank, for any world size: the BEST-checkpoint decision must not
-    # depend on the number of GPUs.  (The reference averages per-batch means, train_utils.py:226 -- the same number whenever
-    # every batch is full, which its DataLoader arranges for validation with the batch sizes of its configs; with a ragged
-    # last batch the sequence-weighted mean is the one that is invariant to how the batches were cut.)
+    # One process: the reference's number exactly -- the mean of the per-batch means (train_utils.py:226), ragged last batch
+    # included -- so that the BEST-checkpoint decision is the reference's.  Several ranks: the mean over every SEQUENCE of every
+    # rank (a rank's "batches" are shards, their per-batch means are not the reference's either; the sequence-weighted mean is the
+    # one that does not depend on the number of GPUs, and equals the reference's whenever every batch is full).
+    if not distributed:
+        return bsum / bnum if bnum else float('nan')
     if distributed:
         acc = torch.tensor([wsum, float(nsum)], dtype=torch.float64, device=device)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)

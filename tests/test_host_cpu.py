@@ -294,6 +294,38 @@ def test_plain_invocation_starts_its_own_ranks(tmp_path, monkeypatch):
     assert ensure_ranks(4, "x.py", []) == (3, 3, 4)
 
 
+def test_parameters_the_loss_does_not_reach_keep_grad_none_with_the_bucket():
+    """Reference semantics of optimizer.zero_grad() + backward: a parameter no loss term reaches has .grad None and Adam skips it (no
+    state, no weight decay).  With the gradients living in GradBucket's views every parameter would have a (zero) gradient tensor and
+    weight decay would shrink the unused ones: GradBucket.drop_untouched() hands the None back.  Also: single-process validation
+    returns the reference's mean of per-batch means (train_utils.py:226) on a ragged last batch."""
+    from caspr_amd.train.loop import GradBucket
+    torch.manual_seed(0)
+    used, unused = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+    params = list(used.parameters()) + list(unused.parameters())
+    ref_used, ref_unused = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+    ref_used.load_state_dict(used.state_dict())
+    ref_unused.load_state_dict(unused.state_dict())
+    ref_params = list(ref_used.parameters()) + list(ref_unused.parameters())
+    opt = torch.optim.Adam(params, lr=1e-2, weight_decay=0.1)
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-2, weight_decay=0.1)
+    bucket = GradBucket(params)
+    x = torch.randn(5, 4)
+    for _ in range(3):
+        bucket.zero()
+        used(x).pow(2).mean().backward()
+        bucket.all_reduce_mean(weight=5)
+        bucket.drop_untouched()
+        assert all(p.grad is None for p in unused.parameters()) and all(p.grad is not None for p in used.parameters())
+        opt.step()
+        ref_opt.zero_grad()
+        ref_used(x).pow(2).mean().backward()
+        ref_opt.step()
+    for p, q in zip(params, ref_params):
+        assert torch.equal(p.data, q.data)
+    assert torch.equal(unused.weight.data, ref_unused.weight.data) and len(opt.state) == 2
+
+
 def test_training_loss_weights():
     """train_utils.py:151-165: 0.01 * mean_{b,t}(sum_n nll) + 100 * mean(tnocs[..., :4]); pretrain tuple has one entry."""
     from caspr_amd.train.loop import training_loss
