@@ -432,11 +432,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
 __global__ __launch_bounds__(256) void conv_gn_finalize_kernel(const f32x4 *__restrict__ part, int PT, int P, int C, int G,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                                float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ pmax,
-                                                               float *__restrict__ mean_out, float *__restrict__ rstd_out)
+                                                               float *__restrict__ mean_out, float *__restrict__ rstd_out, int g0 = 0)
 {
     __shared__ double s_sum[256], s_sq[256], s_m2[256];
     __shared__ float s_mx[256], s_mn[256];
-    const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, tid = threadIdx.x;
+    const int g = g0 + blockIdx.x, b = blockIdx.y, cpg = C / G, tid = threadIdx.x;      // g0: a launch may finalize a RANGE of groups
     const f32x4 *base = part + (long)b * PT * C + g * cpg;
     // every element of `part` = {mean, M2, max, min} of one channel over one 128-point tile.  ONE pass: a thread walks the tiles of
     // ITS channel (cpg <= 256: 256 / cpg tile lanes per channel), summing the tile means, their squares and the tiles' M2 in f64 --
@@ -704,8 +704,8 @@ extern "C" int caspr_conv1x1_gn_pooled_bf16x6_f32(const void *wpk, const float *
 // statistics of the output (as caspr_conv1x1_gn_bf16x6_f32).
 // ---------------------------------------------------------------------------------------------------------------------------
 int caspr_conv_x6w_launch(const void *wpk, const float *bias, const float *bbias, int bb_stride, const float *X, int ldx, const float *in_scale,
-                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout, void *part,
-                          int part_stride, hipStream_t stream) __attribute__((visibility("hidden")));
+                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int mt_begin, int mt_end,
+                          void *part, int part_stride, int reserve_cus, hipStream_t stream) __attribute__((visibility("hidden")));
 
 static int conv_x6w_impl(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
                          const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
@@ -731,8 +731,8 @@ static int conv_x6w_impl(const void *wpk_main, const void *wpk_tail, const float
     } else {
         CASPR_REQUIRE(Y, "conv1x1_x6w: Y is NULL");
     }
-    int rc = caspr_conv_x6w_launch(wpk_main, bias, bbias, Cout, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cmain, part, Cout,
-                                   (hipStream_t)stream);
+    int rc = caspr_conv_x6w_launch(wpk_main, bias, bbias, Cout, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, 0, Cmain / 512, part,
+                                   Cout, 0, (hipStream_t)stream);
     if (rc != CASPR_OK) return rc;
     CASPR_CHECK_LAUNCH("conv1x1_x6w");
     if (Ctail) {
@@ -767,4 +767,56 @@ extern "C" int caspr_conv1x1_x6w_pooled_f32(const void *wpk_main, const void *wp
     CASPR_REQUIRE(G > 0, "conv1x1_x6w_pooled: needs the GroupNorm statistics (G > 0)");
     return conv_x6w_impl(wpk_main, wpk_tail, bias, bbias, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, Cout, G, pool, gamma,
                          beta, eps, scale, shift, pmax, mean, rstd, ws, ws_bytes, stream);
+}
+
+// The same layer in PIECES, for a caller that needs some of the output's GroupNorm statistics before the whole layer is done (the
+// encoder's head: the latent ODE starts from the max over points of the first 64 normalised channels of the 1600 -> 1600 layer,
+// tpointnet2.py:100,111 + caspr.py:169 -- group 0 of 16 -- which are complete after the FIRST channel tile):
+//   caspr_conv1x1_x6w_part_f32      channel tiles mt_begin .. mt_end - 1 of the 512-channel kernel (+ the < 512-channel remainder when
+//                                   with_tail), output and per-tile statistics partials into ws; no finalize.  reserve_cus compute
+//                                   units are left to a kernel of another stream that runs beside it;
+//   caspr_conv_gn_finalize_f32      scale / shift / pmax / mean / rstd of groups g_begin .. g_end - 1 from the partials in ws.
+// Pieces + finalize over all groups == caspr_conv1x1_x6w_f32 / _pooled_f32, bit for bit (tiles and groups are independent).
+extern "C" int caspr_conv1x1_x6w_part_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                                          const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                                          int P, int Cin, int Cout, int mt_begin, int mt_end, int with_tail, int reserve_cus, void *ws, long ws_bytes,
+                                          void *stream)
+{
+    const int Cmain = Cout - Cout % 512, Ctail = Cout - Cmain;
+    CASPR_REQUIRE(wpk_main && X && B > 0 && P > 0 && Cmain >= 512 && (Ctail == 0 || !with_tail || wpk_tail), "conv1x1_x6w_part: bad arguments");
+    CASPR_REQUIRE(mt_begin >= 0 && mt_begin <= mt_end && mt_end <= Cmain / 512, "conv1x1_x6w_part: channel tiles %d..%d of %d", mt_begin, mt_end, Cmain / 512);
+    CASPR_REQUIRE(Cin % 32 == 0 && Cin >= 64 && Cout % 4 == 0 && P % 128 == 0, "conv1x1_x6w_part: needs Cin %% 32 == 0, Cout %% 4 == 0 and P %% 128 == 0");
+    CASPR_REQUIRE(ldx % 4 == 0 && ldx >= Cin && (!Y || (ldy % 4 == 0 && ldy >= Cout)), "conv1x1_x6w_part: row strides must be multiples of 4 and cover the channels");
+    CASPR_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv1x1_x6w_part: in_scale/in_shift must be given together");
+    CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wpk_main % 16) == 0 && ((uintptr_t)wpk_tail % 16) == 0 &&
+                  ((uintptr_t)bias % 16) == 0 && ((uintptr_t)bbias % 16) == 0 && ((uintptr_t)ws % 16) == 0, "conv1x1_x6w_part: pointers must be 16-byte aligned");
+    CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 8 == 0, "conv1x1_x6w_part: in_relu_from must be a non-negative multiple of 8");
+    CASPR_REQUIRE((long)B * (P / 128) * (Cmain / 512) < (1L << 31), "conv1x1_x6w_part: too many tiles");
+    CASPR_REQUIRE(ws && ws_bytes >= caspr_conv_gn_ws_bytes(B, P, Cout), "conv1x1_x6w_part: workspace too small");
+    f32x4 *part = (f32x4 *)ws;
+    int rc = CASPR_OK;
+    if (mt_end > mt_begin) {
+        rc = caspr_conv_x6w_launch(wpk_main, bias, bbias, Cout, X, ldx, in_scale, in_shift, in_relu, in_relu_from, Y, ldy, B, P, Cin, mt_begin, mt_end, part,
+                                   Cout, reserve_cus, (hipStream_t)stream);
+        if (rc != CASPR_OK) return rc;
+        CASPR_CHECK_LAUNCH("conv1x1_x6w_part");
+    }
+    if (Ctail && with_tail)
+        rc = conv_x6_launch(wpk_tail, bias ? bias + Cmain : nullptr, bbias ? bbias + Cmain : nullptr, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
+                            Y ? Y + Cmain : nullptr, ldy, B, P, Cin, Ctail, 0, part + Cmain, stream, Cout);
+    return rc;
+}
+
+extern "C" int caspr_conv_gn_finalize_f32(const void *ws, long ws_bytes, int B, int P, int Cout, int G, int g_begin, int g_end, int pool,
+                                          const float *gamma, const float *beta, float eps, float *scale, float *shift, float *pmax, float *mean,
+                                          float *rstd, void *stream)
+{
+    CASPR_REQUIRE(ws && gamma && beta && scale && shift && G > 0 && Cout % G == 0 && (mean == nullptr) == (rstd == nullptr), "conv_gn_finalize: bad arguments");
+    CASPR_REQUIRE(0 <= g_begin && g_begin < g_end && g_end <= G, "conv_gn_finalize: groups %d..%d of %d", g_begin, g_end, G);
+    CASPR_REQUIRE(pool >= 1 && B % pool == 0 && B / pool <= 65535 && P % X6_TP == 0, "conv_gn_finalize: pool=%d must divide B=%d; P %% 128 == 0", pool, B);
+    CASPR_REQUIRE(ws_bytes >= caspr_conv_gn_ws_bytes(B, P, Cout) && ((uintptr_t)ws % 16) == 0, "conv_gn_finalize: workspace too small or misaligned");
+    conv_gn_finalize_kernel<<<dim3(g_end - g_begin, B / pool), dim3(256), 0, (hipStream_t)stream>>>((const f32x4 *)ws, pool * (P / X6_TP), pool * P, Cout, G, gamma,
+                                                                                                     beta, eps, scale, shift, pmax, mean, rstd, g_begin);
+    CASPR_CHECK_LAUNCH("conv_gn_finalize");
+    return CASPR_OK;
 }

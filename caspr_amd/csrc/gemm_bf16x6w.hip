@@ -38,7 +38,7 @@ struct ConvWArgs {
     const float *bias, *bbias, *X;
     float *Y;
     f32x4 *part;
-    int ldx, ldy, P, Cin, Cout, in_relu, relu_from, Mt, Pt, part_stride, bb_stride, ntiles;
+    int ldx, ldy, P, Cin, Cout, in_relu, relu_from, Mt, Pt, part_stride, bb_stride, ntiles, mt0;
 };
 
 // One chunk of the flattened (tile, k-chunk) sequence a workgroup walks through: everything here is wave-uniform (SGPRs).
@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256, 1) void conv1x1_x6w_kernel(ConvWArgs a, const 
     const int lin_last = blockIdx.x + (nmine - 1) * G;
 
     auto decode = [&](CwChunk &c) XW_INL {
-        c.mt = c.lin / npt;
-        const int gpt = c.lin - c.mt * npt;
+        const int mtl = c.lin / npt;
+        const int gpt = c.lin - mtl * npt;
+        c.mt = a.mt0 + mtl;                 // a launch may cover a RANGE of channel tiles (mt0 .. mt0 + Mt - 1)
         c.b = gpt / a.Pt;
         c.pt = gpt - c.b * a.Pt;
     };
@@ -395,17 +396,19 @@ extern "C" int caspr_pack_weight_x6w(const float *w, int ldw, int Cout, int col0
 }
 
 int caspr_conv_x6w_launch(const void *wpk, const float *bias, const float *bbias, int bb_stride, const float *X, int ldx, const float *in_scale,
-                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout, void *part,
-                          int part_stride, hipStream_t stream) __attribute__((visibility("hidden")));
+                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int mt_begin, int mt_end,
+                          void *part, int part_stride, int reserve_cus, hipStream_t stream) __attribute__((visibility("hidden")));
 
+// channel tiles mt_begin .. mt_end - 1 (512 channels each) of the layer; reserve_cus: compute units left free for a kernel of another
+// stream that is to run BESIDE this one (the persistent grid is static: a workgroup that has to wait for a unit delays its whole share)
 int caspr_conv_x6w_launch(const void *wpk, const float *bias, const float *bbias, int bb_stride, const float *X, int ldx, const float *in_scale,
-                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout, void *part,
-                          int part_stride, hipStream_t stream)
+                          const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int mt_begin, int mt_end,
+                          void *part, int part_stride, int reserve_cus, hipStream_t stream)
 {
     ConvWArgs a;
     a.wpk = (const unsigned char *)wpk; a.bias = bias; a.bbias = bbias; a.X = X; a.Y = Y;
-    a.part = (f32x4 *)part; a.ldx = ldx; a.ldy = ldy; a.P = P; a.Cin = Cin; a.Cout = Cout; a.in_relu = in_relu; a.relu_from = in_relu_from;
-    a.Mt = Cout / CW_TM; a.Pt = P / CW_TP; a.part_stride = part_stride; a.bb_stride = bb_stride;
+    a.part = (f32x4 *)part; a.ldx = ldx; a.ldy = ldy; a.P = P; a.Cin = Cin; a.Cout = mt_end * CW_TM; a.in_relu = in_relu; a.relu_from = in_relu_from;
+    a.Mt = mt_end - mt_begin; a.mt0 = mt_begin; a.Pt = P / CW_TP; a.part_stride = part_stride; a.bb_stride = bb_stride;
     const long ntiles = (long)B * a.Mt * a.Pt;
     a.ntiles = (int)ntiles;
     // persistent: one workgroup per CU (512 registers per lane: one wave per SIMD), each walking through its share of the tiles
@@ -415,7 +418,9 @@ int caspr_conv_x6w_launch(const void *wpk, const float *bias, const float *bbias
         (void)hipGetDevice(&dev);
         n_cu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    const long nblk = ntiles < n_cu ? ntiles : n_cu;
+    long grid = n_cu - (reserve_cus > 0 ? reserve_cus : 0);
+    if (grid < 1) grid = 1;
+    const long nblk = ntiles < grid ? ntiles : grid;
     const bool fused = in_scale != nullptr, stats = part != nullptr;
 #define CW_GO(F, S) conv1x1_x6w_kernel<F, S><<<dim3((unsigned)nblk), dim3(256), CW_LDS, stream>>>(a, in_scale, in_shift)     /* 56 KB: below the 64 KB opt-in limit */
     if (fused && stats) CW_GO(true, true);

@@ -49,6 +49,10 @@ SIGNATURES = {
                                       c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_conv1x1_x6w_pooled_f32": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_fp, c_int, c_int, c_int, c_int,
                                              c_int, c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
+    "caspr_conv1x1_x6w_part_f32": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_fp, c_int, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, ctypes.c_void_p, c_long, c_stream]),
+    "caspr_conv_gn_finalize_f32": (c_int, [ctypes.c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, c_fp,
+                                           c_fp, c_stream]),
     "caspr_gn_ws_bytes": (c_long, [c_int, c_int, c_int, c_int]),
     "caspr_gn_stats_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_float, c_fp, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_latent_rk4_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_stream]),

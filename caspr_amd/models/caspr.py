@@ -10,6 +10,7 @@ Training: in train() mode with grad enabled `forward` is differentiable end to e
 with a HIP backward (caspr_amd/train/encoder_grad.py), the latent ODE and the CNF through the discrete RK4 map with
 every matrix product on the HIP kernels (caspr_amd/train/flow_grad.py).
 """
+import os
 import weakref
 
 import numpy as np
@@ -23,6 +24,36 @@ from .flow import get_point_cnf, count_nfe, PointCNFArgs
 from .utils import standard_normal_logprob, sample_gaussian, sphere_surface_points, truncated_normal
 
 
+class _EarlyLatent:
+    """The latent solve started from inside the encoder's last layer (TPointNet2.forward(early=...)): the ODE's initial state is the
+    first `channels` columns of z0 (caspr.py:169), final after that layer's first channel tile; the solve then runs on a side stream
+    on ONE compute unit per 16 sequences (the single-workgroup kernel: 51 us per evaluation, no co-residency requirement) BESIDE the
+    layer's remaining two thirds, instead of 2.3 ms on 32 units in front of the flow with the rest of the chip idle."""
+
+    def __init__(self, latent_ode, plan, stream):
+        self.latent_ode, self.plan, self.stream = latent_ode, plan, stream
+        self.channels = latent_ode.input_size
+        self.out, self.event = None, None
+
+    def reserve_cus(self, B):
+        return (32 if EARLY_LATENT_TEAM else 1) * ((B + 15) // 16)
+
+    def __call__(self, z0_partial):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            z_init = z0_partial[:, :self.channels]
+            self.out = ops.latent_rk4(z_init, self.plan["sorted_t"], self.latent_ode.rk4_steps, self.latent_ode._weights(), team=EARLY_LATENT_TEAM)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        z0_partial.record_stream(self.stream)
+        self.out.record_stream(main)
+
+
+# the latent solve beside the encoder's last layer (CASPR_EARLY_LATENT=0: in front of the flow, as in rounds 1-3; debugging knob)
+EARLY_LATENT = os.environ.get("CASPR_EARLY_LATENT", "1") != "0"
+EARLY_LATENT_TEAM = os.environ.get("CASPR_EARLY_LATENT", "1") != "single"
+_EARLY_STREAM = {}
 _EARLY_DRAW = {}      # (id(model), device, sample size) -> pinned buffer, copy stream, last copy's event (CaSPR._draw_early)
 
 
@@ -123,14 +154,19 @@ class CaSPR(nn.Module):
         """caspr.py:148-155."""
         return self.encoder(x)
 
-    def aggregate_and_solve_latent(self, z0, time_tensor, _plan=None):
+    def aggregate_and_solve_latent(self, z0, time_tensor, _plan=None, _presolved=None):
         """caspr.py:157-183: unique sorted times -> latent ODE -> map back -> concat the static feature.
         Inference on the GPU takes the synchronisation-free route of LatentODE.solve_at (same values); _plan: what
         reconstruct() prepared ahead of the encoder (LatentODE.plan_times)."""
         B, T = time_tensor.size()
         z_init = z0[:, :self.latent_ode.input_size]
         z_global = z0[:, self.latent_ode.input_size:]
-        if z0.is_cuda and not self._differentiable(z0, time_tensor):
+        if _presolved is not None and _presolved.event is not None:
+            # the solve already ran beside the encoder's last layer (_EarlyLatent): join it, gather the requested stamps
+            torch.cuda.current_stream().wait_event(_presolved.event)
+            self.latent_ode.ode_func._num_evals.copy_(_plan["evals"])
+            sample_feats = _presolved.out[_plan["rows"], _plan["pos"], :]
+        elif z0.is_cuda and not self._differentiable(z0, time_tensor):
             sample_feats = self.latent_ode.solve_at(z_init, time_tensor, _plan)
         else:
             solve_t, time_map = torch.unique(time_tensor, sorted=True, return_inverse=True)
@@ -234,11 +270,18 @@ class CaSPR(nn.Module):
             # what the latent solve needs from the time stamps alone is queued before the encoder (a dozen tiny kernels that
             # otherwise sit between the encoder's last layer and the solve, behind the T-NOCS layer's workgroups)
             plan = self.latent_ode.plan_times(all_times) if defer else None
-            z0, tnocs_pred = self.encoder(x, defer_tnocs=True) if defer else self.encode(x)
+            early_lat = None
+            if defer and EARLY_LATENT and self.latent_ode.input_size <= 64:
+                st = _EARLY_STREAM.get(str(x.device))
+                if st is None:
+                    st = _EARLY_STREAM[str(x.device)] = torch.cuda.Stream(device=x.device)
+                early_lat = _EarlyLatent(self.latent_ode, plan, st)
+            z0, tnocs_pred = self.encoder(x, defer_tnocs=True, early=early_lat) if defer else self.encode(x)
             # the encoder is queued: draw the base samples on the host now (as the reference does inside decode), under it
             early = self._draw_early(B, T, num_points, constant_in_time, x.device) if (defer and y is None and sample_contours is None) else None
             with ops.timed("latent"):
-                z = self.aggregate_and_solve_latent(z0, all_times, plan)
+                z = self.aggregate_and_solve_latent(z0, all_times, plan, early_lat)
+            self._early_latent_used = bool(early_lat is not None and early_lat.event is not None)     # for tests / tools
             if defer:
                 self.encoder.join()
             with ops.timed("decode"):

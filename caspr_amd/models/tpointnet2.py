@@ -106,10 +106,13 @@ class TPointNet2(nn.Module):
             torch.cuda.current_stream().wait_event(ev)
             self._tnocs_ready = None
 
-    def forward(self, x, defer_tnocs=False):
+    def forward(self, x, defer_tnocs=False, early=None):
         """x (B,T,N,4) -> z0 (B, out_feat_size), tnocs (B,T,N,4) | None   (tpointnet2.py:70-115).
         defer_tnocs: the T-NOCS regression (:105-106; nothing downstream of z0 needs it) is issued on the side stream and
-        the caller continues with z0 on the current one; the caller must call join() before anything reads tnocs."""
+        the caller continues with z0 on the current one; the caller must call join() before anything reads tnocs.
+        early: callable(z0_partial) invoked as soon as the first `early.channels` columns of z0 are final -- after the first
+        channel tile of the last head layer (ops.conv1x1_gn_early) -- so that the caller can start the latent solve beside
+        the rest of that layer; not called when the layer does not run in pieces (the caller then proceeds as usual)."""
         if not x.is_cuda:
             raise ValueError("caspr_amd.TPointNet2 runs on the GPU only (HIP kernels); got a %s tensor" % x.device)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -171,8 +174,12 @@ class TPointNet2(nn.Module):
             in_shift = torch.cat([torch.zeros_like(ones), pf.shift], dim=1).contiguous()
             y1, s1, t1 = ops.conv1x1_gn(w_pt, None, X1, self.bn1.weight, self.bn1.bias, bbias=bbias.view(B, -1), in_scale=in_scale,
                                         in_shift=in_shift, in_relu=True, in_relu_from=L)
-        y2, s2, t2, z0 = ops.conv1x1_gn(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, want_max=True,
-                                        in_scale=s1, in_shift=t1, in_relu=True)               # :99-100, 111
+        if early is not None and self.record is None and ops.conv1x1_gn_early_ok(p2, B, P, 16, early.channels):
+            y2, s2, t2, z0 = ops.conv1x1_gn_early(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, early, in_scale=s1, in_shift=t1,
+                                                  in_relu=True, reserve_cus=early.reserve_cus(B))   # :99-100, 111
+        else:
+            y2, s2, t2, z0 = ops.conv1x1_gn(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, want_max=True,
+                                            in_scale=s1, in_shift=t1, in_relu=True)               # :99-100, 111
         del y1
         tnocs_regression = None
         if self.regress_tnocs and defer_tnocs and self.record is None:

@@ -454,6 +454,55 @@ def conv1x1_gn(pw, bias, x, gamma, beta, groups=16, eps=1e-5, want_max=False, wa
     return res
 
 
+def conv1x1_gn_early_ok(pw, B, P, groups, early_channels):
+    """Can conv1x1_gn_early run this layer in pieces?  The 512-channel kernel must take it, in at least two channel tiles, and the
+    channels the caller wants early must lie inside GroupNorm group 0, inside the first tile."""
+    C = pw.cout
+    return bool(CONV_BF16X6 and CONV_X6W and pw.x6w_ok and P % 128 == 0 and _x6w_fills(pw, B, P) and C % groups == 0 and C // 512 >= 2
+                and early_channels <= min(C // groups, 512))
+
+
+def conv1x1_gn_early(pw, bias, x, gamma, beta, on_early, groups=16, eps=1e-5, in_scale=None, in_shift=None, in_relu=False, in_relu_from=0,
+                     reserve_cus=1):
+    """conv1x1_gn(..., want_max=True) in two pieces (caspr_conv1x1_x6w_part_f32 / caspr_conv_gn_finalize_f32): after the FIRST 512-channel
+    tile the statistics of GroupNorm group 0 are final -- `on_early(pmax)` is called with the (B, C) max-over-points tensor whose
+    group-0 columns are valid, on the current stream, and may queue work on another stream behind an event (the latent solve: it
+    starts from pmax[:, :64], caspr.py:169) -- then the remaining tiles run on all but `reserve_cus` compute units, and the full
+    finalize follows.  Returns (y, scale, shift, pmax) with the values of conv1x1_gn, bit for bit."""
+    _chk_f32(bias, in_scale, in_shift, gamma, beta)
+    B, P, _ = x.shape
+    C = pw.cout
+    if not conv1x1_gn_early_ok(pw, B, P, groups, 1):
+        raise ValueError("conv1x1_gn_early: this layer does not run on the 512-channel kernel in >= 2 channel tiles")
+    ldx = _chk_rows(x)
+    dev = x.device
+    y = torch.empty(B, P, (C + 3) // 4 * 4, device=dev, dtype=torch.float32)
+    ldy = _chk_rows(y)
+    scale = torch.empty(B, C, device=dev, dtype=torch.float32)
+    shift = torch.empty(B, C, device=dev, dtype=torch.float32)
+    pmax = torch.empty(B, C, device=dev, dtype=torch.float32)
+    L = _lib.load()
+    ws = _workspace(L.caspr_conv_gn_ws_bytes(B, P, C), dev)
+    main, tail = pw.xw()
+    mt_all = C // 512
+
+    def part(mt0, mt1, with_tail, reserve):
+        _lib.check(L.caspr_conv1x1_x6w_part_f32(_p(main), _p(tail), _p(bias), None, _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu), int(in_relu_from),
+                                                _p(y), ldy, B, P, pw.cin, C, mt0, mt1, int(with_tail), int(reserve), _p(ws), ws.numel(), _stream()),
+                   "caspr_conv1x1_x6w_part_f32")
+
+    def finalize(g0, g1):
+        _lib.check(L.caspr_conv_gn_finalize_f32(_p(ws), ws.numel(), B, P, C, groups, g0, g1, 1, _p(gamma), _p(beta), float(eps), _p(scale), _p(shift),
+                                                _p(pmax), None, None, _stream()), "caspr_conv_gn_finalize_f32")
+    with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):
+        part(0, 1, False, 0)
+        finalize(0, 1)
+        on_early(pmax)
+        part(1, mt_all, True, reserve_cus)
+        finalize(0, groups)
+    return y, scale, shift, pmax
+
+
 FEAT_QUAD, FEAT_PAIRS = 1, 2     # include/caspr_hip.h
 
 
@@ -531,9 +580,11 @@ def check_deferred_errors(wait=True):
         _team_raise_if_failed(key, wait=wait)
 
 
-def latent_rk4(z0, times, steps, wts):
+def latent_rk4(z0, times, steps, wts, team=None):
     """Fixed-step RK4 of the latent dynamics (latent_ode_model.py:45-70): z0 (B,D) (rows may be a column
-    slice of a wider tensor); wts = [PackedWeight0, b0, PackedWeight1, b1, PackedWeight2, b2, PackedWeight3, b3].  -> (B,Tu,D)."""
+    slice of a wider tensor); wts = [PackedWeight0, b0, PackedWeight1, b1, PackedWeight2, b2, PackedWeight3, b3].  -> (B,Tu,D).
+    team: True / False forces the 32-workgroup team kernel / the single-workgroup kernel (None: LATENT_TEAM where the shape allows).
+    Same values up to the re-association of the layer sums (tests: <= 5e-6)."""
     _chk_f32(times, *[w for w in wts[1::2]])
     if not z0.is_cuda or z0.dtype != torch.float32 or z0.dim() != 2 or z0.stride(1) != 1:
         raise ValueError("latent_rk4: z0 must be a float32 GPU (B,D) tensor with unit column stride")
@@ -545,7 +596,7 @@ def latent_rk4(z0, times, steps, wts):
     out = torch.empty(B, Tu, D, device=z0.device, dtype=torch.float32)
     ptrs = [_p(w.data) if isinstance(w, PackedWeight) else _p(w) for w in wts]
     L = _lib.load()
-    if LATENT_TEAM and H == 512 and D <= 64 and B <= 64:
+    if (LATENT_TEAM if team is None else team) and H == 512 and D <= 64 and B <= 64:
         # 32 workgroups per 16 sequences with LDS-resident weights (csrc/ode.hip): the serial chain runs ~3x faster
         key = (z0.device.index, torch.cuda.current_stream().cuda_stream)
         capturing = torch.cuda.is_current_stream_capturing()       # hipGraph capture: no event queries, no host copies

@@ -186,6 +186,21 @@ int caspr_conv1x1_x6w_pooled_f32(const void *wpk_main, const void *wpk_tail, con
                                  int P, int Cin, int Cout, int G, int pool, const float *gamma, const float *beta, float eps, float *scale,
                                  float *shift, float *pmax, float *mean, float *rstd, void *ws, long ws_bytes, void *stream);
 
+/* The same layer in PIECES, for a caller that needs part of the output's GroupNorm statistics before the whole layer is done: the
+ * latent ODE starts from the max over points of the first 64 normalised channels of the head's 1600 -> 1600 layer (tpointnet2.py:100,111,
+ * caspr.py:169) -- inside group 0 of 16, complete after the first 512-channel tile -- so the solve can run BESIDE the rest of the layer.
+ *   _part_     : channel tiles mt_begin .. mt_end-1 of the 512-channel kernel (+ the remainder below 512 channels when with_tail), output
+ *                rows and per-tile statistics partials into ws; reserve_cus compute units stay free for the kernel that runs beside it;
+ *   _finalize_ : scale / shift / pmax / mean / rstd of groups g_begin .. g_end-1 from ws (pool as in the _pooled_ entry).
+ * All pieces + a finalize over all groups == caspr_conv1x1_x6w_f32 bit for bit.                                                   */
+int caspr_conv1x1_x6w_part_f32(const void *wpk_main, const void *wpk_tail, const float *bias, const float *bbias, const float *X, int ldx,
+                               const float *in_scale, const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B,
+                               int P, int Cin, int Cout, int mt_begin, int mt_end, int with_tail, int reserve_cus, void *ws, long ws_bytes,
+                               void *stream);
+int caspr_conv_gn_finalize_f32(const void *ws, long ws_bytes, int B, int P, int Cout, int G, int g_begin, int g_end, int pool,
+                               const float *gamma, const float *beta, float eps, float *scale, float *shift, float *pmax, float *mean,
+                               float *rstd, void *stream);
+
 /* GroupNorm statistics of Y (B,P,C) (nn.GroupNorm(G,C), biased variance, eps):
  *   scale[b,c] = gamma[c]*rstd[b,g(c)] ; shift[b,c] = beta[c] - mean[b,g(c)]*scale[b,c]
  * and, when pmax != NULL, pmax[b,c] = max_p (Y[b,p,c]*scale+shift) (tpointnet2.py:111, pointnet.py:42).

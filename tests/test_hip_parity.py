@@ -1364,3 +1364,35 @@ def test_stress_calibrated_steps_agree_with_dopri5(dev, stress_sd, stress_sd64):
     assert cnt[0] >= 60, cnt
     record("stress_calibrated_vs_converged_f64", got, conv, 1e-5)
     record("stress_calibrated_vs_dopri5", got, dop, e_dop + 1e-5)
+
+
+def test_latent_solve_beside_the_last_head_layer(dev, seeded_sd, sd64):
+    """reconstruct() starts the latent solve from INSIDE the encoder's last layer (ops.conv1x1_gn_early: the ODE's initial state is
+    final after that layer's first channel tile; the team kernel then runs on 32 reserved compute units beside the remaining tiles).
+    Against the serial order of rounds 1-3 (CASPR_EARLY_LATENT=0): the encoder's outputs are bit-identical (the pieces of the layer
+    are the layer), the latent codes and the samples identical too (same kernel, same inputs); and the path is the one that ran."""
+    from caspr_amd.models import CaSPR
+    import caspr_amd.models.caspr as C
+    m = CaSPR()
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    x, sp = car_sequences(3, 4, 1024, seed=77)
+    torch.manual_seed(5)
+    yb = torch.randn(3, 4, 256, 3)
+    outs, used = {}, {}
+    prev = C.EARLY_LATENT
+    try:
+        for flag in (False, True):
+            C.EARLY_LATENT = flag
+            outs[flag] = m.reconstruct(x.to(dev), num_points=256, y=yb.to(dev))
+            torch.cuda.synchronize()
+            used[flag] = m._early_latent_used
+            assert [int(v) for v in m.get_nfe()] == [4 * m.latent_ode.rk4_steps * 3, 4 * m.cnf_args.rk4_steps]
+    finally:
+        C.EARLY_LATENT = prev
+    assert used[True] and not used[False]
+    exact("early_latent_tnocs", outs[True][3], outs[False][3])
+    exact("early_latent_x", outs[True][2], outs[False][2])
+    _, _, x64, t64 = O.reconstruct(sd64, x.double(), yb.double(), cnf_steps=m.cnf_args.rk4_steps, latent_steps=m.latent_ode.rk4_steps)
+    _, _, x32, t32 = O.reconstruct(seeded_sd, x, yb, cnf_steps=m.cnf_args.rk4_steps, latent_steps=m.latent_ode.rk4_steps)
+    record_f64("early_latent_x_vs_f64", outs[True][2], x32, x64, 1e-5)
