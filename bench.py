@@ -409,8 +409,11 @@ def kernel_rooflines(cnf, detail, traffic_table, shape):
         flop = sum(f * len(ms) for f, ms in sa)
         ms_all = sum(sum(ms) for _, ms in sa)
         a_sa = flop / (ms_all * 1e-3) / 1e12
+        tj = traffic_table.get("sa_all:%s" % wl)
         out.append({"kernel": "sa_small_kernel / sa_mlp_kernel (csrc/sa_mlp.hip), all fused set-abstraction launches", "bound": "mfma", "achieved": round(a_sa, 3),
-                    "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(a_sa / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(a_sa / PEAK_MFMA_F32_TFLOPS, 4),
+                    "traffic": int(1024 * (tj["fetch_size_kb_per_step"] * tj["fetch_correction"] + tj["write_size_kb_per_step"])) if tj else None,
+                    "traffic_unit": "bytes/step (all launches)",
                     "launches_per_step": sum(len(ms) for _, ms in sa) // 2, "ms_per_step": round(ms_all / 2, 3)})
     return out
 

@@ -33,5 +33,14 @@ if big:
                                                     "kernel": "conv1x1_x6w_kernel (first 1536 channels; the 64-channel remainder's launch on conv1x1_bf16x6_kernel is not included)" if xw else "conv1x1_bf16x6_kernel",
                                                     "note": note + "; the 1600 -> 1600 head layer over %d rows (input %.2f GB + output %.2f GB algorithmic)"
                                                             % (B * T * N, B * T * N * 1600 * 4 / 1e9, B * T * N * 1600 * 4 / 1e9)}
+# the fused set-abstraction launches (sa_small_kernel / sa_mlp_kernel, every instantiation): HBM-side KB per STEP = sum over the kernels
+# of (average per launch x launches per step); the passes above ran `--steps 2 --warmup 1` = 3 steps + 2 detail steps = 5 steps
+sa = [(k, v) for k, v in rows.items() if ("sa_small_kernel" in k or "sa_mlp_kernel" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+if sa:
+    steps_run = int(os.environ.get("CASPR_PMC_STEPS", "5"))
+    f = sum(v["FETCH_SIZE"]["avg"] * v["FETCH_SIZE"]["n"] for _, v in sa) / steps_run
+    w = sum(v["WRITE_SIZE"]["avg"] * v["WRITE_SIZE"]["n"] for _, v in sa) / steps_run
+    tab["sa_all:%s" % wl] = {"fetch_size_kb_per_step": f, "write_size_kb_per_step": w, "fetch_correction": 2.0, "launches_counted": sum(v["FETCH_SIZE"]["n"] for _, v in sa),
+                             "steps_in_the_pass": steps_run, "source": "profiles/%s" % committed, "note": note + "; all fused set-abstraction launches of one step together"}
 json.dump(tab, open(path, "w"), indent=1, sort_keys=True)
 print("wrote %s: %s" % (path, sorted(tab)))
