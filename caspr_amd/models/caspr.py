@@ -271,7 +271,10 @@ class CaSPR(nn.Module):
             # otherwise sit between the encoder's last layer and the solve, behind the T-NOCS layer's workgroups)
             plan = self.latent_ode.plan_times(all_times) if defer else None
             early_lat = None
-            if defer and EARLY_LATENT and self.latent_ode.input_size <= 64:
+            # worth it while the reserved units cost the layer less than the solve takes: one team (<= 16 sequences = 32 units for the
+            # two thirds of a layer that lasts ~5 ms per 327,680 rows) against ~2.3 ms of solve; larger batches / longer layers keep the
+            # serial order (cfg-5: 4 teams would halve the chip under a 75 ms layer).  Either order gives the same bits.
+            if defer and EARLY_LATENT and self.latent_ode.input_size <= 64 and B <= 16 and B * T * N <= 800000:
                 st = _EARLY_STREAM.get(str(x.device))
                 if st is None:
                     st = _EARLY_STREAM[str(x.device)] = torch.cuda.Stream(device=x.device)
