@@ -9,17 +9,17 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 python $REPO/bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?" >> $OUT/${TAG}_bench.err
-rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats -d /tmp/pk -o r -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-subblock > $OUT/${TAG}_prof_bench.json 2> /tmp/pk.err
+rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats -d /tmp/pk -o r -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-subblock --no-sub-blocks > $OUT/${TAG}_prof_bench.json 2> /tmp/pk.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/pk -name "*results.db" | head -1) $OUT/${TAG}_kernel_stats.txt
 python $REPO/tools/rocprof_timeline.py $(find /tmp/pk -name "*results.db" | head -1) $OUT/${TAG}_step_timeline.txt
 : > $OUT/${TAG}_traffic_pmc.txt
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pp && rocprofv3 --kernel-trace --pmc $C -d /tmp/pp -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/pp.err
+  rm -rf /tmp/pp && rocprofv3 --kernel-trace --pmc $C -d /tmp/pp -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-sub-blocks > /dev/null 2> /tmp/pp.err
   python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pp -name "*results.db" | head -1) /tmp/pmc_$C.txt
   grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w|sa_mlp|sa_small|gn_partial" /tmp/pmc_$C.txt >> $OUT/${TAG}_traffic_pmc.txt
   rm -f /tmp/pmc_$C.txt
 done
-rm -rf /tmp/pm && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d /tmp/pm -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/pm.err
+rm -rf /tmp/pm && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d /tmp/pm -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-sub-blocks > /dev/null 2> /tmp/pm.err
 python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pm -name "*results.db" | head -1) /tmp/pmc_sq.txt
 grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w" /tmp/pmc_sq.txt > $OUT/${TAG}_sq_pmc.txt
 # the traffic table bench.py reads (profiles/kernel_traffic.json): cfg-2
