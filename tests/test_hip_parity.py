@@ -1398,3 +1398,29 @@ def test_latent_solve_beside_the_last_head_layer(dev, seeded_sd, sd64):
     _, _, x64, t64 = O.reconstruct(sd64, x.double(), yb.double(), cnf_steps=m.cnf_args.rk4_steps, latent_steps=m.latent_ode.rk4_steps)
     _, _, x32, t32 = O.reconstruct(seeded_sd, x, yb, cnf_steps=m.cnf_args.rk4_steps, latent_steps=m.latent_ode.rk4_steps)
     record_f64("early_latent_x_vs_f64", outs[True][2], x32, x64, 1e-5)
+
+
+@pytest.mark.parametrize("B,P_,Cin,Cout,reserve", [(2, 1024, 512, 1600, 32), (3, 1280, 576, 1024, 1), (1, 2048, 1600, 1600, 0)])
+def test_conv_layer_in_pieces_is_the_layer(ops, dev, B, P_, Cin, Cout, reserve):
+    """caspr_conv1x1_x6w_part_f32 + caspr_conv_gn_finalize_f32 (ops.conv1x1_gn_early): first channel tile -> statistics of group 0 ->
+    callback -> remaining tiles (+ the remainder below 512 channels) on all but `reserve` compute units -> all groups.  Output,
+    scale / shift and the max over points must equal the one-call entry BIT FOR BIT, and at the time of the callback the columns of
+    group 0 must already hold their final values."""
+    w = rnd(1, Cout, Cin, scale=1.0 / np.sqrt(Cin))
+    b = rnd(2, Cout, scale=0.3)
+    x = rnd(3, B, P_, Cin)
+    sc_in, sh_in = rnd(4, B, Cin).abs() + 0.5, rnd(5, B, Cin)
+    gamma, beta = rnd(6, Cout) * 0.2 + 1.0, rnd(7, Cout) * 0.1
+    pw = ops.PackedWeight(w.to(dev))
+    assert ops.conv1x1_gn_early_ok(pw, B, P_, 16, 64)
+    kw = dict(in_scale=sc_in.to(dev), in_shift=sh_in.to(dev), in_relu=True)
+    whole = ops.conv1x1_gn(pw, b.to(dev), x.to(dev), gamma.to(dev), beta.to(dev), want_max=True, **kw)
+    seen = {}
+
+    def on_early(pmax):
+        seen["g0"] = pmax[:, :Cout // 16].clone()
+    parts = ops.conv1x1_gn_early(pw, b.to(dev), x.to(dev), gamma.to(dev), beta.to(dev), on_early, reserve_cus=reserve, **kw)
+    torch.cuda.synchronize()
+    for i, nm in enumerate(("y", "scale", "shift", "pmax")):
+        exact("conv_pieces_%s_%dx%d" % (nm, Cin, Cout), parts[i], whole[i])
+    exact("conv_pieces_early_group0_%dx%d" % (Cin, Cout), seen["g0"], whole[3][:, :Cout // 16])
