@@ -43,7 +43,10 @@ class _EarlyLatent:
         self.stream.wait_stream(main)
         with torch.cuda.stream(self.stream):
             z_init = z0_partial[:, :self.channels]
-            self.out = ops.latent_rk4(z_init, self.plan["sorted_t"], self.latent_ode.rk4_steps, self.latent_ode._weights(), team=EARLY_LATENT_TEAM)
+            out = ops.latent_rk4(z_init, self.plan["sorted_t"], self.latent_ode.rk4_steps, self.latent_ode._weights(), team=EARLY_LATENT_TEAM)
+            # what aggregate_and_solve_latent does with the solution, here too: off the path between the encoder's last kernel and the flow
+            self.out = out[self.plan["rows"], self.plan["pos"], :]                      # (B, T, H): the requested stamps
+            self.latent_ode.ode_func._num_evals.mul_(0).add_(self.plan["evals"])        # evaluations actually run (an element-wise op, not a blit)
             self.event = torch.cuda.Event()
             self.event.record()
         z0_partial.record_stream(self.stream)
@@ -164,9 +167,13 @@ class CaSPR(nn.Module):
         if _presolved is not None and _presolved.event is not None:
             # the solve already ran beside the encoder's last layer (_EarlyLatent): join it, gather the requested stamps
             torch.cuda.current_stream().wait_event(_presolved.event)
-            self.latent_ode.ode_func._num_evals.copy_(_plan["evals"])
-            sample_feats = _presolved.out[_plan["rows"], _plan["pos"], :]
+            sample_feats = _presolved.out
         elif z0.is_cuda and not self._differentiable(z0, time_tensor):
+            if _plan is not None and _plan.get("event") is not None:
+                torch.cuda.current_stream().wait_event(_plan["event"])                   # the plan was made on another stream
+                for v in _plan.values():
+                    if torch.is_tensor(v):
+                        v.record_stream(torch.cuda.current_stream())
             sample_feats = self.latent_ode.solve_at(z_init, time_tensor, _plan)
         else:
             solve_t, time_map = torch.unique(time_tensor, sorted=True, return_inverse=True)
@@ -210,9 +217,11 @@ class CaSPR(nn.Module):
         torch.randn(*size, out=ent["buf"])   # == torch.randn(*size): same generator, same stream position
         with torch.cuda.stream(ent["stream"]):
             yd = ent["buf"].to(device, non_blocking=True)
+            # log N(y; 0, I) of the draw (caspr.py:258) right behind the copy, under the encoder (decode uses it unless it alters y)
+            lp = standard_normal_logprob(yd).view(samp_batch, num_points, -1).sum(2)
             ent["ev"] = torch.cuda.Event()
             ent["ev"].record(ent["stream"])
-        return yd, ent["ev"]
+        return yd, ent["ev"], lp
 
     def _base_samples(self, B, T, num_points, constant_in_time, truncate_std, sample_contours, y, like, early=None):
         """The base-distribution draw of decode (caspr.py:228-256) -> (B*T, num_points, 3) on `like`'s device."""
@@ -234,7 +243,7 @@ class CaSPR(nn.Module):
                 nsamp_pts += num_points // len(radii)
             y = torch.from_numpy(np.concatenate(contours, axis=1)).to(like).view(samp_size)
         elif early is not None:
-            y, ev = early
+            y, ev = early[0], early[1]
             torch.cuda.current_stream().wait_event(ev)
             y.record_stream(torch.cuda.current_stream())
             if truncate_std is not None:
@@ -249,8 +258,13 @@ class CaSPR(nn.Module):
         """caspr.py:204-267.  `y` (B,T,num_points,3) optionally supplies the base samples."""
         B, T, H = z.size()
         input_dim = self.cnf_args.input_dim
+        given = y is not None
         y = self._base_samples(B, T, num_points, constant_in_time, truncate_std, sample_contours, y, z, early=_early)
-        logp_y = standard_normal_logprob(y).view(B * T, num_points, -1).sum(2)
+        if _early is not None and not given and sample_contours is None and truncate_std is None and not constant_in_time:
+            logp_y = _early[2]                       # computed behind the draw's copy (same values: same op on the same tensor)
+            logp_y.record_stream(torch.cuda.current_stream())
+        else:
+            logp_y = standard_normal_logprob(y).view(B * T, num_points, -1).sum(2)
         z = z.reshape((B * T, H))
         x = self.point_cnf(y, z, reverse=True)
         return y.view((B, T, num_points, input_dim)), logp_y.view((B, T, num_points)), x.view((B, T, num_points, input_dim))
@@ -269,15 +283,23 @@ class CaSPR(nn.Module):
             defer = x.is_cuda and not self._differentiable(x)
             # what the latent solve needs from the time stamps alone is queued before the encoder (a dozen tiny kernels that
             # otherwise sit between the encoder's last layer and the solve, behind the T-NOCS layer's workgroups)
-            plan = self.latent_ode.plan_times(all_times) if defer else None
-            early_lat = None
+            plan, early_lat, st = None, None, None
+            if defer:
+                # (the time-stamp bookkeeping -- sort, inverse permutation, evaluation count: a dozen tiny kernels -- on the stream the
+                # solve will run on, not in front of the encoder)
+                st = _EARLY_STREAM.get(str(x.device))
+                if st is None:
+                    st = _EARLY_STREAM[str(x.device)] = torch.cuda.Stream(device=x.device)
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    plan = self.latent_ode.plan_times(all_times)
+                    plan["event"] = torch.cuda.Event()
+                    plan["event"].record()
+                all_times.record_stream(st)
             # worth it while the reserved units cost the layer less than the solve takes: one team (<= 16 sequences = 32 units for the
             # two thirds of a layer that lasts ~5 ms per 327,680 rows) against ~2.3 ms of solve; larger batches / longer layers keep the
             # serial order (cfg-5: 4 teams would halve the chip under a 75 ms layer).  Either order gives the same bits.
             if defer and EARLY_LATENT and self.latent_ode.input_size <= 64 and B <= 16 and B * T * N <= 800000:
-                st = _EARLY_STREAM.get(str(x.device))
-                if st is None:
-                    st = _EARLY_STREAM[str(x.device)] = torch.cuda.Stream(device=x.device)
                 early_lat = _EarlyLatent(self.latent_ode, plan, st)
             z0, tnocs_pred = self.encoder(x, defer_tnocs=True, early=early_lat) if defer else self.encode(x)
             # the encoder is queued: draw the base samples on the host now (as the reference does inside decode), under it
