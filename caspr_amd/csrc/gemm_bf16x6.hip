@@ -425,6 +425,168 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bf16x6_kernel(const unsigned c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The REMAINDER of a layer below one 512-channel tile of conv1x1_x6w_kernel (1600 = 3 x 512 + 64): <= 64 output channels over all rows.
+// On the kernel above that pass cost 0.79 ms of the 1600 -> 1600 head layer (4 % of the channels, 10 % of the time): half its waves hold
+// no channels and only stage, every 32-k chunk goes through LDS behind two barriers.  With <= 64 channels the products are a twentieth of
+// a full tile's and the pass is bound by READING the input once, so this kernel has no LDS and no barrier in its K loop: a wave owns 64
+// points; lane (j, g) loads the 8 consecutive k (32 bytes) of ITS point straight into B-fragment shape, applies the producer's GroupNorm +
+// ReLU, splits into the three planes in registers and multiplies; the weight fragments come from the same pre-swizzled pack (16 rows x
+// 64 B = 1 KB per fragment, L1 / L2 hits).  Epilogue and statistics format as above (two 64-point halves per tile, combined through LDS).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool FUSED, bool STATS>
+__global__ __launch_bounds__(256) void conv1x1_x6tail_kernel(const unsigned char *__restrict__ wpk, const float *__restrict__ bias,
+                                                             const float *__restrict__ bbias, const float *__restrict__ X, int ldx,
+                                                             const float *__restrict__ in_scale, const float *__restrict__ in_shift, int in_relu,
+                                                             int relu_from, float *__restrict__ Y, int ldy, int P, int Cin, int Cout, int Pt, int ntile,
+                                                             f32x4 *__restrict__ part, int cstride)
+{
+    __shared__ f32x4 sp[2][2][64];                       // [tile of the workgroup][64-point half][channel]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int tl = wave >> 1, hf = wave & 1;
+    const int gt0 = blockIdx.x * 2 + tl;
+    const bool valid = gt0 < ntile;                      // wave-uniform; an invalid wave computes a copy of the last tile and stores nothing
+    const int gt = valid ? gt0 : ntile - 1;
+    const int b = gt / Pt, pt = gt - b * Pt;
+    const int p0 = pt * X6_TP + hf * 64;
+    const int nk = Cin / 32;
+    const int nrt = (Cout + 15) >> 4;                    // live row tiles (<= 4)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float *xrow = X + ((long)b * P + p0 + j) * ldx + 8 * g;          // + 16 ni rows, + 32 kc
+    const long xstep = 16L * ldx;
+    const float *sc = FUSED ? in_scale + (long)b * Cin + 8 * g : nullptr;
+    const float *sh = FUSED ? in_shift + (long)b * Cin + 8 * g : nullptr;
+    const unsigned char *wl = wpk;                                           // channel tile 0 of the remainder's own pack
+    f32x4 ra[4][2], rb[4][2];
+    auto gload = [&](f32x4 (&r)[4][2], int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            r[ni][0] = ld4(xrow + ni * xstep + kc * 32);
+            r[ni][1] = ld4(xrow + ni * xstep + kc * 32 + 4);
+        }
+    };
+    auto chunk = [&](const f32x4 (&r)[4][2], int kc) __attribute__((always_inline)) {
+        bf16x8 af[4][3];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            if (mi < nrt) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[mi][pl] = *(const bf16x8 *)(wl + (long)kc * X6_CHUNK + pl * X6_PA + x6_off(mi * 16 + j, g));
+            }
+        f32x4 s0, s1, t0, t1;
+        float lo = -INFINITY;
+        if (FUSED) {
+            s0 = ld4(sc + kc * 32); s1 = ld4(sc + kc * 32 + 4);
+            t0 = ld4(sh + kc * 32); t1 = ld4(sh + kc * 32 + 4);
+            lo = (in_relu && kc * 32 + 8 * g >= relu_from) ? 0.f : -INFINITY;   // the ReLU switches on at a multiple of 8 channels
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            float xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = r[ni][q >> 2][q & 3];
+                if (FUSED) v = fmaxf(v * (q < 4 ? s0[q & 3] : s1[q & 3]) + (q < 4 ? t0[q & 3] : t1[q & 3]), lo);
+                xv[q] = v;
+            }
+            u32x4 pv[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned p1, p2, p3;
+                x6_split_pair(xv[2 * q], xv[2 * q + 1], p1, p2, p3);
+                pv[0][q] = p1;
+                pv[1][q] = p2;
+                pv[2][q] = p3;
+            }
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, pv[0]), b1 = __builtin_bit_cast(bf16x8, pv[1]), b2 = __builtin_bit_cast(bf16x8, pv[2]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                if (mi < nrt) {          // smallest terms first, as in the kernel above
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][2], b0, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][1], b1, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][0], b2, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][1], b0, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][0], b1, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][0], b0, acc[mi][ni], 0, 0, 0);
+                }
+        }
+    };
+    gload(ra, 0);
+    for (int kc = 0; kc < nk; kc += 2) {
+        gload(rb, kc + 1 < nk ? kc + 1 : kc);
+        chunk(ra, kc);
+        if (kc + 1 < nk) {
+            gload(ra, kc + 2 < nk ? kc + 2 : kc + 1);
+            chunk(rb, kc + 1);
+        }
+    }
+    // ---- epilogue: bias / per-entry bias, store, statistics of the wave's 64 points (two passes), halves combined below
+    const float *bb = bbias ? bbias + (long)b * cstride : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int co = mi * 16 + 4 * g;
+        if (co >= Cout) continue;
+        f32x4 add = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias) add += ld4(bias + co);
+        if (bb) add += ld4(bb + co);
+        f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f}, q4 = s4;
+        f32x4 mx = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn = (f32x4){INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 v = acc[mi][ni] + add;
+            if (STATS) {
+                s4 += v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mx[r] = fmaxf(mx[r], v[r]);
+                    mn[r] = fminf(mn[r], v[r]);
+                }
+            }
+            if (valid && (!STATS || Y)) st4(Y + ((long)b * P + p0 + ni * 16 + j) * ldy + co, v);
+        }
+        if (STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s4[r] = row_allreduce_add<16>(s4[r]) * (1.0f / 64.0f);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 d = acc[mi][ni] + add - s4;
+                q4 += d * d;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                q4[r] = row_allreduce_add<16>(q4[r]);
+                mx[r] = row_allreduce_max<16>(mx[r]);
+                mn[r] = -row_allreduce_max<16>(-mn[r]);
+            }
+            if (j < 4) {
+                const float ss = j == 0 ? s4[0] : (j == 1 ? s4[1] : (j == 2 ? s4[2] : s4[3]));
+                const float qq = j == 0 ? q4[0] : (j == 1 ? q4[1] : (j == 2 ? q4[2] : q4[3]));
+                const float m1 = j == 0 ? mx[0] : (j == 1 ? mx[1] : (j == 2 ? mx[2] : mx[3]));
+                const float m0 = j == 0 ? mn[0] : (j == 1 ? mn[1] : (j == 2 ? mn[2] : mn[3]));
+                sp[tl][hf][co + j] = (f32x4){ss, qq, m1, m0};      // {mean, M2, max, min} of 64 points
+            }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        const int t2 = tid >> 7, c = tid & 127;
+        const int gtw = blockIdx.x * 2 + t2;
+        if (c < Cout && gtw < ntile) {
+            // the tile's two 64-point halves (Chan et al.): mean = (m0 + m1) / 2, M2 = M2_0 + M2_1 + (m1 - m0)^2 * 64 * 64 / 128
+            const f32x4 a0 = sp[t2][0][c], a1 = sp[t2][1][c];
+            const float dm = a1[0] - a0[0];
+            part[(long)gtw * cstride + c] = (f32x4){0.5f * (a0[0] + a1[0]), a0[1] + a1[1] + dm * dm * 32.0f, fmaxf(a0[2], a1[2]), fminf(a0[3], a1[3])};
+        }
+    }
+}
+
 // Folds the per-tile statistics of a STATS conv: one workgroup per (group, batch entry) sums the tiles' channel sums in f64
 // (a thread's elements and the tree over threads are fixed by (P, C, G) only: a batch entry's result does not depend on the
 // batch it sits in), then emits what caspr_gn_stats_f32 does: scale / shift per (b, c), optionally the max over points of the
@@ -698,6 +860,28 @@ extern "C" int caspr_conv1x1_gn_pooled_bf16x6_f32(const void *wpk, const float *
                            scale, shift, pmax, mean, rstd, ws, ws_bytes, stream);
 }
 
+// remainder (<= 64 channels) of a layer whose first channels ran on the 512-channel kernel: conv1x1_x6tail_kernel; `part` / `bbias` are
+// already offset to the remainder's first channel, cstride = the layer's full channel count
+static int conv_x6tail_launch(const void *wpk, const float *bias, const float *bbias, const float *X, int ldx, const float *in_scale,
+                              const float *in_shift, int in_relu, int in_relu_from, float *Y, int ldy, int B, int P, int Cin, int Cout, f32x4 *part,
+                              void *stream, int cstride)
+{
+    CASPR_REQUIRE(wpk && X && (Y || part) && Cout > 0 && Cout <= 64 && Cout % 4 == 0 && Cin % 32 == 0 && P % X6_TP == 0, "conv1x1_x6tail: bad arguments");
+    const int Pt = P / X6_TP;
+    const long ntile = (long)B * Pt;
+    const unsigned grid = (unsigned)((ntile + 1) / 2);
+#define X6T_GO(F, S)                                                                                                                          \
+    conv1x1_x6tail_kernel<F, S><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>((const unsigned char *)wpk, bias, bbias, X, ldx, in_scale, in_shift, \
+                                                                                  in_relu, in_relu_from, Y, ldy, P, Cin, Cout, Pt, (int)ntile, part, cstride)
+    if (in_scale && part) X6T_GO(true, true);
+    else if (in_scale) X6T_GO(true, false);
+    else if (part) X6T_GO(false, true);
+    else X6T_GO(false, false);
+#undef X6T_GO
+    CASPR_CHECK_LAUNCH("conv1x1_x6tail");
+    return CASPR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // The large layers: gemm_bf16x6w.hip's 128-point x 512-channel kernel on the first Cout - Cout % 512 channels, the kernel above
 // on the remainder (1600 = 3 x 512 + 64), both writing into one output / one statistics array; G > 0 adds the GroupNorm
@@ -735,7 +919,11 @@ static int conv_x6w_impl(const void *wpk_main, const void *wpk_tail, const float
                                    Cout, 0, (hipStream_t)stream);
     if (rc != CASPR_OK) return rc;
     CASPR_CHECK_LAUNCH("conv1x1_x6w");
-    if (Ctail) {
+    if (Ctail && Ctail <= 64) {
+        rc = conv_x6tail_launch(wpk_tail, bias ? bias + Cmain : nullptr, bbias ? bbias + Cmain : nullptr, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
+                                Y ? Y + Cmain : nullptr, ldy, B, P, Cin, Ctail, part ? part + Cmain : nullptr, stream, Cout);
+        if (rc != CASPR_OK) return rc;
+    } else if (Ctail) {
         rc = conv_x6_launch(wpk_tail, bias ? bias + Cmain : nullptr, bbias ? bbias + Cmain : nullptr, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
                             Y ? Y + Cmain : nullptr, ldy, B, P, Cin, Ctail, 0, part ? part + Cmain : nullptr, stream, Cout);
         if (rc != CASPR_OK) return rc;
@@ -801,7 +989,10 @@ extern "C" int caspr_conv1x1_x6w_part_f32(const void *wpk_main, const void *wpk_
         if (rc != CASPR_OK) return rc;
         CASPR_CHECK_LAUNCH("conv1x1_x6w_part");
     }
-    if (Ctail && with_tail)
+    if (Ctail && with_tail && Ctail <= 64)
+        rc = conv_x6tail_launch(wpk_tail, bias ? bias + Cmain : nullptr, bbias ? bbias + Cmain : nullptr, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
+                                Y ? Y + Cmain : nullptr, ldy, B, P, Cin, Ctail, part + Cmain, stream, Cout);
+    else if (Ctail && with_tail)
         rc = conv_x6_launch(wpk_tail, bias ? bias + Cmain : nullptr, bbias ? bbias + Cmain : nullptr, X, ldx, in_scale, in_shift, in_relu, in_relu_from,
                             Y ? Y + Cmain : nullptr, ldy, B, P, Cin, Ctail, 0, part + Cmain, stream, Cout);
     return rc;
