@@ -475,10 +475,10 @@ def cpu_baseline_and_parity(args, model, sd, ops, dev, out, x, x_all, sp_all, yb
                                    latent_steps=args.latent_steps)
     checks = []
     TOL = 1e-5            # north_star: "T-NOCS / CNF-sampled xyz within 1e-5 abs", asserted flat against the f64 evaluation
-    # configs[4] (i.i.d. uniform clouds: most neighbourhoods hold a single point, every level's GroupNorm is degenerate) does not
-    # reach 1e-5 in ANY f32 arithmetic -- the f32 oracle is 6e-4 (xyz) / 4e-3 (T-NOCS) from f64 there.  Only for that workload: a
-    # capped slack, never looser than the f32 reference's own error (factor 1), as tests/test_hip_parity.py::record_f64
-    CAP = {"x": 6e-5, "tnocs": 6e-4} if args.clouds == "random" else {}
+    # configs[4] (i.i.d. uniform clouds: most neighbourhoods hold a single point, every level's GroupNorm is degenerate): the f32
+    # oracle is 6e-4 (xyz) / 4e-3 (T-NOCS) from f64 there.  Only for that workload and only for T-NOCS: a capped slack, never looser
+    # than the f32 reference's own error (factor 1), as tests/test_hip_parity.py::record_f64
+    CAP = {"tnocs": 3e-4} if args.clouds == "random" else {}      # xyz is flat since the f64 reference column of round 4 (5.4e-6 at B = 64); T-NOCS 1.5e-4
 
     def cond(name, g, w32, w64):
         e_gpu, e_ref = float((g.double() - w64).abs().max()), float((w32.double() - w64).abs().max())

@@ -308,9 +308,41 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
 // exact coordinate differences (a b - a0 b0 = (a - a0) b + a0 (b - b0)), the statistics add mu back in f64, the normalised deviation is
 // d_s * rstd * gamma (no subtraction), ReLU acts on (n_0, n_0 + delta_s) and returns a deviation again, the final max is n_0 + max(0,
 // max_s delta_s).  An exact reformulation of pointnet2.py:677-698, not an approximation; exact duplicates stay exactly zero throughout.
+// THE REFERENCE COLUMN IS CARRIED IN f64 (round 4, second half).  What the centred form could not fix: a neighbourhood that is ALL copies
+// of one point has zero deviations, its output is the GroupNorm chain of the reference alone, and where two channels of a group differ by
+// ~1e-4 (variance 1e-7 < eps) the f32 ACCUMULATION error of mu = W a_0 + b (1e-7 of its partial sums) is multiplied by rstd = 314, twice
+// in a row: 4e-4 / 6e-4 on the two 16-sample scales, in this kernel as in the reference's own f32 arithmetic.  So mu is NOT taken from
+// column 0 of the MFMA any more: every lane multiplies ITS weight fragment (A layout: row r = lane & 15, k = 16 kc + 4 (lane >> 4) + q)
+// with the reference activations of its k in f64 on the vector pipe (v_fma_f64 runs at the f32 rate on CDNA: 1/16 .. 1/32 of the layer's
+// products), the four k-rows are summed by permlane swaps, a 2 KB LDS window per wave turns row r into the D layout's rows 4 g + e, and
+// GroupNorm normalises the reference in f64 (rstd: v_rsq_f32 + one Newton step) and hands a_0 to the next layer in f64 through the same
+// window.  No barrier: the window is the wave's own.
 // ---------------------------------------------------------------------------------------------
+// sum of x over the four 16-lane rows of the wave (the same lane j of each row), in every lane: the 16-lane rows of a half by
+// v_permlane16_swap, the two halves by v_permlane32_swap (gfx950), on both dwords of the double
+__device__ __forceinline__ double sa_rows_allreduce(double x)
+{
+    unsigned lo = (unsigned)__builtin_bit_cast(unsigned long long, x), hi = (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32);
+    auto both = [](unsigned l, unsigned h) { return __builtin_bit_cast(double, ((unsigned long long)h << 32) | l); };
+    {
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = both(rl[0], rh[0]) + both(rl[1], rh[1]);
+    }
+    lo = (unsigned)__builtin_bit_cast(unsigned long long, x);
+    hi = (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32);
+    {
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = both(rl[0], rh[0]) + both(rl[1], rh[1]);
+    }
+    return x;
+}
+
+// (The second launch bound = resident waves per SIMD hipcc allocates registers for -- it changes the register target even where no limit
+// binds.  Measured per variant with the f64 reference column in, ms per cfg-2 launch without / with a bound: <16,16,16,32> 0.52 / 0.45 (bound 3:
+// 158 registers instead of 184), <32,32,32,64> 1.24 + 0.64 / 0.97 + 0.70 for its two levels (bound 2: 167 instead of 204), <16,32,32,64>
+// 0.52 / 0.55 (240 / 197: no bound).  Hence one body and three entry points.)
 template <int NS, int C1, int C2, int C3>
-__global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
+__device__ __forceinline__ void sa_small_body(const SaArgs &a)
 {
     constexpr int CT = 4;                 // 64 columns per wave
     constexpr int TPC = NS / 16;          // column tiles per centre
@@ -321,6 +353,11 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     const int b = blockIdx.y;
     const int m0 = (blockIdx.x * 4 + wave) * NCEN;
     if (m0 >= a.M) return;                // wave-uniform; no barriers in this kernel
+    // the wave's own LDS window of the f64 reference column: a_0 of the layer input [centre][k], mu of the layer output [row tile][centre][row]
+    __shared__ double s_a0[4][4][64], s_mu[4][4][4][16];
+    double (&a0s)[4][64] = s_a0[wave];
+    double (&mus)[4][4][16] = s_mu[wave];
+    const int ar = lane & 15, ag = lane >> 4;          // A-layout coordinates of this lane: weight row ar of a row tile, k quad ag of a chunk
 #ifdef CASPR_DEBUG_HOOKS
 #define SA_STAMP(i) if (a.trace && blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0) a.trace[i] = __builtin_amdgcn_s_memtime();
 #else
@@ -422,13 +459,28 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
                     if (k + q >= a.C) bf[ct][q] = 0.f;
         }
     };
+    double P1[C1 / 16][NCEN];                        // f64 partial of mu = W a_0 (this lane's weight row ar, its k quad of every chunk)
+#pragma unroll
+    for (int rt = 0; rt < C1 / 16; ++rt)
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen) P1[rt][cen] = 0.0;
     auto mma1 = [&](const f32x4(&bf)[CT], const f32x4(&af)[C1 / 16]) {
+        // the reference quads of this lane's k (exact f32 inputs) ride in column 0 of each neighbourhood's first tile: row broadcast; the
+        // f64 products sit BETWEEN the MFMAs of the chunk (behind them, fenced, the widest variant lost a quarter: 0.44 -> 0.55 ms)
+        double rq[NCEN][4];
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rq[cen][q] = (double)dpp_mov<0x150>(bf[cen * TPC][q]);      // row_newbcast:0
 #pragma unroll
         for (int rt = 0; rt < C1 / 16; ++rt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = mfma16(af[rt][q], bf[ct][q], h1[rt][ct]);
+                const double wq = (double)af[rt][q];
+#pragma unroll
+                for (int cen = 0; cen < NCEN; ++cen) P1[rt][cen] = __builtin_fma(wq, rq[cen][q], P1[rt][cen]);
             }
     };
     auto load_a1 = [&](f32x4(&af)[C1 / 16], int kc) {
@@ -461,6 +513,15 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
             mma1(b0, w0);
         }
     }
+    // the four k-rows of the partials summed, then row ar of tile rt -> the window (every lane row writes the same value)
+    auto publish_mu = [&](auto &P, auto RTc) {
+        constexpr int RT = decltype(RTc)::value;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int cen = 0; cen < NCEN; ++cen) mus[rt][cen][ar] = sa_rows_allreduce(P[rt][cen]);
+    };
+    publish_mu(P1, std::integral_constant<int, C1 / 16>{});
 
     // bias + GroupNorm(16) per neighbourhood on a register-resident layer output in the centred form: on entry column 0 of the
     // neighbourhood's first tile holds W a_0 (lane j = 0), every other column W d_s.  FINAL = false: ReLU, and the output is written back
@@ -476,11 +537,13 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
             const f32x4 ga = ld4(L.gamma + rt * 16 + 4 * g), be = ld4(L.beta + rt * 16 + 4 * g);
 #pragma unroll
             for (int cen = 0; cen < NCEN; ++cen) {
-                // mu = W a_0 + bias of this neighbourhood (rows 4g..4g+3), to all 16 lanes of the row; sample 0's deviation is zero
-                f32x4 mu;
+                // mu = W a_0 + bias of this neighbourhood (rows 4g..4g+3) in f64 from the window; sample 0's deviation is zero (column 0 of
+                // the MFMA carried W a_0 in f32: not used)
+                __builtin_amdgcn_sched_barrier(0);      // one (row tile, centre) at a time: hoisted, the window reads of all of them cost 128 registers
+                double mu[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    mu[e] = dpp_mov<0x150>(h[rt][cen * TPC][e]) + bias4[e];        // row_newbcast:0
+                    mu[e] = mus[rt][cen][4 * g + e] + (double)bias4[e];
                     if (refl) h[rt][cen * TPC][e] = 0.f;
                 }
                 f32x4 mx = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -492,7 +555,7 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
 #pragma unroll
                         for (int r = 0; r < CPG; ++r) {
                             // one-channel groups: the constant cancels exactly, leave it out (sigma can be ~1e-2 of it)
-                            const double o = CPG > 1 ? (double)mu[sg * CPG + r] : 0.0;
+                            const double o = CPG > 1 ? mu[sg * CPG + r] : 0.0;
                             const double x = (double)h[rt][cen * TPC + t][sg * CPG + r] + o;
                             s1 += x;
                             s2 += x * x;
@@ -504,18 +567,25 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
                     double var = s2 * inv - mean * mean;      // f64: exact enough even when var << mean^2
                     var = var < 0.0 ? 0.0 : var;
                     const float rstd = __builtin_amdgcn_rsqf((float)var + 1e-5f);
+                    // the reference needs rstd beyond f32: one Newton step of r <- r (1.5 - 0.5 v r^2) in f64
+                    double r64 = (double)rstd;
+                    r64 = r64 * (1.5 - 0.5 * (var + 1e-5) * r64 * r64);
 #pragma unroll
                     for (int r = 0; r < CPG; ++r) {
                         const int e = sg * CPG + r;
                         const float sc = rstd * ga[e];
-                        const float n0 = (float)((CPG > 1 ? (double)mu[e] : 0.0) - mean) * sc + be[e];      // the reference, normalised
+                        const double n64 = ((CPG > 1 ? mu[e] : 0.0) - mean) * (r64 * (double)ga[e]) + (double)be[e];      // the reference, normalised
+                        const float n0 = (float)n64;
                         if (FINAL) {
                             float dm = 0.f;
 #pragma unroll
                             for (int t = 0; t < TPC; ++t) dm = fmaxf(dm, h[rt][cen * TPC + t][e] * sc);
                             mx[e] = n0 + row_allreduce_max<16>(dm);
                         } else {
-                            const float a0 = n0 > 0.f ? n0 : 0.f;
+                            const double a64 = n64 > 0.0 ? n64 : 0.0;
+                            const float a0 = (float)a64;
+                            a0s[cen][16 * rt + 4 * g + e] = a64;          // the next layer's reference input, in f64 (every lane of the row
+                                                                          // writes the same value: no branch for hipcc to sink 32 doubles into)
 #pragma unroll
                             for (int t = 0; t < TPC; ++t) {
                                 const float dl = h[rt][cen * TPC + t][e] * sc;       // normalised deviation: no subtraction
@@ -552,6 +622,30 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) hout[rt][ct] = mfma16(af[rt][kc][q], hin[kc][ct][q], hout[rt][ct]);
         }
+        // mu = W a_0 of the reference column in f64: this lane's weight row ar against the a_0 of its k quads (the window), the four
+        // k-rows summed, row ar published for norm()
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen) {          // one centre at a time: RO doubles live, not RO x NCEN
+            double P[RO];
+#pragma unroll
+            for (int rt = 0; rt < RO; ++rt) P[rt] = 0.0;
+#pragma unroll
+            for (int kc = 0; kc < RI; ++kc) {
+                double av[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[q] = a0s[cen][16 * kc + 4 * ag + q];
+#pragma unroll
+                for (int rt = 0; rt < RO; ++rt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float w = af[rt][kc][q];
+                        asm volatile("" : "+v"(w));          // convert HERE, per centre: hoisted, the RO x RI x 4 doubles cost 64-128 registers
+                        P[rt] = __builtin_fma((double)w, av[q], P[rt]);
+                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RO; ++rt) mus[rt][cen][ar] = sa_rows_allreduce(P[rt]);
+        }
     };
     using I1 = std::integral_constant<int, C1 / 16>;
     using I2 = std::integral_constant<int, C2 / 16>;
@@ -571,6 +665,13 @@ __global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a)
     SA_STAMP(7)
     SA_STAMP(8)
 }
+
+template <int NS, int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
+template <int NS, int C1, int C2, int C3>
+__global__ __launch_bounds__(256, 2) void sa_small_kernel_w2(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
+template <int NS, int C1, int C2, int C3>
+__global__ __launch_bounds__(256, 3) void sa_small_kernel_w3(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
 
 template <int NS, int NCOL>
 static int launch_sa(const SaArgs &a, int B, size_t shmem, hipStream_t st)
@@ -633,10 +734,10 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
         const int cpb = 4 * (64 / ns);   // centres per 256-thread block (4 waves x 64 columns)
         dim3 grid(ceil_div(M, cpb), B);
         bool done = true;
-        if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 16) sa_small_kernel<16, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
-        else if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 32) sa_small_kernel<32, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
+        if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 16) sa_small_kernel_w3<16, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
+        else if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 32) sa_small_kernel_w3<32, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
         else if (C1 == 32 && C2 == 32 && C3 == 64 && ns == 16) sa_small_kernel<16, 32, 32, 64><<<grid, dim3(256), 0, st>>>(a);
-        else if (C1 == 32 && C2 == 32 && C3 == 64 && ns == 32) sa_small_kernel<32, 32, 32, 64><<<grid, dim3(256), 0, st>>>(a);
+        else if (C1 == 32 && C2 == 32 && C3 == 64 && ns == 32) sa_small_kernel_w2<32, 32, 32, 64><<<grid, dim3(256), 0, st>>>(a);
         else done = false;
         if (done) {
             CASPR_CHECK_LAUNCH("sa_mlp_max(small)");
