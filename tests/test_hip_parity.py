@@ -403,9 +403,10 @@ def test_conv1x1_gn_fused(ops, dev, B, P_, Cin, Cout):
         assert res[0] is not None       # unsupported row count: conv1x1 + gn_stats
 
 
-@pytest.mark.parametrize("B,P_,Cin,Cout", [(1, 1280, 1600, 1600), (2, 256, 512, 512), (1, 384, 1536, 512), (1, 128, 256, 1088)])
+@pytest.mark.parametrize("B,P_,Cin,Cout", [(1, 1280, 1600, 1600), (2, 256, 512, 512), (1, 384, 1536, 512), (1, 128, 256, 1088), (3, 128, 512, 560)])
 def test_conv1x1_x6w_kernel(ops, dev, B, P_, Cin, Cout):
-    """The 128-point x 512-channel conv (csrc/gemm_bf16x6w.hip; a remainder of the channels on the 256-channel kernel): plain and
+    """The 128-point x 512-channel conv (csrc/gemm_bf16x6w.hip; a remainder of <= 64 channels on conv1x1_x6tail_kernel -- 64 of 1600 and of
+    1088, 48 of 560 with an odd number of 128-point tiles -- a larger one on the 256-channel kernel): plain and
     with the producer's GroupNorm + ReLU fused, bias + per-batch bias, against the f64 contraction at the conv kernels' common
     tolerance; the GroupNorm statistics of its epilogue against the other kernel's; and it IS the kernel that ran."""
     w = rnd(1, Cout, Cin, scale=1.0 / np.sqrt(Cin))
