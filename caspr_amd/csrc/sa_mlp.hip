@@ -637,11 +637,7 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
 #pragma unroll
                 for (int rt = 0; rt < RO; ++rt)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float w = af[rt][kc][q];
-                        asm volatile("" : "+v"(w));          // convert HERE, per centre: hoisted, the RO x RI x 4 doubles cost 64-128 registers
-                        P[rt] = __builtin_fma((double)w, av[q], P[rt]);
-                    }
+                    for (int q = 0; q < 4; ++q) P[rt] = __builtin_fma((double)af[rt][kc][q], av[q], P[rt]);
             }
 #pragma unroll
             for (int rt = 0; rt < RO; ++rt) mus[rt][cen][ar] = sa_rows_allreduce(P[rt]);
