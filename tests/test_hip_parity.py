@@ -1426,3 +1426,14 @@ def test_conv_layer_in_pieces_is_the_layer(ops, dev, B, P_, Cin, Cout, reserve):
     for i, nm in enumerate(("y", "scale", "shift", "pmax")):
         exact("conv_pieces_%s_%dx%d" % (nm, Cin, Cout), parts[i], whole[i])
     exact("conv_pieces_early_group0_%dx%d" % (Cin, Cout), seen["g0"], whole[3][:, :Cout // 16])
+
+
+def test_transposing_reduction_lane_map(dev):
+    """xw_treduce16 / xw_rows_add (csrc/x6w_common.h: v_permlane16_swap + bank-masked DPP; the statistics epilogue of the persistent conv)
+    against a host reduction, lane by lane: tools/micro/treduce_check (built by __graft_entry__.build())."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "micro", "treduce_check")
+    if not os.path.exists(exe):
+        pytest.skip("tools/micro/treduce_check is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "treduce_check: 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
