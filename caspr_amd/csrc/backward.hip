@@ -437,6 +437,139 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_skinny_kernel(const float *
 
 // number of row slabs: enough workgroups (tiles x slabs ~ 2048) to fill 256 CUs even when the weight is one tile,
 // at least 512 rows per slab, at most 4096 slabs
+// ---------------------------------------------------------------------------------------------
+// weight gradient of a NARROW conv over many rows (the training encoder's set-abstraction MLPs: 1.3 - 2.6 M grouped rows, 9 - 131
+// inputs, 16 - 128 outputs).  The call is a stream -- (Cin + Cout) floats per row against a few hundred MFMA cycles -- and the
+// 128 x 128 tile above spent it staging padding through LDS (0.4 - 0.8 ms per call, 1 - 2 TB/s of useful traffic).  Here no LDS stage
+// at all: the f32 MFMA 16x16x4 contracts over 4 ROWS, its A operand (lane (g, j): dY[row 4t + g][16 ta + j]) and B operand
+// (X[row 4t + g][16 tb + j]) are single floats of a 64-byte piece of a row, loaded straight from global memory, U steps (16 U rows per
+// workgroup: the four waves take consecutive 4-row steps) in flight before the first MFMA.  A wave owns NTA x NTB output tiles
+// (<= 16: 64 accumulators; wider shapes stay on the LDS tile).  The bias gradient rides along on the VALU (the lane's own
+// dY values).  Waves are combined in wave order through LDS, slabs in slab order by slab_reduce: deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int NTA, int NTB, int U>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_narrow_kernel(const float *__restrict__ dY, int lddy, const float *__restrict__ X,
+                                                                   int ldx, long R, int Cin, int Cout, long rows_per_slab,
+                                                                   float *__restrict__ part, float *__restrict__ bpart)
+{
+    __shared__ __attribute__((aligned(16))) float red[NTA * NTB * 256];
+    __shared__ float bred[4][NTA * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int slab = blockIdx.x, tb0 = blockIdx.y * NTB;
+    const long r_beg = (long)slab * rows_per_slab;
+    const long r_end = (r_beg + rows_per_slab) < R ? (r_beg + rows_per_slab) : R;
+
+    bool oka[NTA], okb[NTB];
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) oka[ta] = 16 * ta + j < Cout;
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) okb[tb] = 16 * (tb0 + tb) + j < Cin;
+    f32x4 acc[NTA][NTB];
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NTB; ++tb) acc[ta][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[NTA];
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta) bsum[ta] = 0.f;
+
+    for (long r0 = r_beg; r0 < r_end; r0 += 16 * U) {
+        float a[U][NTA], b[U][NTB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = r0 + 16 * u + 4 * wave + g;
+            const bool ok = row < r_end;
+            const float *pa = dY + row * lddy + j;
+            const float *pb = X + row * ldx + 16 * tb0 + j;
+#pragma unroll
+            for (int ta = 0; ta < NTA; ++ta) a[u][ta] = (ok && oka[ta]) ? pa[16 * ta] : 0.f;
+#pragma unroll
+            for (int tb = 0; tb < NTB; ++tb) b[u][tb] = (ok && okb[tb]) ? pb[16 * tb] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ta = 0; ta < NTA; ++ta) {
+                bsum[ta] += a[u][ta];
+#pragma unroll
+                for (int tb = 0; tb < NTB; ++tb) acc[ta][tb] = mfma16(a[u][ta], b[u][tb], acc[ta][tb]);
+            }
+    }
+
+    // bias gradient: the four row phases g of a wave, then the four waves, in a fixed order
+    if (bpart && blockIdx.y == 0) {
+#pragma unroll
+        for (int ta = 0; ta < NTA; ++ta) {
+            float t = bsum[ta];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (g == 0) bred[wave][16 * ta + j] = t;
+        }
+    }
+    // the four waves' tiles: waves 1..3 hand theirs to wave 0 one after the other
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int ta = 0; ta < NTA; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NTB; ++tb) st4(&red[((ta * NTB + tb) * 64 + lane) * 4], acc[ta][tb]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int ta = 0; ta < NTA; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NTB; ++tb) acc[ta][tb] = acc[ta][tb] + ld4(&red[((ta * NTB + tb) * 64 + lane) * 4]);
+        }
+    }
+    if (wave != 0) return;
+    if (bpart && blockIdx.y == 0) {
+#pragma unroll
+        for (int ta = 0; ta < NTA; ++ta)
+            if (g == 0 && oka[ta]) bpart[(long)slab * Cout + 16 * ta + j] = ((bred[0][16 * ta + j] + bred[1][16 * ta + j]) + bred[2][16 * ta + j]) + bred[3][16 * ta + j];
+    }
+    float *pp = part + (long)slab * Cout * Cin;
+#pragma unroll
+    for (int ta = 0; ta < NTA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NTB; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * ta + 4 * g + r, k = 16 * (tb0 + tb) + j;
+                if (co < Cout && k < Cin) pp[(long)co * Cin + k] = acc[ta][tb][r];
+            }
+}
+
+// -> true if the narrow kernel took the call
+static bool wgrad_narrow_launch(hipStream_t st, const float *dY, int lddy, const float *X, int ldx, long R, int Cin, int Cout, int S, float *part,
+                                float *bpart)
+{
+    const int tA = ceil_div(Cout, 16), tB = ceil_div(Cin, 16);
+    const int nta = tA > 4 ? 8 : tA > 2 ? 4 : tA;
+    int ntb = tB > 4 ? 8 : tB > 2 ? 4 : tB;
+    // measured (cfg-3 step): with more than 16 tiles per wave (280 registers, one workgroup per CU) or a second pass over dY the 128 x 128
+    // LDS tile is the faster one again (96 -> 128: 0.40 vs 0.22 ms, 131 -> 64: 0.37 vs 0.31, 64 -> 96: 0.20 vs 0.18)
+    if (nta * ntb > 16 || ntb < tB) return false;
+    const long rps = ((R + S - 1) / S + 127) / 128 * 128;   // a multiple of 16 U for both U
+    dim3 grid(S, ceil_div(tB, ntb));
+#define WN(A, B_, U_) conv1x1_wgrad_narrow_kernel<A, B_, U_><<<grid, dim3(256), 0, st>>>(dY, lddy, X, ldx, R, Cin, Cout, rps, part, bpart)
+#define WN_ROW(A)                                     \
+    if (nta == A) {                                   \
+        if (ntb == 1) WN(A, 1, 8);                    \
+        else if (ntb == 2) WN(A, 2, 8);               \
+        else if (ntb == 4) WN(A, (A * 4 <= 16 ? 4 : 1), 8); \
+        else WN(A, (A * 8 <= 16 ? 8 : 1), 4);         \
+        return true;                                  \
+    }
+    WN_ROW(1) WN_ROW(2) WN_ROW(4) WN_ROW(8)
+#undef WN_ROW
+#undef WN
+    return false;
+}
+
 static int pick_slabs(long R, int Cin, int Cout)
 {
     const long tiles = (long)ceil_div(Cout, WG_T) * ceil_div(Cin, WG_T);
@@ -489,6 +622,17 @@ static int wgrad_impl(bool bf16x6, const float *dY, int lddy, const float *X, in
         launch_slab_reduce(part, (long)Cout * Cin, S, accumulate, dW, st);
         CASPR_CHECK_LAUNCH("conv1x1_wgrad");
         return CASPR_OK;
+    }
+    // narrow convs over many rows (both matrix modes: the f32 products are at least as exact as the split's)
+    if (!in_scale && Cout <= 128 && Cin <= 160 && R >= 65536) {
+        if (S > 1024) S = 1024;
+        float *bp = dbias ? part + (long)S * ((long)Cout * Cin) : nullptr;
+        if (wgrad_narrow_launch(st, dY, lddy, X, ldx, R, Cin, Cout, S, part, bp)) {
+            launch_slab_reduce(part, (long)Cout * Cin, S, accumulate, dW, st);
+            if (dbias) launch_slab_reduce(bp, Cout, S, accumulate, dbias, st);
+            CASPR_CHECK_LAUNCH("conv1x1_wgrad(narrow)");
+            return CASPR_OK;
+        }
     }
     // bf16x6: the 256 x 256 tile where both widths fill it reasonably (padded area at most 20 % above the 128-tile's), else 128 x 128
     int kind = 0, T = WG_T;

@@ -500,6 +500,124 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv1x1, narrow inputs (Cin < 32 * ST_DB = 192) over many rows: the set-abstraction MLPs of the TRAINING encoder run as plain convs
+// over the grouped rows (1.3 - 2.6 M rows of 9 - 131 channels into 16 - 128, forward and data gradient; the inference path has them
+// in sa_mlp.hip).  Such a call is a pure stream -- 2.6 M x (32 + 32) floats in and out against 5 GFLOP -- and on the LDS-tiled kernel
+// (128 output channels x 64 points per workgroup, every K tile staged through LDS behind a barrier) it moved ~2 TB/s.  Here a wave
+// owns 32 rows and ALL the output channels of its 128-channel slab (NMI = 1 / 2 / 4 / 8 row tiles, chosen from Cout on the host: no
+// MFMAs on padding tiles), issues every activation load of its rows up front (at most 12 chunks x 2 column tiles of 16 bytes: the whole
+// K extent is in flight before the first MFMA) and reads the weight fragments from the pack as it goes (a few KB, L1 resident).
+// Products are accumulated in ascending k like the other f32 kernels.
+// ---------------------------------------------------------------------------------------------
+#define NW_MAXKC 12
+template <int NMI>
+__global__ __launch_bounds__(256, 2) void conv1x1_narrow_kernel(const float *__restrict__ wp, const float *__restrict__ bias,
+                                                                const float *__restrict__ bbias, const float *__restrict__ X,
+                                                                int ldx, float *__restrict__ Y, int ldy, int P, int Cin, int Cout,
+                                                                int act)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.y * 128 + wave * 32;
+    const int co0 = blockIdx.x * (NMI * 16);
+    const int KC = 2 * ((Cin + 31) / 32);
+    const int MT16 = (Cout + 15) / 16;
+    const int Cin4 = (Cin + 3) & ~3;
+    const int mt0 = co0 >> 4;
+    if (p0 >= P) return;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, MT16 * KC * 1024, 0x00020000);
+    const int wvoff = lane * 16;
+    int wsoff[NMI];
+#pragma unroll
+    for (int mi = 0; mi < NMI; ++mi) wsoff[mi] = ((mt0 + mi) < MT16 ? mt0 + mi : 0) * KC * 1024;
+    const float *xrow[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int p = p0 + ni * 16 + j;
+        xrow[ni] = X + ((long)b * P + (p < P ? p : P - 1)) * ldx + 4 * g;
+    }
+
+    f32x4 bfr[NW_MAXKC][2];
+#pragma unroll
+    for (int kc = 0; kc < NW_MAXKC; ++kc) {
+        if (kc < KC) {
+            const int k = 16 * kc + 4 * g;
+            const bool in = k < Cin4;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bfr[kc][ni] = in ? ld4(xrow[ni] + 16 * kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 acc[NMI][2];
+#pragma unroll
+    for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int kc = 0; kc < NW_MAXKC; ++kc) {
+        if (kc < KC) {
+            f32x4 af[NMI];
+#pragma unroll
+            for (int mi = 0; mi < NMI; ++mi)
+                af[mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff[mi] + kc * 1024, 0));
+            const int k = 16 * kc + 4 * g;
+            if (k + 4 > Cin) {   // the padding columns of the last float4 hold whatever the producer left there
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (k + q >= Cin) bfr[kc][ni][q] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < NMI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16(af[mi][q], bfr[kc][ni][q], acc[mi][ni]);
+        }
+    }
+
+    const float *bb = bbias ? bbias + (long)b * Cout : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < NMI; ++mi) {
+        if (mt0 + mi >= MT16) continue;
+        const int co = co0 + mi * 16 + 4 * g;
+        float add[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+            if (co + r < Cout) {
+                if (bias) v += bias[co + r];
+                if (bb) v += bb[co + r];
+            }
+            add[r] = v;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int p = p0 + ni * 16 + j;
+            if (p >= P) continue;
+            f32x4 v = acc[mi][ni];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] += add[r];
+                if ((act & 0xff) == 1) v[r] = sigmoid_f(v[r]);
+            }
+            float *dst = Y + ((long)b * P + p) * ldy + co;
+            if (co + 3 < Cout) {
+                st4(dst, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < Cout) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // conv1x1 over at most 16 rows per batch entry (the latent ODE's layers in training: 8 sequences per GPU, 576 products per step of
 // 64-512 channels; the per-sequence bias of the head conv): one workgroup per (16 output channels, batch entry) -- the choice of
 // this kernel depends on P only, never on B, so a batch entry's result does not depend on the batch around it --, the K chunks dealt round-robin to its four waves (A fragment straight from
@@ -585,6 +703,20 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     // for short rows-per-batch (coarse levels) and narrow inputs (set-abstraction MLPs).  CASPR_GEMM_KERNEL: 1 / 4 force
     // the LDS kernel with 128 / 64-point tiles, 7 forces streaming.
     // row-invariant calls always take the LDS kernel (the kernel choice itself must not depend on P)
+    // narrow inputs over many rows (the training encoder's set-abstraction convs): the whole K extent of a wave's rows in flight at once
+    if ((force == 0 || force == 8) && P >= 128 && Cin < 32 * ST_DB && !in_scale && !(act & CASPR_CONV_ROW_INVARIANT)) {
+        const int mt16 = ceil_div(Cout, 16);
+        const int nmi = mt16 >= 5 ? 8 : mt16 >= 3 ? 4 : mt16;
+        dim3 grid(ceil_div(mt16, nmi), ceil_div(P, 128), B);
+#define NW_LAUNCH(N) conv1x1_narrow_kernel<N><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, Y, ldy, P, Cin, Cout, act)
+        if (nmi == 8) NW_LAUNCH(8);
+        else if (nmi == 4) NW_LAUNCH(4);
+        else if (nmi == 2) NW_LAUNCH(2);
+        else NW_LAUNCH(1);
+#undef NW_LAUNCH
+        CASPR_CHECK_LAUNCH("conv1x1(narrow)");
+        return CASPR_OK;
+    }
     if (force == 7 || (force == 0 && P >= 128 && Cin >= 32 * ST_DB && !(act & CASPR_CONV_ROW_INVARIANT))) {
         dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
 #define ST_LAUNCH(F, N) conv1x1_stream_kernel<F, N><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, \

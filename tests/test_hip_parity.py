@@ -230,7 +230,10 @@ def test_chamfer(ops, dev):
                                           (2, 200, 518, 512), (1, 256, 576, 1600), (1, 384, 1600, 1600), (2, 100, 1600, 4),
                                           (1, 20, 1600, 3078), (1, 1, 1024, 1600),
                                           # streaming kernel (P >= 128, Cin >= 192): narrow outputs, ragged rows and K, one wave's worth of rows + 1
-                                          (2, 300, 1600, 4), (1, 129, 200, 130), (2, 260, 1539, 3), (3, 128, 192, 16)])
+                                          (2, 300, 1600, 4), (1, 129, 200, 130), (2, 260, 1539, 3), (3, 128, 192, 16),
+                                          # narrow kernel (P >= 128, Cin < 192): every row-tile count, ragged K / rows / outputs, two slabs
+                                          (2, 1000, 9, 32), (1, 300, 131, 64), (2, 257, 99, 96), (1, 129, 191, 130), (2, 200, 16, 16),
+                                          (1, 640, 32, 48), (2, 128, 3, 5)])
 def test_conv1x1(ops, dev, B, P_, Cin, Cout):
     ldx = (Cin + 3) // 4 * 4
     x = torch.zeros(B, P_, ldx)
@@ -262,6 +265,21 @@ def test_conv1x1_fused_input_and_epilogues(ops, dev):
     # column-sliced packing == packing the slice
     pw2 = ops.PackedWeight(torch.cat([torch.zeros(Cout, 1), w], 1).to(dev), col0=1)
     assert torch.equal(pw2.data, pw.data)
+
+
+def test_conv1x1_narrow_epilogues_and_batch_invariance(ops, dev):
+    """The narrow kernel (the training encoder's set-abstraction convs): per-entry bias + sigmoid epilogue, a strided output, and an
+    entry's rows giving the same bits whatever the batch around them."""
+    B, P_, Cin, Cout = 3, 777, 99, 80
+    x, w, b, bb = rnd(1, B, P_, 100), rnd(2, Cout, Cin, scale=0.1), rnd(3, Cout, scale=0.1), rnd(4, B, Cout)
+    want = torch.sigmoid(x[:, :, :Cin].double() @ w.double().t() + b.double() + bb.double().unsqueeze(1))
+    pw = ops.PackedWeight(w.to(dev))
+    buf = torch.zeros(B, P_, 128, device=dev)
+    got = ops.conv1x1(pw, b.to(dev), x.to(dev), bbias=bb.to(dev), act=1, out=buf[:, :, 16:96])
+    record("conv1x1_narrow_epilogues", got, want, 2e-6)
+    assert float(buf[:, :, :16].abs().max()) == 0.0 and float(buf[:, :, 96:].abs().max()) == 0.0
+    one = ops.conv1x1(pw, b.to(dev), x[1:2].to(dev), bbias=bb[1:2].to(dev), act=1)
+    exact("conv1x1_narrow_batch_invariance", one[:, :, :Cout], got[1:2])
 
 
 def test_conv1x1_repeatable_under_load(ops, dev):

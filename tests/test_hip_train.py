@@ -124,6 +124,33 @@ def test_conv1x1_wgrad_direct(matmul_mode, B, P, Cin, Cout):
     rel("wgrad_plain[%d,%d]" % (Cin, Cout), dW2, torch.einsum("bpo,bpi->oi", dy.double(), x.double()), 3e-6)
 
 
+@pytest.mark.parametrize("B,P,Cin,Cout", [(2, 40000, 9, 32), (1, 70001, 16, 16), (3, 30000, 32, 64), (2, 33000, 99, 32), (1, 66000, 131, 64),
+                                          (2, 35000, 96, 128), (1, 65536, 64, 96), (1, 65600, 3, 5), (2, 33000, 160, 17), (2, 40000, 64, 32), (1, 70000, 16, 128),
+                                          (1, 70000, 32, 100), (2, 36000, 64, 64)])
+def test_conv1x1_wgrad_narrow(matmul_mode, B, P, Cin, Cout):
+    """The weight gradient of a narrow conv over many rows (the training encoder's set-abstraction MLPs: conv1x1_wgrad_narrow_kernel, no
+    LDS stage, operands straight from global memory): against float64 with the bias gradient, garbage in the pad columns of both
+    operands, accumulate, bit-reproducibility -- every tile-count instantiation the dispatch can pick."""
+    from caspr_amd import train_ops as T
+    dev = "cuda:0"
+    ldx, ldy = (Cin + 3) // 4 * 4 + 4, (Cout + 3) // 4 * 4
+    xw, dyw = rnd(1, B, P, ldx), rnd(2, B, P, ldy)
+    x, dy = xw[:, :, :Cin], dyw[:, :, :Cout]
+    want = torch.einsum("bpo,bpi->oi", dy.double(), x.double())
+    xd, dyd = xw.to(dev), dyw.to(dev)
+    dW, db = torch.empty(Cout, Cin, device=dev), torch.empty(Cout, device=dev)
+    T.conv1x1_wgrad(dyd, xd, Cin, Cout, dW, db)
+    rel("wgrad_narrow[%d,%d]" % (Cin, Cout), dW, want, 3e-6)
+    rel("wgrad_narrow_bias[%d,%d]" % (Cin, Cout), db, dy.double().sum(dim=(0, 1)), 3e-6)
+    dW2, db2 = dW.clone(), db.clone()
+    T.conv1x1_wgrad(dyd, xd, Cin, Cout, dW2, db2, accumulate=True)
+    rel("wgrad_narrow_accumulate[%d,%d]" % (Cin, Cout), dW2, 2 * want, 3e-6)
+    rel("wgrad_narrow_bias_accumulate[%d,%d]" % (Cin, Cout), db2, 2 * dy.double().sum(dim=(0, 1)), 3e-6)
+    dW3 = torch.empty_like(dW)
+    T.conv1x1_wgrad(dyd, xd, Cin, Cout, dW3, None)
+    assert torch.equal(dW, dW3)
+
+
 @pytest.mark.parametrize("B,n,M,ns,C,dims", [(2, 256, 64, 16, 6, (16, 16, 32)), (2, 128, 32, 32, 96, (64, 96, 128)), (1, 64, 16, 32, 512, (256, 256, 512))])
 def test_set_abstraction_scale_backward(B, n, M, ns, C, dims):
     """group -> 3 x (conv -> per-neighbourhood GroupNorm(16) [-> ReLU]) -> max over samples  (pointnet2.py:391-409,649-703):
