@@ -234,6 +234,22 @@ __device__ __forceinline__ void team_barrier(const LatTeam &t, unsigned &gen, bo
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave: later loads see the other workgroups' stores
 }
 
+// Training tier (MODE 1 / 2; caspr_latent_rk4_team_tape_f32 / _adjoint_f32).  The discrete RK4 map is differentiated by hand
+// (caspr_amd/train/flow_grad.py: LatentSolve): its forward pass needs, per evaluation e, the layer inputs x_e, h1_e, h2_e, h3_e (the "tape":
+// rows [e][sequence][channel]), its reverse sweep is the SAME chain of four products with the transposed weights in reverse order --
+// W3^T (64 -> 512) takes the place of layer 0, W2^T, W1^T of the 512 x 512 layers, W0^T (512 -> 64) of the output layer -- with the tanh
+// replaced by a multiplication with 1 - h^2 from the tape, the RK4 combinations by their adjoints, and every product's input kept as the
+// layer's delta (rows as the tape: the weight gradients are then ONE product per layer over all evaluations, conv1x1_wgrad on the host).
+// One launch each way instead of ~650 (8-row products, tanh, addcmul: 72 evaluations at cfg-3).
+struct LatTape {
+    float *x, *h1, *h2, *h3;          // MODE 1: written; MODE 2: h1..h3 read.  x rows are xw floats wide, the others 512
+    float *d0, *d1, *d2, *d3;         // MODE 2: deltas of the four layers (d3 rows xw wide)
+    const float *gout;                // MODE 2: (B, Tu, D) gradient of the solve's output
+    float *gz;                        // MODE 2: (B, D) gradient of z0
+    int xw;
+};
+
+template <int MODE>
 __global__ __launch_bounds__(256) void latent_rk4_team_kernel(const float *__restrict__ z0, int ldz,
                                                               const float *__restrict__ times, int B, int Tu, int D,
                                                               int steps, const float *__restrict__ w0p,
@@ -241,12 +257,12 @@ __global__ __launch_bounds__(256) void latent_rk4_team_kernel(const float *__res
                                                               const float *__restrict__ b1, const float *__restrict__ w2p,
                                                               const float *__restrict__ b2, const float *__restrict__ w3p,
                                                               const float *__restrict__ b3, float *__restrict__ out,
-                                                              char *ws, long ws_stride)
+                                                              char *ws, long ws_stride, LatTape tp)
 {
     constexpr int KCH = 32;                       // 512 / 16
     __shared__ __attribute__((aligned(16))) float sW0[4 * 256], sW1[KCH * 256], sW2[KCH * 256], sW3[4 * 256];
     __shared__ __attribute__((aligned(16))) float s_in[16 * LAT_NCOL * 4], s_h[128 * LAT_NCOL * 4], s_part[4][256];
-    __shared__ float s_z[64 * LAT_NCOL], s_acc[64 * LAT_NCOL], s_k[64 * LAT_NCOL];
+    __shared__ float s_z[64 * LAT_NCOL], s_acc[64 * LAT_NCOL], s_k[64 * LAT_NCOL], s_acc2[MODE == 2 ? 64 * LAT_NCOL : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int w = blockIdx.x, grp = blockIdx.y;
@@ -270,9 +286,11 @@ __global__ __launch_bounds__(256) void latent_rk4_team_kernel(const float *__res
     }
     for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
         const int d = i / LAT_NCOL, c = i % LAT_NCOL;
-        const float v = (d < D && b0i + c < B) ? z0[(long)(b0i + c) * ldz + d] : 0.f;
+        float v;
+        if (MODE == 2) v = (d < D && b0i + c < B) ? tp.gout[((long)(b0i + c) * Tu + (Tu - 1)) * D + d] : 0.f;     // adjoint state: dL/dz(t_last)
+        else v = (d < D && b0i + c < B) ? z0[(long)(b0i + c) * ldz + d] : 0.f;
         s_z[i] = v;
-        if (w == 0 && d < D && b0i + c < B) out[((long)(b0i + c) * Tu) * D + d] = v;
+        if (MODE != 2 && w == 0 && d < D && b0i + c < B) out[((long)(b0i + c) * Tu) * D + d] = v;
     }
     for (int i = tid; i < 16 * LAT_NCOL * 4; i += 256) s_in[i] = 0.f;
     __syncthreads();
@@ -293,35 +311,56 @@ __global__ __launch_bounds__(256) void latent_rk4_team_kernel(const float *__res
         __syncthreads();
         return r;
     };
-    auto tanh_bias = [&](f32x4 a, const float *bias) {
-        const f32x4 bb = ld4(bias + w * 16 + 4 * g);
+    // the hidden layers' epilogue on this workgroup's 16 units x 16 sequences (lane: units 16 w + 4 g .., sequence column j).
+    // MODE 0 / 1: tanh(a + bias) [-> tape];  MODE 2: a (1 - h^2) with h from the tape, kept as the layer's delta
+    const bool col_ok = b0i + j < B;
+    auto act = [&](f32x4 a, const float *bias, float *tape_h, float *delta, int e) {
         f32x4 v;
+        const long off = ((long)e * B + b0i + j) * 512 + w * 16 + 4 * g;
+        if (MODE == 2) {
+            const f32x4 t = col_ok ? ld4(tape_h + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = tanhf(a[q] + bb[q]);
+            for (int q = 0; q < 4; ++q) v[q] = a[q] * (1.0f - t[q] * t[q]);
+            if (wave == 0 && col_ok) st4(delta + off, v);
+        } else {
+            const f32x4 bb = ld4(bias + w * 16 + 4 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = tanhf(a[q] + bb[q]);
+            if (MODE == 1 && wave == 0 && col_ok) st4(tape_h + off, v);
+        }
         return v;
     };
     auto fetch_h = [&](const float *src) {   // full 512 x 16 activation of the team -> LDS
         for (int i = tid; i < 128 * LAT_NCOL; i += 256) st4(&s_h[i * 4], ld4(src + i * 4));
         __syncthreads();
     };
-    auto write_in = [&](float a, const float *kv) {
+    // s_in = ca * A + cb * Bv as a B-tile (row d, column c); Bv may be null
+    auto write_in = [&](float ca, const float *A, float cb, const float *Bv) {
         for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
             const int d = i / LAT_NCOL, c = i % LAT_NCOL;
-            if (d < D) s_in[btile_off(d >> 2, c, LAT_NCOL) + (d & 3)] = kv ? s_z[i] + a * kv[i] : s_z[i];
+            // the forward forms stay z + a k / z exactly as written since round 1 (ca == 1 there)
+            if (d < D) s_in[btile_off(d >> 2, c, LAT_NCOL) + (d & 3)] = Bv ? (MODE == 2 ? ca * A[i] + cb * Bv[i] : A[i] + cb * Bv[i]) : (MODE == 2 ? ca * A[i] : A[i]);
         }
         __syncthreads();
     };
     float *hb0 = team.hbuf, *hb1 = team.hbuf + 128 * LAT_NCOL * 4;
-    auto dyn = [&]() {   // s_in -> s_k   (latent_ode_model.py:139-147)
-        f32x4 v = tanh_bias(tile(sW0, KC0, s_in), b0);
+    auto dyn = [&](int e) {   // s_in -> s_k   (latent_ode_model.py:139-147; MODE 2: its transpose)
+        if (MODE != 0 && w == 0) {   // the evaluation's input: x_e of the tape, or the output layer's delta
+            float *dst = MODE == 1 ? tp.x : tp.d3;
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
+                const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+                if (d < D && b0i + c < B) dst[((long)e * B + b0i + c) * tp.xw + d] = s_in[btile_off(d >> 2, c, LAT_NCOL) + (d & 3)];
+            }
+        }
+        f32x4 v = act(tile(sW0, KC0, s_in), b0, MODE == 2 ? tp.h3 : tp.h1, tp.d2, e);
         if (wave == 0) st4(hb0 + btile_off(w * 4 + g, j, LAT_NCOL), v);
         team_barrier(team, gen, dead);
         fetch_h(hb0);
-        v = tanh_bias(tile(sW1, KCH, s_h), b1);
+        v = act(tile(sW1, KCH, s_h), b1, tp.h2, tp.d1, e);
         if (wave == 0) st4(hb1 + btile_off(w * 4 + g, j, LAT_NCOL), v);
         team_barrier(team, gen, dead);
         fetch_h(hb1);
-        v = tanh_bias(tile(sW2, KCH, s_h), b2);
+        v = act(tile(sW2, KCH, s_h), b2, MODE == 2 ? tp.h1 : tp.h3, tp.d0, e);
         if (wave == 0) {   // own 16 hidden units x 16 columns = the B fragment of K-slice w of the output layer
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -340,37 +379,79 @@ __global__ __launch_bounds__(256) void latent_rk4_team_kernel(const float *__res
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int d = mt * 16 + 4 * g + q;
-                if (d < D) s_k[d * LAT_NCOL + j] = sum[q] + b3[d];
+                if (d < D) s_k[d * LAT_NCOL + j] = MODE == 2 ? sum[q] : sum[q] + b3[d];
             }
         }
         __syncthreads();
     };
 
     const float t_first = times[0];
+    if (MODE == 2) {
+        // reverse sweep: the evaluations in the opposite order, e counts down from the forward pass's total
+        int e = 0;
+        for (int ti = 1; ti < Tu; ++ti) e += (times[ti] - t_first != times[ti - 1] - t_first) ? 4 * steps : 0;     // the forward pass's own test
+        for (int ti = Tu - 1; ti >= 1; --ti) {
+            const float r0 = times[ti - 1] - t_first, r1 = times[ti] - t_first;
+            const double h = ((double)r1 - (double)r0) / (double)steps;
+            const float hh = (float)h, h2 = (float)(0.5 * h), h3 = (float)(h / 3.0), h6 = (float)(h / 6.0);
+            for (int s = 0; s < (r1 != r0 ? steps : 0); ++s) {
+                e -= 4;
+                write_in(h6, s_z, 0.f, nullptr);          // dL/dk4
+                dyn(e + 3);
+                for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_k[i];
+                __syncthreads();
+                write_in(h3, s_z, hh, s_k);               // dL/dk3 = h/3 gz + h g4
+                dyn(e + 2);
+                for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_acc[i] + s_k[i];
+                __syncthreads();
+                write_in(h3, s_z, h2, s_k);               // dL/dk2 = h/3 gz + h/2 g3
+                dyn(e + 1);
+                for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc2[i] = s_k[i];
+                __syncthreads();
+                write_in(h6, s_z, h2, s_k);               // dL/dk1 = h/6 gz + h/2 g2
+                dyn(e);
+                for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_z[i] = (s_z[i] + s_acc[i]) + (s_acc2[i] + s_k[i]);
+                __syncthreads();
+            }
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
+                const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+                if (d < D && b0i + c < B) s_z[i] += tp.gout[((long)(b0i + c) * Tu + (ti - 1)) * D + d];
+            }
+            __syncthreads();
+        }
+        if (w == 0)
+            for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
+                const int d = i / LAT_NCOL, c = i % LAT_NCOL;
+                if (d < D && b0i + c < B) tp.gz[(long)(b0i + c) * D + d] = dead ? __builtin_nanf("") : s_z[i];
+            }
+        return;
+    }
+    int e = 0;
     for (int ti = 1; ti < Tu; ++ti) {
         const float r0 = times[ti - 1] - t_first, r1 = times[ti] - t_first;
         const double h = ((double)r1 - (double)r0) / (double)steps;
         const float hh = (float)h, h2 = (float)(0.5 * h), h6 = (float)(h / 6.0);
         for (int s = 0; s < (r1 != r0 ? steps : 0); ++s) {
-            write_in(0.f, nullptr);
-            dyn();
+            write_in(1.f, s_z, 0.f, nullptr);
+            dyn(e);
             for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_k[i];
             __syncthreads();
-            write_in(h2, s_k);
-            dyn();
+            write_in(1.f, s_z, h2, s_k);
+            dyn(e + 1);
             for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_acc[i] + 2.0f * s_k[i];
             __syncthreads();
-            write_in(h2, s_k);
-            dyn();
+            write_in(1.f, s_z, h2, s_k);
+            dyn(e + 2);
             for (int i = tid; i < 64 * LAT_NCOL; i += 256) s_acc[i] = s_acc[i] + 2.0f * s_k[i];
             __syncthreads();
-            write_in(hh, s_k);
-            dyn();
+            write_in(1.f, s_z, hh, s_k);
+            dyn(e + 3);
             for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
                 const float a = s_acc[i] + s_k[i];
                 s_z[i] = s_z[i] + h6 * a;
             }
             __syncthreads();
+            e += 4;
         }
         if (w == 0)
             for (int i = tid; i < 64 * LAT_NCOL; i += 256) {
@@ -405,9 +486,62 @@ extern "C" int caspr_latent_rk4_team_f32(const float *z0, int ldz, const float *
     // the barrier words of every group, zeroed by a KERNEL: a hipMemsetAsync here is a runtime blit, and behind a long kernel of
     // the same stream it started ~215 us after that kernel's end (step timelines of round 3) -- on the critical path of the step
     latent_team_zero_kernel<<<dim3(groups), dim3(64), 0, st>>>((char *)ws, (long)LM_WS_STRIDE);
-    latent_rk4_team_kernel<<<dim3(LM_TEAM, groups), dim3(256), 0, st>>>(z0, ldz, times, B, Tu, D, steps, w0p, b0, w1p, b1, w2p, b2, w3p, b3,
-                                                                        out, (char *)ws, (long)LM_WS_STRIDE);
+    latent_rk4_team_kernel<0><<<dim3(LM_TEAM, groups), dim3(256), 0, st>>>(z0, ldz, times, B, Tu, D, steps, w0p, b0, w1p, b1, w2p, b2, w3p, b3,
+                                                                           out, (char *)ws, (long)LM_WS_STRIDE, LatTape{});
     CASPR_CHECK_LAUNCH("latent_rk4_team");
+    return CASPR_OK;
+}
+
+// Training tier: the same solve leaving its tape -- x (E, B, xw), h1 / h2 / h3 (E, B, 512), E = 4 * steps * (Tu - 1) evaluations in the order
+// they are made (rows of evaluations a zero-length interval skips are not written: the caller zero-fills) ...
+extern "C" int caspr_latent_rk4_team_tape_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H, int steps,
+                                              const float *w0p, const float *b0, const float *w1p, const float *b1, const float *w2p,
+                                              const float *b2, const float *w3p, const float *b3, float *out, float *tape_x, int xw,
+                                              float *tape_h1, float *tape_h2, float *tape_h3, void *ws, long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(z0 && times && out && w0p && w1p && w2p && w3p && b0 && b1 && b2 && b3 && ws && tape_x && tape_h1 && tape_h2 && tape_h3,
+                  "latent_rk4_team_tape: null pointer");
+    CASPR_REQUIRE(B > 0 && Tu > 0 && steps > 0 && D > 0 && D <= 64 && H == 512 && ldz >= D && xw >= D && xw % 4 == 0,
+                  "latent_rk4_team_tape: needs D<=64, H==512, xw >= D a multiple of 4 (got D=%d H=%d xw=%d)", D, H, xw);
+    CASPR_REQUIRE(ws_bytes >= caspr_latent_team_ws_bytes(B) && ((uintptr_t)ws % 256) == 0, "latent_rk4_team_tape: workspace too small or misaligned");
+    CASPR_REQUIRE(((uintptr_t)tape_h1 % 16) == 0 && ((uintptr_t)tape_h2 % 16) == 0 && ((uintptr_t)tape_h3 % 16) == 0, "latent_rk4_team_tape: tape must be 16-byte aligned");
+    const int groups = ceil_div(B, LAT_NCOL);
+    CASPR_REQUIRE(groups * LM_TEAM <= 128, "latent_rk4_team_tape: %d sequences need %d co-resident workgroups (> 128)", B, groups * LM_TEAM);
+    hipStream_t st = (hipStream_t)stream;
+    LatTape tp{};
+    tp.x = tape_x; tp.h1 = tape_h1; tp.h2 = tape_h2; tp.h3 = tape_h3; tp.xw = xw;
+    latent_team_zero_kernel<<<dim3(groups), dim3(64), 0, st>>>((char *)ws, (long)LM_WS_STRIDE);
+    latent_rk4_team_kernel<1><<<dim3(LM_TEAM, groups), dim3(256), 0, st>>>(z0, ldz, times, B, Tu, D, steps, w0p, b0, w1p, b1, w2p, b2, w3p, b3,
+                                                                           out, (char *)ws, (long)LM_WS_STRIDE, tp);
+    CASPR_CHECK_LAUNCH("latent_rk4_team_tape");
+    return CASPR_OK;
+}
+
+// ... and the reverse sweep of that discrete map: gout (B, Tu, D) -> gz (B, D) = dL/dz0 and the four layers' deltas (rows as the tape:
+// d0 / d1 / d2 (E, B, 512), d3 (E, B, xw)), with w3tp .. w0tp the packs of the TRANSPOSED weights (W3^T: 512 x D first, W0^T: D x 512 last).
+// dW_l = delta_l^T tape_l (conv1x1_wgrad over the E B rows), db_l = column sums of delta_l.  Deterministic (no atomics on data).
+extern "C" int caspr_latent_rk4_team_adjoint_f32(const float *gout, const float *times, int B, int Tu, int D, int H, int steps,
+                                                 const float *w3tp, const float *w2tp, const float *w1tp, const float *w0tp,
+                                                 const float *tape_h1, const float *tape_h2, const float *tape_h3, float *d0, float *d1,
+                                                 float *d2, float *d3, int xw, float *gz, void *ws, long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(gout && times && gz && w0tp && w1tp && w2tp && w3tp && ws && tape_h1 && tape_h2 && tape_h3 && d0 && d1 && d2 && d3,
+                  "latent_rk4_team_adjoint: null pointer");
+    CASPR_REQUIRE(B > 0 && Tu > 0 && steps > 0 && D > 0 && D <= 64 && H == 512 && xw >= D && xw % 4 == 0,
+                  "latent_rk4_team_adjoint: needs D<=64, H==512, xw >= D a multiple of 4 (got D=%d H=%d xw=%d)", D, H, xw);
+    CASPR_REQUIRE(ws_bytes >= caspr_latent_team_ws_bytes(B) && ((uintptr_t)ws % 256) == 0, "latent_rk4_team_adjoint: workspace too small or misaligned");
+    CASPR_REQUIRE(((uintptr_t)tape_h1 % 16) == 0 && ((uintptr_t)tape_h2 % 16) == 0 && ((uintptr_t)tape_h3 % 16) == 0 && ((uintptr_t)d0 % 16) == 0 &&
+                      ((uintptr_t)d1 % 16) == 0 && ((uintptr_t)d2 % 16) == 0, "latent_rk4_team_adjoint: tape / deltas must be 16-byte aligned");
+    const int groups = ceil_div(B, LAT_NCOL);
+    CASPR_REQUIRE(groups * LM_TEAM <= 128, "latent_rk4_team_adjoint: %d sequences need %d co-resident workgroups (> 128)", B, groups * LM_TEAM);
+    hipStream_t st = (hipStream_t)stream;
+    LatTape tp{};
+    tp.h1 = const_cast<float *>(tape_h1); tp.h2 = const_cast<float *>(tape_h2); tp.h3 = const_cast<float *>(tape_h3);
+    tp.d0 = d0; tp.d1 = d1; tp.d2 = d2; tp.d3 = d3; tp.gout = gout; tp.gz = gz; tp.xw = xw;
+    latent_team_zero_kernel<<<dim3(groups), dim3(64), 0, st>>>((char *)ws, (long)LM_WS_STRIDE);
+    latent_rk4_team_kernel<2><<<dim3(LM_TEAM, groups), dim3(256), 0, st>>>(nullptr, 0, times, B, Tu, D, steps, w3tp, nullptr, w2tp, nullptr, w1tp, nullptr,
+                                                                           w0tp, nullptr, nullptr, (char *)ws, (long)LM_WS_STRIDE, tp);
+    CASPR_CHECK_LAUNCH("latent_rk4_team_adjoint");
     return CASPR_OK;
 }
 

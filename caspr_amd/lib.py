@@ -59,6 +59,10 @@ SIGNATURES = {
     "caspr_latent_team_ws_bytes": (c_long, [c_int]),
     "caspr_latent_rk4_team_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                           ctypes.c_void_p, c_long, c_stream]),
+    "caspr_latent_rk4_team_tape_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                               c_fp, c_int, c_fp, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
+    "caspr_latent_rk4_team_adjoint_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                                  c_fp, c_fp, c_int, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_cnf_rk4_f32": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_float, c_int, c_int,
                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_stream]),
     "caspr_cnf_x6_packed_bytes": (c_long, []),

@@ -580,6 +580,22 @@ def check_deferred_errors(wait=True):
         _team_raise_if_failed(key, wait=wait)
 
 
+def _team_track(key, ws, B):
+    """Queue the team kernel's error words (one per group of 16 sequences) for a later, non-blocking check (_team_raise_if_failed)."""
+    groups = (B + 15) // 16
+    words = ws[:groups * _LM_WS_STRIDE_WORDS * 4].view(torch.int32)[16::_LM_WS_STRIDE_WORDS]      # the error word of each group
+    ring = _team_status.setdefault(key, [])
+    if len(ring) >= 64:                              # nobody drained for 64 solves: bound the backlog (blocks on the oldest)
+        ring[0][1].synchronize()
+        _team_raise_if_failed(key)
+    slot = next((i for i, h in enumerate(_team_pool) if h.numel() == groups), None)
+    host = _team_pool.pop(slot) if slot is not None else torch.zeros(groups, dtype=torch.int32).pin_memory()
+    ev = torch.cuda.Event()
+    host.copy_(words, non_blocking=True)
+    ev.record(torch.cuda.current_stream())
+    ring.append((host, ev))
+
+
 def latent_rk4(z0, times, steps, wts, team=None):
     """Fixed-step RK4 of the latent dynamics (latent_ode_model.py:45-70): z0 (B,D) (rows may be a column
     slice of a wider tensor); wts = [PackedWeight0, b0, PackedWeight1, b1, PackedWeight2, b2, PackedWeight3, b3].  -> (B,Tu,D).
@@ -606,20 +622,8 @@ def latent_rk4(z0, times, steps, wts, team=None):
             ws = _team_workspace(L.caspr_latent_team_ws_bytes(B), z0.device)
             _lib.check(L.caspr_latent_rk4_team_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *ptrs, _p(out), _p(ws), ws.numel(),
                                                    _stream()), "caspr_latent_rk4_team_f32")
-        if capturing:
-            return out
-        groups = (B + 15) // 16
-        words = ws[:groups * _LM_WS_STRIDE_WORDS * 4].view(torch.int32)[16::_LM_WS_STRIDE_WORDS]      # the error word of each group
-        ring = _team_status.setdefault(key, [])
-        if len(ring) >= 64:                              # nobody drained for 64 solves: bound the backlog (blocks on the oldest)
-            ring[0][1].synchronize()
-            _team_raise_if_failed(key)
-        slot = next((i for i, h in enumerate(_team_pool) if h.numel() == groups), None)
-        host = _team_pool.pop(slot) if slot is not None else torch.zeros(groups, dtype=torch.int32).pin_memory()
-        ev = torch.cuda.Event()
-        host.copy_(words, non_blocking=True)
-        ev.record(torch.cuda.current_stream())
-        ring.append((host, ev))
+        if not capturing:
+            _team_track(key, ws, B)
         return out
     with timed("latent_rk4"):
         _lib.check(L.caspr_latent_rk4_f32(_p(z0), z0.stride(0), _p(times), B, Tu, D, H, int(steps), *ptrs, _p(out), _stream()), "caspr_latent_rk4_f32")

@@ -403,9 +403,77 @@ class LatentSolve(torch.autograd.Function):
     gradient accumulations per step (cfg-3: 72 evaluations x 4 layers); same arithmetic otherwise.
     z0 (B,D), tt (Tu,) device times, steps, then w0, b0, ..., w3, b3 -> (B,Tu,D)."""
 
+    TEAM = True        # the one-launch forms (caspr_latent_rk4_team_tape_f32 / _adjoint_f32) where the shape allows
+
+    @staticmethod
+    def _team_ok(z0, ws, bs):
+        return (LatentSolve.TEAM and len(ws) == 4 and all(b is not None for b in bs) and z0.shape[0] <= 64 and ws[0].shape[0] == 512
+                and ws[1].shape == (512, 512) and ws[2].shape == (512, 512) and ws[3].shape[1] == 512 and ws[0].shape[1] == ws[3].shape[0] <= 64
+                and ws[0].shape[1] == z0.shape[1])
+
+    @staticmethod
+    def _forward_team(ctx, z0, tt, steps, ws, bs):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        L = _lib.load()
+        B, D = z0.shape
+        Tu = tt.shape[0]
+        E, xw = 4 * steps * (Tu - 1), (D + 3) // 4 * 4
+        dev = z0.device
+        pk = [_packed(w, False) for w in ws]
+        bd = [b.detach().contiguous() for b in bs]
+        zc = z0.detach().contiguous()
+        tape = [torch.zeros(E * B, xw, device=dev, dtype=torch.float32)] + [torch.zeros(E * B, 512, device=dev, dtype=torch.float32) for _ in range(3)]
+        out = torch.empty(B, Tu, D, device=dev, dtype=torch.float32)
+        key = (dev.index, torch.cuda.current_stream().cuda_stream)
+        ops._team_raise_if_failed(key)
+        wsb = ops._team_workspace(L.caspr_latent_team_ws_bytes(B), dev)
+        ptrs = [p_ for w, b in zip(pk, bd) for p_ in (_p(w.data), _p(b))]
+        with ops.timed("latent_rk4_tape"):
+            _lib.check(L.caspr_latent_rk4_team_tape_f32(_p(zc), zc.stride(0), _p(tt), B, Tu, D, 512, int(steps), *ptrs, _p(out), _p(tape[0]), xw, _p(tape[1]),
+                                                        _p(tape[2]), _p(tape[3]), _p(wsb), wsb.numel(), _stream()), "caspr_latent_rk4_team_tape_f32")
+        ops._team_track(key, wsb, B)
+        ctx.team, ctx.tape, ctx.tt, ctx.steps, ctx.ws = True, tape, tt, steps, ws
+        return out
+
+    @staticmethod
+    def _backward_team(ctx, gout):
+        from .. import lib as _lib
+        from ..ops import _p, _stream
+        L = _lib.load()
+        tape, tt, steps, ws = ctx.tape, ctx.tt, ctx.steps, ctx.ws
+        B, Tu, D = gout.shape
+        xw = tape[0].shape[1]
+        dev = gout.device
+        pkt = [_packed(w, True) for w in ws]
+        g = gout.contiguous()
+        deltas = [torch.zeros_like(tape[1]) for _ in range(3)] + [torch.zeros_like(tape[0])]
+        gz = torch.empty(B, D, device=dev, dtype=torch.float32)
+        key = (dev.index, torch.cuda.current_stream().cuda_stream)
+        ops._team_raise_if_failed(key)
+        wsb = ops._team_workspace(L.caspr_latent_team_ws_bytes(B), dev)
+        with ops.timed("latent_rk4_adjoint"):
+            _lib.check(L.caspr_latent_rk4_team_adjoint_f32(_p(g), _p(tt), B, Tu, D, 512, int(steps), _p(pkt[3].data), _p(pkt[2].data), _p(pkt[1].data),
+                                                           _p(pkt[0].data), _p(tape[1]), _p(tape[2]), _p(tape[3]), _p(deltas[0]), _p(deltas[1]),
+                                                           _p(deltas[2]), _p(deltas[3]), xw, _p(gz), _p(wsb), wsb.numel(), _stream()),
+                       "caspr_latent_rk4_team_adjoint_f32")
+        ops._team_track(key, wsb, B)
+        grads = []
+        for i in range(4):
+            cout, cin = ws[i].shape
+            dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
+            db = torch.empty(cout, device=dev, dtype=torch.float32)
+            T.conv1x1_wgrad(deltas[i].view(1, deltas[i].shape[0], -1), tape[i].view(1, tape[i].shape[0], -1), cin, cout, dw, db)
+            grads += [dw, db]
+        ctx.tape = None
+        return (gz, None, None) + tuple(grads)
+
     @staticmethod
     def forward(ctx, z0, tt, steps, *wb):
         ws, bs = wb[0::2], wb[1::2]
+        if LatentSolve._team_ok(z0, ws, bs):
+            return LatentSolve._forward_team(ctx, z0, tt, steps, ws, bs)
+        ctx.team = False
         pk = [_packed(w, False) for w in ws]
         bd = [b.detach().contiguous() for b in bs]
         B = z0.shape[0]
@@ -436,6 +504,8 @@ class LatentSolve(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.team:
+            return LatentSolve._backward_team(ctx, gout)
         tape, hs, steps, ws = ctx.tape, ctx.hs, ctx.steps, ctx.ws
         pkt = [_packed(w, True) for w in ws]
         B = gout.shape[0]

@@ -109,6 +109,27 @@ int caspr_gn_rows_bwd_f32(const float *Y, int ldy, long NB, int ns, int C, const
                           float *dY, int lddy, float *dgamma, float *dbeta, int accumulate, void *ws,
                           long ws_bytes, void *stream);
 
+/* The latent ODE's training path in one launch each way (latent_ode_model.py:45-70,139-147 through torch.autograd + torchdiffeq's
+ * adjoint in the reference, train_utils.py:173; here the gradient of the discrete RK4 map).
+ * caspr_latent_rk4_team_tape_f32: caspr_latent_rk4_team_f32 (include/caspr_hip.h: same arguments, same values) that also leaves the tape
+ *   of its E = 4 steps (Tu - 1) evaluations, in the order they are made: tape_x (E, B, xw) the evaluation's input (xw >= D, a multiple
+ *   of 4), tape_h1 / h2 / h3 (E, B, 512) the three tanh outputs.  Evaluations a zero-length interval skips leave their rows untouched
+ *   (zero-fill the tape: they then contribute nothing to the weight gradients).
+ * caspr_latent_rk4_team_adjoint_f32: the reverse sweep.  gout (B, Tu, D) = dL/d(out) -> gz (B, D) = dL/dz0 and the per-layer deltas
+ *   d0 / d1 / d2 (E, B, 512), d3 (E, B, xw) (rows as the tape), from which dW_l = d_l^T tape_l and db_l = colsum(d_l) follow as ONE
+ *   caspr_conv1x1_wgrad_f32 per layer over the E B rows.  w3tp .. w0tp: caspr_pack_weight of the TRANSPOSED weights (W3^T (512, D) ..
+ *   W0^T (D, 512)).  Both: D <= 64, H == 512, B <= 64; ws: caspr_latent_team_ws_bytes(B), 256-byte aligned.  Deterministic.          */
+int caspr_latent_rk4_team_tape_f32(const float *z0, int ldz, const float *times, int B, int Tu, int D, int H, int steps,
+                                   const float *w0p, const float *b0, const float *w1p, const float *b1,
+                                   const float *w2p, const float *b2, const float *w3p, const float *b3, float *out,
+                                   float *tape_x, int xw, float *tape_h1, float *tape_h2, float *tape_h3, void *ws,
+                                   long ws_bytes, void *stream);
+int caspr_latent_rk4_team_adjoint_f32(const float *gout, const float *times, int B, int Tu, int D, int H, int steps,
+                                      const float *w3tp, const float *w2tp, const float *w1tp, const float *w0tp,
+                                      const float *tape_h1, const float *tape_h2, const float *tape_h3, float *d0,
+                                      float *d1, float *d2, float *d3, int xw, float *gz, void *ws, long ws_bytes,
+                                      void *stream);
+
 /* Gated softplus layer of the CNF's ODE function (ConcatSquashLinear + Softplus, diffeq_layers.py:83-90,
  * odefunc.py:98-105) on value and tangent rows of Z (2R, ldz) = the layer's matrix product; frame f = p / n has its
  * own gate / beta rows (hyper networks of the context).  Row layout: blk = R puts the value of point p in row p and its

@@ -701,8 +701,11 @@ def test_eval_mode_forward_is_differentiable_and_cnf_forward_draws_fresh_noise(s
                         e=torch.randn(2, 8, 3, device=dev), logp=torch.zeros(2, 64, 1, device=dev))
 
 
-def test_latent_solve_single_node_matches_per_layer_autograd_and_f64():
-    """LatentSolve (one autograd node, hand-written reverse sweep, weight gradients of all evaluations as one product per layer)
+@pytest.mark.parametrize("team,nseq", [(True, 8), (False, 8), (True, 20)])
+def test_latent_solve_single_node_matches_per_layer_autograd_and_f64(monkeypatch, team, nseq):
+    """team: the one-launch forms (caspr_latent_rk4_team_tape_f32 / _adjoint_f32: 32 workgroups per 16 sequences, the tape and the deltas
+    written by the kernels) against the launch-per-product form of the same node; 20 sequences = two teams, the second one ragged.
+    LatentSolve (one autograd node, hand-written reverse sweep, weight gradients of all evaluations as one product per layer)
     against the per-layer form differentiated by torch.autograd on the same kernels, and against float64 autograd of the same
     RK4 map on the CPU (latent_ode_model.py:45-70,139-147 with the fixed-step solver of DESIGN.md section 4)."""
     from caspr_amd.models.latent_ode_model import LatentODE
@@ -711,9 +714,10 @@ def test_latent_solve_single_node_matches_per_layer_autograd_and_f64():
     torch.manual_seed(11)
     lat = LatentODE(input_size=64, hidden_size=512, num_layers=2).to(dev)
     lat.rk4_steps = 2
-    z0 = rnd(1, 8, 64, scale=0.5).to(dev).requires_grad_(True)
+    monkeypatch.setattr(FG.LatentSolve, "TEAM", team)
+    z0 = rnd(1, nseq, 64, scale=0.5).to(dev).requires_grad_(True)
     times = torch.tensor([0.0, 0.2, 0.2, 0.55, 1.0], device=dev)          # a repeated stamp: a zero-length interval
-    wgt = rnd(2, 8, 5, 64).to(dev)
+    wgt = rnd(2, nseq, 5, 64).to(dev)
     params = [p for p in lat.ode_func.parameters()]
 
     def grads(fn):
