@@ -690,7 +690,7 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     CASPR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)wp % 16) == 0, "conv1x1: pointers must be 16-byte aligned");
     CASPR_REQUIRE(B <= 65535, "conv1x1: B=%d > 65535", B);
     CASPR_REQUIRE(in_relu_from >= 0 && in_relu_from % 4 == 0, "conv1x1: in_relu_from=%d must be a non-negative multiple of 4", in_relu_from);
-    const int force = CASPR_DEBUG_ENV_INT("CASPR_GEMM_KERNEL");   // debug build only: 1 = 128-point tiles, 7 = streaming (experiments)
+    const int force = CASPR_DEBUG_ENV_INT("CASPR_GEMM_KERNEL");   // debug build only: 1 = 128-point tiles, 7 = streaming, 8 = narrow where its contract holds (experiments)
     const size_t lds_pad = (size_t)CASPR_DEBUG_ENV_INT("CASPR_GEMM_LDS_PAD") * 1024;   // occupancy experiments, debug build only
     CASPR_REQUIRE(ceil_div(P, 128) <= 65535, "conv1x1: P=%d rows per batch entry exceed the grid (split the call)", P);
     if (force == 0 && P <= 16 && !in_scale && !(act & CASPR_CONV_ROW_INVARIANT)) {
