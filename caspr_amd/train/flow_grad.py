@@ -471,6 +471,10 @@ class LatentSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z0, tt, steps, *wb):
         ws, bs = wb[0::2], wb[1::2]
+        ctx.single = tt.shape[0] == 1
+        if ctx.single:          # one time stamp: nothing to integrate (odeint returns the initial state, latent_ode_model.py:58-66)
+            ctx.ws, ctx.has_b = ws, [b is not None for b in bs]
+            return z0.detach().unsqueeze(1).clone()
         if LatentSolve._team_ok(z0, ws, bs):
             return LatentSolve._forward_team(ctx, z0, tt, steps, ws, bs)
         ctx.team = False
@@ -504,6 +508,9 @@ class LatentSolve(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.single:
+            zeros = [g for w, hb in zip(ctx.ws, ctx.has_b) for g in (torch.zeros_like(w), torch.zeros(w.shape[0], device=w.device, dtype=w.dtype) if hb else None)]
+            return (gout[:, 0].contiguous(), None, None) + tuple(zeros)
         if ctx.team:
             return LatentSolve._backward_team(ctx, gout)
         tape, hs, steps, ws = ctx.tape, ctx.hs, ctx.steps, ctx.ws

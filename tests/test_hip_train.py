@@ -762,6 +762,24 @@ def test_latent_solve_single_node_matches_per_layer_autograd_and_f64(monkeypatch
         rel("latent_node_vs_f64_dp%d" % i, a, b, 3e-5)
 
 
+def test_latent_solve_with_one_time_stamp_is_the_identity():
+    """One time stamp: the solve returns its initial state (odeint at a single time, latent_ode_model.py:58-66), dL/dz0 is the output's
+    gradient and the dynamics net gets zero gradients -- not an exception from an empty tape."""
+    from caspr_amd.models.latent_ode_model import LatentODE
+    from caspr_amd.train import flow_grad as FG
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    lat = LatentODE(input_size=64, hidden_size=512, num_layers=2).to(dev)
+    z0 = rnd(1, 4, 64).to(dev).requires_grad_(True)
+    wgt = rnd(2, 4, 1, 64).to(dev)
+    wb = [x for i in (0, 2, 4, 6) for x in (lat.ode_func.dynamics_net[i].weight, lat.ode_func.dynamics_net[i].bias)]
+    out = FG.LatentSolve.apply(z0, torch.tensor([0.3], device=dev), 2, *wb)
+    assert out.shape == (4, 1, 64) and torch.equal(out[:, 0], z0.detach())
+    (out * wgt).sum().backward()
+    assert torch.equal(z0.grad, wgt[:, 0])
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in wb)
+
+
 def test_cnf_fused_layers_match_the_separate_passes():
     """The ODE function's hidden layers with the gated softplus in the conv's epilogue (CnfLayer / CnfLayerOut, row layout blk = 32)
     against the separate passes (linear_rows + CnfAct in the [values | tangents] layout, blk = R), forward and every gradient, and
