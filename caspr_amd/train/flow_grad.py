@@ -426,13 +426,16 @@ class LatentSolve(torch.autograd.Function):
         tape = [torch.zeros(E * B, xw, device=dev, dtype=torch.float32)] + [torch.zeros(E * B, 512, device=dev, dtype=torch.float32) for _ in range(3)]
         out = torch.empty(B, Tu, D, device=dev, dtype=torch.float32)
         key = (dev.index, torch.cuda.current_stream().cuda_stream)
-        ops._team_raise_if_failed(key)
+        capturing = torch.cuda.is_current_stream_capturing()       # as ops.latent_rk4: no event queries / host copies under hipGraph capture
+        if not capturing:
+            ops._team_raise_if_failed(key)
         wsb = ops._team_workspace(L.caspr_latent_team_ws_bytes(B), dev)
         ptrs = [p_ for w, b in zip(pk, bd) for p_ in (_p(w.data), _p(b))]
         with ops.timed("latent_rk4_tape"):
             _lib.check(L.caspr_latent_rk4_team_tape_f32(_p(zc), zc.stride(0), _p(tt), B, Tu, D, 512, int(steps), *ptrs, _p(out), _p(tape[0]), xw, _p(tape[1]),
                                                         _p(tape[2]), _p(tape[3]), _p(wsb), wsb.numel(), _stream()), "caspr_latent_rk4_team_tape_f32")
-        ops._team_track(key, wsb, B)
+        if not capturing:
+            ops._team_track(key, wsb, B)
         ctx.team, ctx.tape, ctx.tt, ctx.steps, ctx.ws = True, tape, tt, steps, ws
         return out
 
@@ -450,14 +453,17 @@ class LatentSolve(torch.autograd.Function):
         deltas = [torch.zeros_like(tape[1]) for _ in range(3)] + [torch.zeros_like(tape[0])]
         gz = torch.empty(B, D, device=dev, dtype=torch.float32)
         key = (dev.index, torch.cuda.current_stream().cuda_stream)
-        ops._team_raise_if_failed(key)
+        capturing = torch.cuda.is_current_stream_capturing()       # as ops.latent_rk4: no event queries / host copies under hipGraph capture
+        if not capturing:
+            ops._team_raise_if_failed(key)
         wsb = ops._team_workspace(L.caspr_latent_team_ws_bytes(B), dev)
         with ops.timed("latent_rk4_adjoint"):
             _lib.check(L.caspr_latent_rk4_team_adjoint_f32(_p(g), _p(tt), B, Tu, D, 512, int(steps), _p(pkt[3].data), _p(pkt[2].data), _p(pkt[1].data),
                                                            _p(pkt[0].data), _p(tape[1]), _p(tape[2]), _p(tape[3]), _p(deltas[0]), _p(deltas[1]),
                                                            _p(deltas[2]), _p(deltas[3]), xw, _p(gz), _p(wsb), wsb.numel(), _stream()),
                        "caspr_latent_rk4_team_adjoint_f32")
-        ops._team_track(key, wsb, B)
+        if not capturing:
+            ops._team_track(key, wsb, B)
         grads = []
         for i in range(4):
             cout, cin = ws[i].shape
