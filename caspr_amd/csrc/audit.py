@@ -38,12 +38,26 @@ def _code_object(obj):
 
 
 def _kernel(notes, dis, name):
-    meta = notes[max(0, notes.index(name) - 400):]
-    meta = meta[:meta.index(name) + 600]
-    body = dis[dis.index("<%s>:" % name):]
-    body = body[:body.index("s_endpgm")]
+    """-> (the metadata entry of kernel `name` in the amdhsa.kernels note, its instruction list).  The note is a YAML list whose
+    entries start with "  - ." at list depth; the entry is found by its `.name:` line, not by character windows."""
+    entry, cur = None, []
+    for ln in notes.splitlines() + ["  - .end"]:
+        if re.match(r"^\s{0,4}- \.", ln):
+            if any(re.match(r"^\s*(- )?\.name:\s+%s\s*$" % re.escape(name), l) for l in cur):
+                entry = "\n".join(cur)
+                break
+            cur = [ln]
+        else:
+            cur.append(ln)
+    if entry is None:
+        raise AuditError("%s: no metadata entry in the code object's notes" % name)
+    try:
+        body = dis[dis.index("<%s>:" % name):]
+        body = body[:body.index("s_endpgm")]
+    except ValueError:
+        raise AuditError("%s: not found in the disassembly" % name) from None
     ins = [ln.split("//")[0].strip() for ln in body.splitlines() if ln.startswith("\t")]
-    return meta, ins
+    return entry, ins
 
 
 def _need(cond, what):
@@ -101,16 +115,20 @@ AUDITS = {"ode_bf16x6w.hip": audit_cnf_x6w, "gemm_bf16x6w.hip": audit_conv_x6w}
 
 
 def audit_objects(objs_by_source):
-    """objs_by_source: {source file name: object path}.  Raises AuditError (naming the compiler) on the first violation."""
+    """objs_by_source: {source file name: object path}.  Raises AuditError (naming the compiler) on the first violation -- including
+    missing LLVM tools and anything unexpected while taking the code object apart.  CASPR_SKIP_AUDIT=1 (build.py) turns a failure
+    into a loud warning: for a ROCm point release that schedules differently but correctly -- after `pytest -m gpu` has shown that
+    the two kernels still compute what the oracle says."""
     if not tools_present():
-        raise AuditError("the ROCm LLVM tools (%s) are needed to audit the hand-managed accumulator kernels" % LLVM)
+        raise AuditError("the ROCm LLVM tools (%s: llvm-objdump, llvm-objcopy, llvm-readelf, clang-offload-bundler) are needed to audit the "
+                         "hand-managed accumulator kernels" % LLVM)
     res = {}
     for src, fn in AUDITS.items():
         if src in objs_by_source:
             try:
                 res[src] = fn(objs_by_source[src])
-            except AuditError as e:
+            except (AuditError, ValueError, IndexError, subprocess.CalledProcessError) as e:
                 ver = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], capture_output=True, text=True).stdout.splitlines()[:2]
-                raise AuditError("%s\n  this compiler: %s\n  tested with:   %s\n  -> the library is NOT produced"
-                                 % (e, " / ".join(ver), TESTED_HIPCC)) from None
+                raise AuditError("%s\n  this compiler: %s\n  tested with:   %s\n  -> the library is NOT produced (CASPR_SKIP_AUDIT=1 overrides, "
+                                 "see caspr_amd/csrc/audit.py)" % (e, " / ".join(ver), TESTED_HIPCC)) from None
     return res

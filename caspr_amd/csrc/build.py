@@ -57,7 +57,16 @@ def build(force=False, verbose=False):
         # values in a0..a255 or spills there would corrupt them silently (audit.py); the debug / experiment flavours carry trace hooks and switches that change the counts
         if not DEBUG:
             from caspr_amd.csrc import audit
-            audit.audit_objects(by_src)
+            try:
+                audit.audit_objects(by_src)
+            except audit.AuditError as e:
+                # CASPR_SKIP_AUDIT=1: link anyway (a ROCm point release that schedules or unrolls differently but correctly would
+                # otherwise make the whole framework unbuildable); the GPU suite then is the judge of the two kernels
+                if os.environ.get("CASPR_SKIP_AUDIT", "0") != "1":
+                    raise
+                import warnings
+                warnings.warn("caspr_amd build: code-object audit FAILED and was skipped on request (CASPR_SKIP_AUDIT=1):\n%s\n"
+                              "run `pytest -m gpu` before trusting cnf_rk4_x6w_kernel / conv1x1_x6w_kernel" % e, RuntimeWarning)
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     return OUT
 

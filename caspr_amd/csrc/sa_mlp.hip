@@ -23,6 +23,7 @@ struct SaArgs {
     const int32_t *idx;
     int ldf, n, M, C;
     int feat_kind;     // CASPR_FEAT_QUAD | CASPR_FEAT_PAIRS: feat = quadratic augmentation of xyz (caspr_prep_input_f32)
+    int lo_in, lo_out; // CASPR_FEAT_LO_IN: feat rows carry low parts at column ldf / 2; CASPR_FEAT_LO_OUT: the low part of the output goes to column ldo / 2 + out_off
     SaLayer L[3];
     float *out;
     int ldo, out_off;
@@ -341,6 +342,16 @@ __device__ __forceinline__ double sa_rows_allreduce(double x)
 // binds.  Measured per variant with the f64 reference column in, ms per cfg-2 launch without / with a bound: <16,16,16,32> 0.52 / 0.45 (bound 3:
 // 158 registers instead of 184), <32,32,32,64> 1.24 + 0.64 / 0.97 + 0.70 for its two levels (bound 2: 167 instead of 204), <16,32,32,64>
 // 0.52 / 0.55 (240 / 197: no bound).  Hence one body and three entry points.)
+// Between a lane's write to the wave's own LDS window (s_a0 / s_mu) and another lane's read of it: LDS operations of one wave issue in
+// order, so no hardware barrier is needed -- but the COMPILER must keep the ds_write in front of the ds_read; the fence pair + the wave
+// barrier (a scheduling fence, no instruction) make that a contract instead of an observation (round-4 advice).
+__device__ __forceinline__ void sa_window_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int NS, int C1, int C2, int C3>
 __device__ __forceinline__ void sa_small_body(const SaArgs &a)
 {
@@ -433,6 +444,44 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
     };
     // B fragments of chunk kc straight from global memory: deviations from the neighbourhood's sample 0, and in sample 0's own column
     // (lane j = 0 of the neighbourhood's first tile, whose deviation is zero) the reference itself
+    // THE LOW PART OF THE REFERENCE INPUT (round 5).  The reference column is f64 from layer 1 on, but its INPUT was f32: the first
+    // level's quadratic features as caspr_prep_input_f32 rounds them (x^2 ~ 6 carries 4e-7), the deeper levels' features as the previous
+    // level stored them.  In a ball that holds ONE point the whole output is the GroupNorm chain of that input, and a two-channel group
+    // whose channels differ by ~1e-4 multiplies the input rounding by up to 158: 4e-4 on cfg-5's clouds.  rlo = what the f32 quad lacks:
+    // the exact f64 products of the coordinates minus the rounded feature (feat_kind), or the low part the previous level stored next to
+    // its output (lo_in); its product with the weights joins the f64 partials of mu behind the product loop.
+    // Only a ball that holds ONE point needs it: balls of 2..8 distinct points are re-evaluated in f64 behind this kernel
+    // (sa_repair_f64_kernel), larger ones carry the f32 rounding of their deviation columns anyway.  Wave-uniform.
+    bool single = false;
+#pragma unroll
+    for (int cen = 0; cen < NCEN; ++cen) {
+        bool same = true;
+#pragma unroll
+        for (int t = 0; t < TPC; ++t) same = same && __builtin_amdgcn_ballot_w64(nrow[cen * TPC + t] != rrow[cen]) == 0ull;
+        single = single || same;
+    }
+    const bool want_lo = (a.feat_kind != 0 || a.lo_in != 0) && single;
+    auto ref_lo = [&](int cen, int k, const f32x4 &ref) -> f32x4 {
+        f32x4 lo = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.feat_kind) {
+            if (k < C4) {
+                const float *q = a.xyz + ((long)b * a.n + rrow[cen]) * 3;
+                const double x0 = (double)q[0], y0 = (double)q[1], z0 = (double)q[2];
+                const bool qd = a.feat_kind & CASPR_FEAT_QUAD, both = qd && (a.feat_kind & CASPR_FEAT_PAIRS);
+                const double xz = x0 * z0, xy = x0 * y0, zy = z0 * y0;
+                const double f0 = qd ? x0 * x0 : xz, f1 = qd ? y0 * y0 : xy, f2 = qd ? z0 * z0 : zy;
+                const double e0 = k == 0 ? f0 : (both ? xy : 0.0), e1 = k == 0 ? f1 : (both ? zy : 0.0);
+                const double e2 = k == 0 ? f2 : 0.0, e3 = k == 0 ? (both ? xz : 0.0) : 0.0;
+                lo[0] = (float)(e0 - (double)ref[0]);
+                lo[1] = (float)(e1 - (double)ref[1]);
+                lo[2] = (float)(e2 - (double)ref[2]);
+                lo[3] = (float)(e3 - (double)ref[3]);
+            }
+        } else if (k < C4) {
+            lo = ld4(a.feat + ((long)b * a.n + rrow[cen]) * a.ldf + (a.ldf >> 1) + k);
+        }
+        return lo;
+    };
     auto gather = [&](f32x4(&bf)[CT], int kc) {
         const int k = kc * 16 + 4 * g;
         f32x4 ref[NCEN];
@@ -512,6 +561,29 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
             mask(b0, kcu - 1);
             mma1(b0, w0);
         }
+        // the low part of the reference input, behind the product loop (its registers are free again): P1 += W lo in f64, this lane's
+        // weight row against the low parts of ITS k quads -- one more pass over the weight fragments (L1) and, with lo_in, one 16-byte
+        // load per centre and chunk
+        if (want_lo) {
+#pragma unroll 1
+            for (int kc = 0; kc < kcu; ++kc) {
+                const int k = kc * 16 + 4 * g;
+                f32x4 wl[C1 / 16];
+                load_a1(wl, kc);
+#pragma unroll
+                for (int cen = 0; cen < NCEN; ++cen) {
+                    f32x4 ref = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (a.feat_kind) ref = in_quad(rrow[cen], k, cx[cen * TPC], cy[cen * TPC], cz[cen * TPC]);
+                    f32x4 lo = ref_lo(cen, k, ref);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) lo[q] = k + q < a.C ? lo[q] : 0.f;
+#pragma unroll
+                    for (int rt = 0; rt < C1 / 16; ++rt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) P1[rt][cen] = __builtin_fma((double)wl[rt][q], (double)lo[q], P1[rt][cen]);
+                }
+            }
+        }
     }
     // the four k-rows of the partials summed, then row ar of tile rt -> the window (every lane row writes the same value)
     auto publish_mu = [&](auto &P, auto RTc) {
@@ -522,6 +594,7 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
             for (int cen = 0; cen < NCEN; ++cen) mus[rt][cen][ar] = sa_rows_allreduce(P[rt][cen]);
     };
     publish_mu(P1, std::integral_constant<int, C1 / 16>{});
+    sa_window_sync();
 
     // bias + GroupNorm(16) per neighbourhood on a register-resident layer output in the centred form: on entry column 0 of the
     // neighbourhood's first tile holds W a_0 (lane j = 0), every other column W d_s.  FINAL = false: ReLU, and the output is written back
@@ -546,7 +619,7 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
                     mu[e] = mus[rt][cen][4 * g + e] + (double)bias4[e];
                     if (refl) h[rt][cen * TPC][e] = 0.f;
                 }
-                f32x4 mx = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 mx = (f32x4){0.f, 0.f, 0.f, 0.f}, mlo = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sg = 0; sg < 4 / CPG; ++sg) {
                     double s1 = 0.0, s2 = 0.0;
@@ -580,7 +653,10 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
                             float dm = 0.f;
 #pragma unroll
                             for (int t = 0; t < TPC; ++t) dm = fmaxf(dm, h[rt][cen * TPC + t][e] * sc);
-                            mx[e] = n0 + row_allreduce_max<16>(dm);
+                            dm = row_allreduce_max<16>(dm);
+                            mx[e] = n0 + dm;
+                            // what the f32 output lacks of (f64 reference + largest deviation): stored next to it when the next level asks
+                            mlo[e] = (float)((n64 + (double)dm) - (double)mx[e]);
                         } else {
                             const double a64 = n64 > 0.0 ? n64 : 0.0;
                             const float a0 = (float)a64;
@@ -597,8 +673,10 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
                         }
                     }
                 }
-                if (FINAL && refl && cval[cen * TPC])
+                if (FINAL && refl && cval[cen * TPC]) {
                     st4(a.out + ((long)b * a.M + m0 + cen) * a.ldo + a.out_off + rt * 16 + 4 * g, mx);
+                    if (a.lo_out) st4(a.out + ((long)b * a.M + m0 + cen) * a.ldo + (a.ldo >> 1) + a.out_off + rt * 16 + 4 * g, mlo);
+                }
             }
         }
     };
@@ -642,17 +720,20 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
 #pragma unroll
             for (int rt = 0; rt < RO; ++rt) mus[rt][cen][ar] = sa_rows_allreduce(P[rt]);
         }
+        sa_window_sync();          // mus published -> norm() of this layer reads rows 4 g + e
     };
     using I1 = std::integral_constant<int, C1 / 16>;
     using I2 = std::integral_constant<int, C2 / 16>;
     using I3 = std::integral_constant<int, C3 / 16>;
     SA_STAMP(2)
     norm(h1, I1{}, a.L[0], std::false_type{});
+    sa_window_sync();              // a0s of layer 1 written by every row's lanes -> layer 2 reads the k quads of other lanes
     SA_STAMP(3)
     f32x4 h2[C2 / 16][CT];
     layer(h2, I2{}, h1, I1{}, a.L[1]);
     SA_STAMP(4)
     norm(h2, I2{}, a.L[1], std::false_type{});
+    sa_window_sync();
     SA_STAMP(5)
     f32x4 h3[C3 / 16][CT];
     layer(h3, I3{}, h2, I2{}, a.L[2]);
@@ -668,6 +749,230 @@ template <int NS, int C1, int C2, int C3>
 __global__ __launch_bounds__(256, 2) void sa_small_kernel_w2(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
 template <int NS, int C1, int C2, int C3>
 __global__ __launch_bounds__(256, 3) void sa_small_kernel_w3(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
+
+// ---------------------------------------------------------------------------------------------
+// SMALL NEIGHBOURHOODS IN f64 (round 5).  What the centred form with an f64 reference column could not reach: a ball that holds 2..4
+// distinct points has 1..3 distinct deviation columns, and a GroupNorm group of one or two channels in which ALL of them happen to cancel
+// (|W d| ~ 1e-3 out of partial sums of magnitude ~4) has a variance below eps: rstd -> 316 multiplies the f32 ACCUMULATION error of the
+// MFMA's W d (4e-7), three layers in a row -- 4e-4 on the isolated 16-sample scale of level 0, 3.5e-5 on cfg-5's T-NOCS, in this build as
+// in the reference's own f32 arithmetic.  With K distinct points the coincidence needs K - 1 independent cancellations, so the tail dies
+// quickly with K; the cases that matter are exactly the cheap ones.  This kernel runs BEHIND the register kernel and re-evaluates every
+// neighbourhood with 2 <= K <= KMAX distinct samples entirely in f64 on the vector pipe (v_fma_f64 runs at the f32 rate on CDNA): the K
+// distinct columns only, the statistics weighted with the columns' multiplicities (ball query pads with copies of the first hit:
+// multiplicity ns - K + 1 for column 0, 1 for the others), and overwrites the register kernel's output rows.  16 lanes own one
+// neighbourhood: lane r the output rows 16 rt + r of every row tile (GroupNorm groups of 1 / 2 / 4 channels = 1 / 2 / 4 adjacent lanes);
+// the activations of a layer pass through a wave-private LDS window (f64), the weights come from the same A-pack the MFMA kernel reads.
+// K = 1 (all copies of one point) stays with the register kernel, whose reference column is f64 already.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int sa_row_bcast_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+// (ball of row `row`: K = number of distinct samples when the row has ball query's layout -- entry 0 the first hit, entries 1..K-1 the
+// other hits, then copies of entry 0 -- else 0; the 16 lanes of a DPP row look at one neighbourhood)
+__device__ __forceinline__ int sa_row_distinct(const int32_t *row, int ns, int r, int &i0, int &first)
+{
+    i0 = row[r];
+    const int i1 = ns > 16 ? row[16 + r] : 0;
+    first = sa_row_bcast_i32<0x150>(i0);        // row_newbcast:0
+    int cnt = (i0 != first ? 1 : 0) + ((ns > 16 && i1 != first) ? 1 : 0);
+    cnt += sa_row_bcast_i32<0xB1>(cnt);
+    cnt += sa_row_bcast_i32<0x4E>(cnt);
+    cnt += sa_row_bcast_i32<0x141>(cnt);
+    cnt += sa_row_bcast_i32<0x140>(cnt);
+    const int K = cnt + 1;
+    int bad = ((i0 != first) != (r >= 1 && r < K) ? 1 : 0) + ((ns > 16 && ((i1 != first) != (16 + r < K))) ? 1 : 0);
+    bad += sa_row_bcast_i32<0xB1>(bad);
+    bad += sa_row_bcast_i32<0x4E>(bad);
+    bad += sa_row_bcast_i32<0x141>(bad);
+    bad += sa_row_bcast_i32<0x140>(bad);
+    return bad == 0 ? K : 0;
+}
+
+// KLO <= K <= KHI distinct samples.  A workgroup surveys 64 neighbourhoods, lists the ones in its range in LDS, and its 16 lane groups
+// walk that list: on dense clouds the kernel is the index read, on sparse ones the lane groups stay busy whatever the pattern of
+// small balls (with a fixed neighbourhood per lane group a wave paid for four whenever one of them was small).
+template <int KLO, int KHI>
+__global__ __launch_bounds__(256) void sa_repair_f64_kernel(SaArgs a, int ns)
+{
+    constexpr int KMAX = KHI;
+    constexpr int CMAX = 64;                              // widest LAST layer (register budget: CMAX / 16 x KMAX doubles)
+    constexpr int CACT = 32;                              // widest first / second layer: what passes through the LDS window
+    constexpr int RTM = CMAX / 16;
+    constexpr int NBW = 64;                               // neighbourhoods surveyed per workgroup
+    constexpr int STR = KMAX * CACT + 2;                  // + 2 doubles: the 16 windows of a workgroup start in different banks
+    __shared__ double s_act[16 * STR];
+    __shared__ int s_list[NBW];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x, r = tid & 15, nb = tid >> 4;
+    const int b = blockIdx.y;
+    double *act = s_act + nb * STR;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < NBW / 16; ++i) {
+        const int m = blockIdx.x * NBW + nb + 16 * i;
+        const int mm = m < a.M ? m : a.M - 1;
+        int i0, first;
+        const int K = sa_row_distinct(a.idx + ((long)b * a.M + mm) * ns, ns, r, i0, first);
+        if (m < a.M && K >= KLO && K <= KHI && r == 0) s_list[atomicAdd(&s_cnt, 1)] = m;
+    }
+    __syncthreads();
+    const int nlist = s_cnt;
+#pragma unroll 1
+    for (int li = nb; li < nlist; li += 16) {
+        const int m = s_list[li];
+        int i0, first;
+        const int K = sa_row_distinct(a.idx + ((long)b * a.M + m) * ns, ns, r, i0, first);
+        int rows[KMAX];
+        rows[0] = first;
+        if (KMAX > 1) rows[1] = sa_row_bcast_i32<0x151>(i0);
+        if (KMAX > 2) rows[2] = sa_row_bcast_i32<0x152>(i0);
+        if (KMAX > 3) rows[3] = sa_row_bcast_i32<0x153>(i0);
+        if (KMAX > 4) rows[4] = sa_row_bcast_i32<0x154>(i0);
+        if (KMAX > 5) rows[5] = sa_row_bcast_i32<0x155>(i0);
+        if (KMAX > 6) rows[6] = sa_row_bcast_i32<0x156>(i0);
+        if (KMAX > 7) rows[7] = sa_row_bcast_i32<0x157>(i0);
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) rows[c] = c < K ? rows[c] : first;
+        double mult[KMAX];
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) mult[c] = c == 0 ? (double)(ns - K + 1) : (c < K ? 1.0 : 0.0);
+
+        const int C4 = (a.C + 3) & ~3;
+        double y[RTM][KMAX];
+        // ---- layer 1 from global memory: K order [feat (C, padded to C4) | dx dy dz 0]
+        {
+            const SaLayer L = a.L[0];
+            const int RT = L.cout >> 4;
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) y[rt][c] = 0.0;
+            const float *cen = a.new_xyz + ((long)b * a.M + m) * 3;
+            const float ccx = cen[0], ccy = cen[1], ccz = cen[2];
+            const int nkq = (C4 >> 2) + 1;
+            for (int kq = 0; kq < nkq; ++kq) {
+                double x[KMAX][4];
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) {
+                    const float *p = a.xyz + ((long)b * a.n + rows[c]) * 3;
+                    if (kq * 4 == C4) {
+                        x[c][0] = (double)(p[0] - ccx);           // the grouper's f32 subtraction (pointnet2.py:391-398)
+                        x[c][1] = (double)(p[1] - ccy);
+                        x[c][2] = (double)(p[2] - ccz);
+                        x[c][3] = 0.0;
+                    } else if (a.feat_kind) {
+                        // the first level's quadratic augmentation (tpointnet2.py:79-90) from the coordinates, in f64
+                        const double px = (double)p[0], py = (double)p[1], pz = (double)p[2];
+                        const bool qd = a.feat_kind & CASPR_FEAT_QUAD, both = qd && (a.feat_kind & CASPR_FEAT_PAIRS);
+                        const double xz = px * pz, xy = px * py, zy = pz * py;
+                        const double f0 = qd ? px * px : xz, f1 = qd ? py * py : xy, f2 = qd ? pz * pz : zy;
+                        x[c][0] = kq == 0 ? f0 : (both ? xy : 0.0);
+                        x[c][1] = kq == 0 ? f1 : (both ? zy : 0.0);
+                        x[c][2] = kq == 0 ? f2 : 0.0;
+                        x[c][3] = kq == 0 ? (both ? xz : 0.0) : 0.0;
+                    } else {
+                        const float *fr = a.feat + ((long)b * a.n + rows[c]) * a.ldf + kq * 4;
+                        const f32x4 v = ld4(fr);
+                        const f32x4 vl = a.lo_in ? ld4(fr + (a.ldf >> 1)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[c][q] = kq * 4 + q < a.C ? (double)v[q] + (double)vl[q] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) {
+                    if (rt < RT) {
+                        const f32x4 w = ld4(L.wp + (((long)rt * L.kc + (kq >> 2)) * 64 + (kq & 3) * 16 + r) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int c = 0; c < KMAX; ++c) y[rt][c] = __builtin_fma((double)w[q], x[c][q], y[rt][c]);
+                    }
+                }
+            }
+        }
+#pragma unroll 1
+        for (int l = 0; l < 3; ++l) {
+            const SaLayer L = a.L[l];
+            const int RT = L.cout >> 4;                   // = channels per GroupNorm(16) group
+            if (l > 0) {
+                // ---- layers 2, 3 from the window
+                const int nkq = a.L[l - 1].cout >> 2;
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c) y[rt][c] = 0.0;
+                for (int kq = 0; kq < nkq; ++kq) {
+                    double x[KMAX][4];
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[c][q] = act[c * CACT + kq * 4 + q];
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) {
+                        if (rt < RT) {
+                            const f32x4 w = ld4(L.wp + (((long)rt * L.kc + (kq >> 2)) * 64 + (kq & 3) * 16 + r) * 4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int c = 0; c < KMAX; ++c) y[rt][c] = __builtin_fma((double)w[q], x[c][q], y[rt][c]);
+                        }
+                    }
+                }
+                // every lane of the neighbourhood has read the window before the next layer's activations overwrite it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- bias, GroupNorm(16) over (RT channels x ns samples) with the columns' multiplicities, two passes in f64
+            const double inv_cnt = 1.0 / (double)(RT * ns);
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) {
+                if (rt < RT) {
+                    const int ch = rt * 16 + r;
+                    const double bias = (double)L.bias[ch], ga = (double)L.gamma[ch], be = (double)L.beta[ch];
+                    double s1 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c) {
+                        y[rt][c] += bias;
+                        s1 += mult[c] * y[rt][c];
+                    }
+                    if (RT >= 2) s1 += dpp_mov<0xB1>(s1);
+                    if (RT >= 4) s1 += dpp_mov<0x4E>(s1);
+                    const double mean = s1 * inv_cnt;
+                    double s2 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c) {
+                        const double d = y[rt][c] - mean;
+                        s2 += mult[c] * d * d;
+                    }
+                    if (RT >= 2) s2 += dpp_mov<0xB1>(s2);
+                    if (RT >= 4) s2 += dpp_mov<0x4E>(s2);
+                    const double rstd = 1.0 / sqrt(s2 * inv_cnt + 1e-5);
+                    double mx = -INFINITY;
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c) {
+                        double v = (y[rt][c] - mean) * (rstd * ga) + be;
+                        if (l < 2) {
+                            v = v > 0.0 ? v : 0.0;
+                            act[c * CACT + ch] = v;
+                        } else if (c < K) {
+                            mx = v > mx ? v : mx;
+                        }
+                    }
+                    if (l == 2) {
+                        float *o = a.out + ((long)b * a.M + m) * a.ldo + a.out_off + ch;
+                        const float hi = (float)mx;
+                        o[0] = hi;
+                        if (a.lo_out) o[a.ldo >> 1] = (float)(mx - (double)hi);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
 
 template <int NS, int NCOL>
 static int launch_sa(const SaArgs &a, int B, size_t shmem, hipStream_t st)
@@ -710,8 +1015,13 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = feat; a.idx = idx;
     a.ldf = ldf; a.n = n; a.M = M; a.C = C;
     const int want_c = ((feat_kind & CASPR_FEAT_QUAD) ? 3 : 0) + ((feat_kind & CASPR_FEAT_PAIRS) ? 3 : 0);
-    CASPR_REQUIRE(feat_kind == 0 || (feat_kind > 0 && feat_kind <= 3 && C == want_c), "sa_mlp_max: feat_kind=%d does not describe C=%d channels", feat_kind, C);
-    a.feat_kind = feat_kind;
+    const int aug = feat_kind & (CASPR_FEAT_QUAD | CASPR_FEAT_PAIRS);
+    CASPR_REQUIRE(feat_kind >= 0 && feat_kind < 16 && (aug == 0 || C == want_c), "sa_mlp_max: feat_kind=%d does not describe C=%d channels", feat_kind, C);
+    a.feat_kind = aug;
+    a.lo_in = (feat_kind & CASPR_FEAT_LO_IN) ? 1 : 0;
+    a.lo_out = (feat_kind & CASPR_FEAT_LO_OUT) ? 1 : 0;
+    CASPR_REQUIRE(!a.lo_in || (aug == 0 && feat && ldf % 8 == 0 && ldf / 2 >= ((C + 3) & ~3)), "sa_mlp_max: CASPR_FEAT_LO_IN needs feat rows of [C | low parts of C] (ldf=%d, C=%d)", ldf, C);
+    CASPR_REQUIRE(!a.lo_out || (ldo % 8 == 0 && ldo / 2 >= out_off + C3), "sa_mlp_max: CASPR_FEAT_LO_OUT needs out rows of [channels | their low parts] (ldo=%d)", ldo);
     const int K0 = ((C + 3) & ~3) + 3;
     a.L[0] = {w1p, b1, g1, be1, C1, 2 * ((K0 + 31) / 32)};
     a.L[1] = {w2p, b2, g2, be2, C2, 2 * ((C1 + 31) / 32)};
@@ -737,9 +1047,21 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
         else done = false;
         if (done) {
             CASPR_CHECK_LAUNCH("sa_mlp_max(small)");
+            // neighbourhoods of 2..8 distinct samples once more, in f64 (see sa_repair_f64_kernel); debug build: CASPR_SA_REPAIR_K=-1 skips it, 4 stops at 4
+            // (the window of sa_repair_f64_kernel holds first / second layers of <= 32 channels: every shape of this branch)
+            // 5..8 at the FIRST level only (feat_kind set): its outputs are what the second level's small balls amplify; the second
+            // level's own outputs go to the wide levels, whose groups of >= 4 channels do not (tools/sa_repair_sweep.py)
+            const int rk = CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K"), rk1 = CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K1");
+            const dim3 rgrid(ceil_div(M, 64), B);
+            if (rk >= 0) {
+                sa_repair_f64_kernel<2, 4><<<rgrid, dim3(256), 0, st>>>(a, ns);
+                if ((rk == 0 || rk >= 8) && (a.feat_kind != 0 || rk1 >= 8)) sa_repair_f64_kernel<5, 8><<<rgrid, dim3(256), 0, st>>>(a, ns);
+                CASPR_CHECK_LAUNCH("sa_mlp_max(repair)");
+            }
             return CASPR_OK;
         }
     }
+    CASPR_REQUIRE(!a.lo_in && !a.lo_out, "sa_mlp_max: low parts (CASPR_FEAT_LO_IN / _OUT) exist for the register kernel's shapes only (widths <= 64)");
     const int bigK = (K0 > 160) || (C3 > 128);
     const int ncol = bigK ? 32 : 64;
     const size_t shmem = (size_t)(a.rowsA + a.rowsB) * ncol * 16 + (3 * 64 + 16 + 64) * 4 + 64;

@@ -10,7 +10,6 @@ Training: in train() mode with grad enabled `forward` is differentiable end to e
 with a HIP backward (caspr_amd/train/encoder_grad.py), the latent ODE and the CNF through the discrete RK4 map with
 every matrix product on the HIP kernels (caspr_amd/train/flow_grad.py).
 """
-import os
 import weakref
 
 import numpy as np
@@ -18,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..config import config as _cfg
 from .tpointnet2 import TPointNet2
 from .latent_ode_model import LatentODE
 from .flow import get_point_cnf, count_nfe, PointCNFArgs
@@ -27,23 +27,30 @@ from .utils import standard_normal_logprob, sample_gaussian, sphere_surface_poin
 class _EarlyLatent:
     """The latent solve started from inside the encoder's last layer (TPointNet2.forward(early=...)): the ODE's initial state is the
     first `channels` columns of z0 (caspr.py:169), final after that layer's first channel tile; the solve then runs on a side stream
-    on ONE compute unit per 16 sequences (the single-workgroup kernel: 51 us per evaluation, no co-residency requirement) BESIDE the
-    layer's remaining two thirds, instead of 2.3 ms on 32 units in front of the flow with the rest of the chip idle."""
+    BESIDE the layer's remaining two thirds -- on the team kernel with 32 RESERVED compute units per 16 sequences (its LDS-resident
+    weights make it immune to the layer's L2 traffic: 2.65 ms), or, when the team kernel is switched off (ops.LATENT_TEAM = False or
+    config.early_latent_team = False), on the single-workgroup kernel with one reserved unit -- instead of 2.3 ms in front of the flow
+    with the rest of the chip idle.  The kernel is the one every other solve of the process uses (ops.LATENT_TEAM decides both), so a
+    sequence's latent codes do not depend on which path solved them."""
 
     def __init__(self, latent_ode, plan, stream):
         self.latent_ode, self.plan, self.stream = latent_ode, plan, stream
         self.channels = latent_ode.input_size
         self.out, self.event = None, None
 
+    @staticmethod
+    def team():
+        return bool(ops.LATENT_TEAM and EARLY_LATENT_TEAM)
+
     def reserve_cus(self, B):
-        return (32 if EARLY_LATENT_TEAM else 1) * ((B + 15) // 16)
+        return (32 if self.team() else 1) * ((B + 15) // 16)
 
     def __call__(self, z0_partial):
         main = torch.cuda.current_stream()
         self.stream.wait_stream(main)
         with torch.cuda.stream(self.stream):
             z_init = z0_partial[:, :self.channels]
-            out = ops.latent_rk4(z_init, self.plan["sorted_t"], self.latent_ode.rk4_steps, self.latent_ode._weights(), team=EARLY_LATENT_TEAM)
+            out = ops.latent_rk4(z_init, self.plan["sorted_t"], self.latent_ode.rk4_steps, self.latent_ode._weights(), team=self.team())
             # what aggregate_and_solve_latent does with the solution, here too: off the path between the encoder's last kernel and the flow
             self.out = out[self.plan["rows"], self.plan["pos"], :]                      # (B, T, H): the requested stamps
             self.latent_ode.ode_func._num_evals.mul_(0).add_(self.plan["evals"])        # evaluations actually run (an element-wise op, not a blit)
@@ -53,9 +60,9 @@ class _EarlyLatent:
         self.out.record_stream(main)
 
 
-# the latent solve beside the encoder's last layer (CASPR_EARLY_LATENT=0: in front of the flow, as in rounds 1-3; debugging knob)
-EARLY_LATENT = os.environ.get("CASPR_EARLY_LATENT", "1") != "0"
-EARLY_LATENT_TEAM = os.environ.get("CASPR_EARLY_LATENT", "1") != "single"
+# the latent solve beside the encoder's last layer (config.early_latent = False: in front of the flow, as in rounds 1-3)
+EARLY_LATENT = _cfg.early_latent
+EARLY_LATENT_TEAM = _cfg.early_latent_team
 _EARLY_STREAM = {}
 _EARLY_DRAW = {}      # (id(model), device, sample size) -> pinned buffer, copy stream, last copy's event (CaSPR._draw_early)
 
@@ -65,11 +72,41 @@ def _drop_early_draw(owner):
         _EARLY_DRAW.pop(k, None)
 
 
+_GUARD_STREAM = {}
+_UNSET = object()
+
+
+def _guard_stream(device):
+    key = str(device)
+    if key not in _GUARD_STREAM:
+        _GUARD_STREAM[key] = torch.cuda.Stream(device=device)
+    return _GUARD_STREAM[key]
+
+
+def _other_steps(S):
+    """The step count a guarded solve is compared with, and the factor that turns max |x_S - x_other| into the error estimate of the
+    S-step result (RK4, global error ~ C h^4): half the steps when S is even -- x_S/2 - x_S = 15 e_S, estimate = diff / 15 -- else
+    twice -- x_S - x_2S = (15 / 16) e_S, estimate = diff * 16 / 15."""
+    return (S // 2, 1.0 / 15.0) if (S % 2 == 0 and S >= 2) else (2 * S, 16.0 / 15.0)
+
+
 class CaSPR(nn.Module):
     def __init__(self, radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], local_feat_size=512, latent_feat_size=1600,
                  ode_hidden_size=512, motion_feat_size=64, pretrain_tnocs=False, augment_quad=True, augment_pairs=True,
-                 cnf_blocks=1, regress_tnocs=True, *, cnf_rk4_steps=8, latent_rk4_steps=2):
+                 cnf_blocks=1, regress_tnocs=True, *, cnf_rk4_steps=8, latent_rk4_steps=2, check_tol=None, latent_check_tol=None,
+                 check_action="raise", check_points=64):
         super(CaSPR, self).__init__()
+        # Run-time accuracy guard of the fixed-step integrators (off by default).  The reference's dopri5 controls its error at every
+        # call (CNF atol = rtol = 1e-5, flow.py:96-99; latent ODE 1e-3, latent_ode_model.py:38,83); a fixed step count does not.  With
+        # check_tol set, every inference solve (reconstruct / decode / aggregate_and_solve_latent under no_grad) is repeated at half
+        # the step count on `check_points` samples per frame (the latent solve: all of it, on one compute unit) on a side stream, the
+        # results are compared on the device, and the Richardson estimate of the delivered solution's error is examined through
+        # ops.check_deferred_errors() / at the next guarded call: CasprAccuracyError (check_action "raise") or a RuntimeWarning
+        # ("warn") when it exceeds check_tol (latent: latent_check_tol, default 100 x check_tol = the reference's ratio).
+        self.check_tol = check_tol
+        self.latent_check_tol = latent_check_tol
+        self.check_action = check_action
+        self.check_points = check_points
         self.pretrain_tnocs = pretrain_tnocs
         self.augment_quad = augment_quad
         self.augment_pairs = augment_pairs
@@ -180,9 +217,58 @@ class CaSPR(nn.Module):
             pred_z = self.gen_latent(z_init, solve_t)
             batch_inds = torch.arange(B, device=z0.device).view((-1, 1)).repeat((1, T))
             sample_feats = pred_z[batch_inds, time_map, :]
+        if self.check_tol is not None and z0.is_cuda and not self._differentiable(z0, time_tensor):
+            self._guard_latent(z_init, time_tensor, sample_feats, _plan)
         B_global, H_global = z_global.size()
         z_global = z_global.unsqueeze(1).expand(B_global, sample_feats.size()[1], H_global)
         return torch.cat([sample_feats, z_global], dim=2)
+
+    # ------------------------------------------------------------------------------------------ run-time accuracy guard
+    def _guard_latent(self, z_init, time_tensor, sample_feats, plan):
+        """The latent solve once more at half (or twice) the steps per interval, on the single-workgroup kernel (one compute unit,
+        no co-residency requirement: it may run beside anything) on the guard stream; max |z_L - z_L'| over the requested stamps
+        goes to the deferred channel (ops.guard_track).  Nothing on the current stream waits for it."""
+        L = self.latent_ode.rk4_steps
+        L2, factor = _other_steps(L)
+        tol = self.latent_check_tol if self.latent_check_tol is not None else 100.0 * self.check_tol
+        main = torch.cuda.current_stream()
+        gs = _guard_stream(z_init.device)
+        gs.wait_stream(main)
+        with torch.cuda.stream(gs), ops.untimed():
+            if plan is None or plan["shape"] != tuple(time_tensor.shape):
+                plan = self.latent_ode.plan_times(time_tensor)
+            zc = ops.latent_rk4(z_init, plan["sorted_t"], L2, self.latent_ode._weights(), team=False)[plan["rows"], plan["pos"], :]
+            diff = (sample_feats - zc).abs().amax()
+            ops.guard_track(diff, {"name": "latent", "tol": float(tol), "factor": factor, "steps": L, "other_steps": L2, "action": self.check_action,
+                                   "what": "latent ODE (latent_ode_model.py:45-70; reference: dopri5 at rtol = atol = 1e-3)"})
+        for t_ in (z_init, sample_feats, time_tensor):
+            t_.record_stream(gs)
+
+    def _guard_cnf(self, y, z, x):
+        """The point CNF once more on the first `check_points` samples of every frame at half (or twice) the step count, on the guard
+        stream (it needs y and z only, so it runs beside the tail of the main launch); max |x_S - x_S'| goes to the deferred channel."""
+        from .cnf import CNF
+        blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
+        S = blocks[0].rk4_steps
+        S2, factor = _other_steps(S)
+        g = min(int(self.check_points), y.shape[1])
+        main = torch.cuda.current_stream()
+        gs = _guard_stream(y.device)
+        gs.wait_stream(main)
+        saved = [(b, b.rk4_steps) for b in blocks]
+        with torch.cuda.stream(gs), ops.untimed():
+            try:
+                for b in blocks:
+                    b.rk4_steps, b._count_evals = _other_steps(b.rk4_steps)[0], False
+                xh = self.point_cnf(y[:, :g].contiguous(), z, reverse=True)
+            finally:
+                for b, st in saved:
+                    b.rk4_steps, b._count_evals = st, True
+            diff = (x[:, :g] - xh).abs().amax()
+            ops.guard_track(diff, {"name": "cnf", "tol": float(self.check_tol), "factor": factor, "steps": S, "other_steps": S2, "action": self.check_action,
+                                   "what": "point CNF (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"})
+        for t_ in (y, z, x):
+            t_.record_stream(gs)
 
     def gen_latent(self, z0, timestamps):
         """caspr.py:185-196."""
@@ -267,11 +353,20 @@ class CaSPR(nn.Module):
             logp_y = standard_normal_logprob(y).view(B * T, num_points, -1).sum(2)
         z = z.reshape((B * T, H))
         x = self.point_cnf(y, z, reverse=True)
+        if self.check_tol is not None and x.is_cuda and not torch.is_grad_enabled():
+            self._guard_cnf(y, z, x)
         return y.view((B, T, num_points, input_dim)), logp_y.view((B, T, num_points)), x.view((B, T, num_points, input_dim))
 
     def reconstruct(self, x, num_points=1024, constant_in_time=False, timestamps=None, max_timestamp=5.0,
-                    truncate_std=None, sample_contours=None, y=None):
-        """caspr.py:269-308 -> (y, logp_y, x, tnocs_pred).  `y` (B,T,num_points,3) optionally supplies the base samples."""
+                    truncate_std=None, sample_contours=None, y=None, check_tol=_UNSET):
+        """caspr.py:269-308 -> (y, logp_y, x, tnocs_pred).  `y` (B,T,num_points,3) optionally supplies the base samples.
+        check_tol: the accuracy guard's tolerance for THIS call (default: the model's `check_tol` attribute; None = off)."""
+        if check_tol is not _UNSET:
+            prev, self.check_tol = self.check_tol, check_tol
+            try:
+                return self.reconstruct(x, num_points, constant_in_time, timestamps, max_timestamp, truncate_std, sample_contours, y)
+            finally:
+                self.check_tol = prev
         with torch.no_grad():
             B, T, N, _ = x.size()
             if timestamps is None:
@@ -316,7 +411,7 @@ class CaSPR(nn.Module):
     def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16, 32, 64, 128), num_points=512, timestamps=None, max_timestamp=5.0,
                             latent_tol=None, latent_candidates=(1, 2, 4, 8, 16, 32)):
         """Pick the CNF's fixed RK4 step count the way an adaptive solver picks its step: by an error estimate on the
-        actual weights and input.  Decodes the first sequence of `x` with S and 2S steps (same base samples) for each
+        actual weights and input.  Decodes every sequence of `x` with S and 2S steps (same base samples) for each
         candidate S in ascending order and keeps the first S whose step-doubling difference max|x_S - x_2S| (= 15/16 of the
         S-step error for a 4th-order method) is <= tol.  Sets `rk4_steps` on every CNF block; returns (S, {S: difference}) with the
         differences of the candidates that were tried.  With `latent_tol` the latent ODE's steps per interval are chosen FIRST, the
@@ -326,10 +421,17 @@ class CaSPR(nn.Module):
         the defaults of this build (8 steps, 2 per interval) are kept unless this is called."""
         from .cnf import CNF
         blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
+        guard, self.check_tol = self.check_tol, None          # the candidates below are MEANT to be under-resolved: no guard while choosing
+        try:
+            return self._calibrate(blocks, x, tol, candidates, num_points, timestamps, max_timestamp, latent_tol, latent_candidates)
+        finally:
+            self.check_tol = guard
+
+    def _calibrate(self, blocks, x, tol, candidates, num_points, timestamps, max_timestamp, latent_tol, latent_candidates):
         with torch.no_grad():
-            xs = x[:1]
+            xs = x                   # every sequence of x (round 4 looked at the first only: the worst one decides)
             z0, _ = self.encode(xs)
-            times = xs[:, :, 0, 3] / max_timestamp if timestamps is None else timestamps.view(1, -1).to(xs)
+            times = xs[:, :, 0, 3] / max_timestamp if timestamps is None else timestamps.view(1, -1).repeat(xs.shape[0], 1).to(xs)
             lat = None
             if latent_tol is not None:
                 zs, ldiffs, lchosen = {}, {}, max(latent_candidates)
@@ -347,7 +449,7 @@ class CaSPR(nn.Module):
                 self.latent_ode.rk4_steps = lchosen
                 lat = (lchosen, ldiffs)
             z = self.aggregate_and_solve_latent(z0, times)
-            y = torch.randn(1, z.shape[1], num_points, self.cnf_args.input_dim, device=x.device)
+            y = torch.randn(z.shape[0], z.shape[1], num_points, self.cnf_args.input_dim, device=x.device)
             sols, diffs, chosen = {}, {}, max(candidates)
 
             def sol(S):

@@ -35,6 +35,7 @@ class CNF(nn.Module):
         self.solver_options = {}
         self.conditional = conditional
         self.rk4_steps = rk4_steps
+        self._count_evals = True      # False while the accuracy guard repeats a solve (CaSPR._guard_cnf): get_nfe() counts the real one only
         self._cache = WeightCache()
 
     def _weights(self):
@@ -98,7 +99,8 @@ class CNF(nn.Module):
         res = ops.cnf_rk4(x.contiguous(), hyper, w["tcol"], w["w0"], w["b0"], w["w1p"], w["b1"], w["w2p"], w["b2"], w["w3"], w["b3"],
                           self.end_time(), self.rk4_steps, reverse, mbn_in, mbn_out, e=e,
                           logp=None if logpx is None else logpx.contiguous(), w1x=w1x, w2x=w2x)
-        self.odefunc._num_evals += 4 * self.rk4_steps
+        if self._count_evals:
+            self.odefunc._num_evals += 4 * self.rk4_steps
         return res
 
     def forward(self, x, context=None, logpx=None, integration_times=None, reverse=False):

@@ -8,6 +8,7 @@ folded into the consumer's operand load (`Lazy`).
 Internally everything is point-major (B, P, C); the sub-module `forward`s keep the reference's
 channels-first signatures by transposing at the boundary.
 """
+import contextlib
 from typing import Iterable
 
 import torch
@@ -15,10 +16,21 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..config import config as _cfg
 from ..utils.weight_cache import WeightCache
 from .lazy import Lazy
 
 NUM_GROUPS = 16  # for group norm (pointnet2.py:12)
+LO_PARTS = _cfg.sa_lo_parts  # the first set-abstraction level hands its output to the second as an unevaluated sum hi + lo (PointNet2feat.run)
+SCALE_STREAMS = _cfg.sa_scale_streams  # the two scales of a set-abstraction level on two streams (PointNet2SetAbstraction.run)
+_SCALE_STREAM = {}
+
+
+def _scale_stream(device):
+    key = (device.type, device.index)
+    if key not in _SCALE_STREAM:
+        _SCALE_STREAM[key] = torch.cuda.Stream(device=device)
+    return _SCALE_STREAM[key]
 
 
 def separate_xyz_and_features(points):
@@ -196,9 +208,15 @@ class PointNet2SetAbstraction(nn.Module):
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def run(self, xyz, feat, C, record=None, idx=None, feat_kind=0):
+    def narrow(self):
+        """All point MLPs of this level run on the register kernel (every width <= 64): the shapes that can exchange low parts."""
+        return all(max(d) <= 64 for d in self.pointnet_layer_dims_list)
+
+    def run(self, xyz, feat, C, record=None, idx=None, feat_kind=0, lo_in=False, lo_out=False):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels (or None).
-        -> new_xyz (B,M,3), new_feat (B,M,Cout).  `idx` = precomputed self.indices(xyz); feat_kind: see ops.sa_mlp_max."""
+        -> new_xyz (B,M,3), new_feat (B,M,Cout).  `idx` = precomputed self.indices(xyz); feat_kind: see ops.sa_mlp_max.
+        lo_out: new_feat is (B,M,2 Cout) = [features | their low parts] (ops.FEAT_LO_OUT: what the f32 value lacks of the kernel's f64
+        result); lo_in: `feat` is such a tensor of the previous level, C its feature count (ops.FEAT_LO_IN).  narrow() levels only."""
         B = xyz.shape[0]
         M = self.num_points_out
         if idx is None:
@@ -206,18 +224,32 @@ class PointNet2SetAbstraction(nn.Module):
         if "scale_ready" not in idx:
             self._await(idx)
         new_xyz = idx["new_xyz"]
-        out = torch.empty(B, M, self.get_num_features_out(), device=xyz.device, dtype=torch.float32)
+        if (lo_in or lo_out) and not self.narrow():
+            raise ValueError("low parts are exchanged by the register set-abstraction kernel only (all widths <= 64)")
+        feat_kind = feat_kind | (ops.FEAT_LO_IN if lo_in else 0) | (ops.FEAT_LO_OUT if lo_out else 0)
+        out = torch.empty(B, M, self.get_num_features_out() * (2 if lo_out else 1), device=xyz.device, dtype=torch.float32)
+        # The scales of a level are independent (they read the same input and write disjoint column ranges of `out`): the LAST one
+        # is issued on a second stream, so that one scale's latency-bound phases (GroupNorm / max chains, the f64 re-evaluation of
+        # small balls on the vector pipe) run beside the other's MFMAs; joined before the level returns.
+        main = torch.cuda.current_stream()
+        side = None
+        if SCALE_STREAMS and xyz.is_cuda and len(self.layers) > 1 and not torch.cuda.is_current_stream_capturing():
+            side = _scale_stream(xyz.device)
+            side.wait_stream(main)
         off = 0
         for i, ns in enumerate(self.layers):
-            if "scale_ready" in idx:
-                self._await(idx, i)
-            if ops.CONV_BF16X6 and C + 3 >= ROWS_MIN_CIN and (M * ns) % 128 == 0:
-                self._run_rows(xyz, new_xyz, feat, C, idx["ball_idx"][i], i, out, off)
-                off += self.pointnet_layer_dims_list[i][-1]
-                continue
-            ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off,
-                           feat_kind=feat_kind)  # :391-409
+            on_side = side is not None and i == len(self.layers) - 1
+            with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
+                if "scale_ready" in idx:
+                    self._await(idx, i)
+                if ops.CONV_BF16X6 and C + 3 >= ROWS_MIN_CIN and (M * ns) % 128 == 0:
+                    self._run_rows(xyz, new_xyz, feat, C, idx["ball_idx"][i], i, out, off)
+                else:
+                    ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off,
+                                   feat_kind=feat_kind)  # :391-409
             off += self.pointnet_layer_dims_list[i][-1]
+        if side is not None:
+            main.wait_stream(side)
         if record is not None:
             record.append(idx)
         return new_xyz, out
@@ -397,11 +429,18 @@ class PointNet2feat(nn.Module):
         if idx is None:
             idx = self.indices(xyz)
         xyz_list, feat_list, ch_list = [xyz], [feat], [C]
-        for l, sa in enumerate(self.set_abstractions):                                          # pointnet2.py:232
-            xyz, feat = sa.run(xyz, feat, C, record, idx["sa"][l], feat_kind=feat_kind if l == 0 else 0)
-            C = feat.shape[2]
+        # the first level hands its output to the second as hi + lo (both run on the register kernel, whose f64 reference column and f64
+        # re-evaluation of small balls would otherwise start from f32-rounded inputs: DESIGN.md section 5, round 5); everything else
+        # reads the hi half through a strided view
+        sas = self.set_abstractions
+        lo_from = [l + 1 < len(sas) and sas[l].narrow() and sas[l + 1].narrow() and LO_PARTS and l == 0 for l in range(len(sas))]
+        for l, sa in enumerate(sas):                                                            # pointnet2.py:232
+            lo_in = l > 0 and lo_from[l - 1]
+            with ops.timed("enc_set_abstraction"):       # wall time of the level on the main stream (its scales overlap on two streams)
+                xyz, feat = sa.run(xyz, feat, C, record, idx["sa"][l], feat_kind=feat_kind if l == 0 else 0, lo_in=lo_in, lo_out=lo_from[l])
+            C = sa.get_num_features_out()
             xyz_list.append(xyz)
-            feat_list.append(feat)
+            feat_list.append(feat[:, :, :C] if lo_from[l] else feat)                           # consumers other than the next level: hi only
             ch_list.append(C)
         prev = Lazy(feat_list[-1], ch_list[-1])
         target = -2

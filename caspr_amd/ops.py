@@ -9,11 +9,11 @@ Layouts: activations are point-major (B, P, C) float32 with row stride = last-di
 leading-dimension is given; index tensors are int32.
 """
 import ctypes
-import os
 
 import torch
 
 from . import lib as _lib
+from .config import config as _cfg
 
 
 # Optional stage timing with HIP events recorded on the launch stream (bench.py's roofline numbers).
@@ -44,6 +44,20 @@ class timed:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record(torch.cuda.current_stream())
             TIMERS.setdefault(self.name, []).append((self.t0, t1))
+        return False
+
+
+class untimed:
+    """with ops.untimed(): ...  -> no timer records inside (the accuracy guard's check solves must not enter bench.py's per-kernel means)."""
+
+    def __enter__(self):
+        global TIMING
+        self.prev, TIMING = TIMING, False
+        return self
+
+    def __exit__(self, *exc):
+        global TIMING
+        TIMING = self.prev
         return False
 
 
@@ -201,11 +215,9 @@ def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale
 # Shapes the bf16x6 kernels do not cover (Cin < 192 or not a multiple of 32, fewer than 128 rows per batch entry, the
 # set-abstraction MLPs, the latent ODE) run on the f32 MFMA kernels in either mode.  CASPR_MATMUL=f32 selects the f32
 # kernels at import; set_matmul_mode() switches at run time (bench.py times both in one process).
-_mode = os.environ.get("CASPR_MATMUL", "bf16x6").strip().lower()
-if _mode not in ("bf16x6", "f32"):
-    raise ValueError("CASPR_MATMUL must be 'bf16x6' or 'f32', got %r" % _mode)
+_mode = _cfg.matmul            # caspr_amd/config.py (the environment only under CASPR_DEBUG=1)
 CONV_BF16X6 = _mode == "bf16x6"      # pointwise convs (conv1x1) on the bf16x6 kernel where the shape allows
-CONV_X6W = os.environ.get("CASPR_CONV_X6W", "1") != "0"     # ... and the layers with >= 512 output channels on the 512-channel kernel
+CONV_X6W = _cfg.conv_x6w             # ... and the layers with >= 512 output channels on the 512-channel kernel
 CNF_BF16X6 = _mode == "bf16x6"       # point-CNF solves on the bf16x6 kernel
 _X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstraction / input layers)
 # the 512-channel kernel (gemm_bf16x6w.hip) from this many input channels.  Round 3: 1024 (one workgroup per tile, prologue / epilogue
@@ -213,8 +225,8 @@ _X6_MIN_CIN = 192     # below this the f32 LDS kernel is used anyway (set-abstra
 # epilogue shorter (6.8 vs 7.07 ms on the head layer), so the layers with >= 512 output channels, >= 512 input channels and >= 1024 rows
 # per batch entry (_X6W_MIN_ROWS: the coarse levels -- 640 tiles at cfg-2 -- quantise badly onto a persistent grid of 256 workgroups) take it:
 # in-step at cfg-2 576 -> 1600: 3.40 -> 3.24 ms, 512 -> 512: 0.92 -> 0.87, 544 -> 512: 0.89 -> 0.84; the 128 -> 1024 layer (4 k-chunks per
-# tile) and the 81,920-row levels are faster on the 256-channel kernel.  (CASPR_X6W_MIN_CIN: debugging knob of the Python host)
-_X6W_MIN_CIN = int(os.environ.get("CASPR_X6W_MIN_CIN", "512"))
+# tile) and the 81,920-row levels are faster on the 256-channel kernel.  (config.x6w_min_cin)
+_X6W_MIN_CIN = _cfg.x6w_min_cin
 _X6W_MIN_ROWS = 1024
 _X6_GN_MIN_CIN = 64   # conv + GroupNorm statistics in one pass (conv1x1_gn): pays from a smaller width (no second pass over the output)
 
@@ -499,17 +511,19 @@ def conv1x1_gn_early(pw, bias, x, gamma, beta, on_early, groups=16, eps=1e-5, in
         finalize(0, 1)
         on_early(pmax)
         part(1, mt_all, True, reserve_cus)
-        finalize(0, groups)
+        finalize(1, groups)         # group 0 is final already (and the side stream may be reading its pmax / scale / shift right now)
     return y, scale, shift, pmax
 
 
-FEAT_QUAD, FEAT_PAIRS = 1, 2     # include/caspr_hip.h
+FEAT_QUAD, FEAT_PAIRS, FEAT_LO_IN, FEAT_LO_OUT = 1, 2, 4, 8     # include/caspr_hip.h
 
 
 def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0):
     """Fused grouper + 3-layer point MLP + GroupNorm + max (pointnet2.py:391-409,649-703).
     feat (B,n,ldf) point-major with C valid channels; layers = 3 x (PackedWeight, bias, gamma, beta).
-    feat_kind: FEAT_QUAD | FEAT_PAIRS when feat is prep_input's quadratic augmentation of xyz (first level)."""
+    feat_kind: FEAT_QUAD | FEAT_PAIRS when feat is prep_input's quadratic augmentation of xyz (first level); FEAT_LO_OUT: `out` rows are
+    [channels | their low parts] (the second half of the row receives what the f32 output lacks of the kernel's f64 result); FEAT_LO_IN:
+    `feat` rows are [C channels .. | low parts from column ldf / 2] as a FEAT_LO_OUT call wrote them (include/caspr_hip.h)."""
     _chk_f32(xyz, new_xyz, feat, out)
     _chk_i32(idx)
     B, n, _ = xyz.shape
@@ -527,7 +541,7 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0):
     return out
 
 
-LATENT_TEAM = os.environ.get("CASPR_LATENT_TEAM", "1") != "0"   # multi-workgroup latent ODE kernel (0: single-workgroup kernel)
+LATENT_TEAM = _cfg.latent_team   # multi-workgroup latent ODE kernel (False: single-workgroup kernel)
 _team_ws = {}
 
 
@@ -569,15 +583,85 @@ def _team_raise_if_failed(key, wait=False):
         _team_pool.append(host)
     if failed:
         raise _lib.CasprHipError("caspr_latent_rk4_team_f32: a team barrier gave up (the 32 x ceil(B/16) workgroups were not co-resident "
-                                 "within the spin bound); the solve's output was poisoned with NaN.  Set CASPR_LATENT_TEAM=0 to use the "
+                                 "within the spin bound); the solve's output was poisoned with NaN.  Set caspr_amd.ops.LATENT_TEAM = False "
+                                 "(config.latent_team; it also takes the early solve of reconstruct() off the team kernel) to use the "
                                  "single-workgroup kernel when other streams / processes saturate the GPU")
 
 
 def check_deferred_errors(wait=True):
-    """Raise CasprHipError if an earlier asynchronous kernel reported a failure (today: the latent team kernel's barrier).
-    wait=True blocks until the status words of every outstanding solve have arrived."""
+    """Raise CasprHipError if an earlier asynchronous kernel reported a failure (the latent team kernel's barrier), or
+    CasprAccuracyError / warn if a run-time accuracy check of the fixed-step integrators came back above its tolerance
+    (guard_track).  wait=True blocks until the status words of every outstanding solve / check have arrived."""
     for key in list(_team_status):
         _team_raise_if_failed(key, wait=wait)
+    _guard_drain(wait=wait)
+
+
+# ---------------------------------------------------------------------------------------------
+# Run-time accuracy guard of the fixed-step integrators (models/caspr.py: CaSPR.check_tol).  The reference's dopri5 bounds its
+# integration error at every call (flow.py:96-99, cnf.py:100-119, latent_ode_model.py:38,83); a fixed step count does not.  With the
+# guard on, every solve is repeated on a subsample at half (or twice) the step count on a side stream, the two results are compared
+# ON THE DEVICE, and the maximum difference travels to pinned host memory behind the comparison -- the same deferred channel as the
+# team kernel's error word: no host synchronisation in the path; the verdict is read at the next guarded call or by
+# check_deferred_errors().
+# ---------------------------------------------------------------------------------------------
+class CasprAccuracyError(_lib.CasprHipError):
+    """A guarded RK4 solve whose step-halving error estimate exceeds the tolerance asked for (CaSPR.check_tol)."""
+
+
+_guard_ring = []         # [(pinned host tensor, event, meta)], oldest first
+_guard_pool = []
+GUARD_LAST = {}          # name -> the last drained record {"diff", "estimate", "tol", "steps", "other_steps", "ok"}
+GUARD_HISTORY_MAX = 0.0  # largest estimate / tol ratio seen since reset_guard()
+
+
+def reset_guard():
+    global GUARD_HISTORY_MAX
+    GUARD_LAST.clear()
+    GUARD_HISTORY_MAX = 0.0
+
+
+def guard_track(diff, meta):
+    """diff: 0-dim float32 device tensor = max |x_S - x_S'| of a check (on the CURRENT stream); meta: {"name", "tol", "factor",
+    "steps", "other_steps", "action", "what"} -- estimate = factor * diff is compared with tol when the copy has arrived."""
+    if len(_guard_ring) >= 64:                      # nobody drained for 64 checks: bound the backlog (blocks on the oldest)
+        _guard_ring[0][1].synchronize()
+    _guard_drain(wait=False)
+    host = _guard_pool.pop() if _guard_pool else torch.zeros(1, dtype=torch.float32).pin_memory()
+    host.copy_(diff.reshape(1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _guard_ring.append((host, ev, meta))
+
+
+def _guard_drain(wait=False):
+    import math
+    import warnings
+    global GUARD_HISTORY_MAX
+    failed = []
+    while _guard_ring:
+        host, ev, meta = _guard_ring[0]
+        if wait:
+            ev.synchronize()
+        if not ev.query():
+            break
+        _guard_ring.pop(0)
+        d = float(host[0])
+        _guard_pool.append(host)
+        est = meta["factor"] * d
+        ok = math.isfinite(est) and est <= meta["tol"]
+        GUARD_LAST[meta["name"]] = {"diff": d, "estimate": est, "tol": meta["tol"], "steps": meta["steps"], "other_steps": meta["other_steps"], "ok": ok}
+        GUARD_HISTORY_MAX = max(GUARD_HISTORY_MAX, est / meta["tol"] if math.isfinite(est) else float("inf"))
+        if not ok:
+            msg = ("%s: RK4 with %d steps is not converged to the tolerance asked for: max |x_%d - x_%d| = %.3e on the checked subsample -> "
+                   "error estimate %.3e > check_tol %.1e.  Raise the step count (CaSPR.calibrate_rk4_steps picks it by step doubling) or "
+                   "the tolerance." % (meta["what"], meta["steps"], meta["steps"], meta["other_steps"], d, est, meta["tol"]))
+            if meta["action"] == "warn":
+                warnings.warn(msg, RuntimeWarning, stacklevel=3)
+            else:
+                failed.append(msg)
+    if failed:
+        raise CasprAccuracyError("; ".join(failed))
 
 
 def _team_track(key, ws, B):

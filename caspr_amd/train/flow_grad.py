@@ -583,9 +583,10 @@ def latent_solve_layers(lat, z0, times):
     return torch.stack(outs, dim=1)
 
 
-OUT_NODE = __import__("os").environ.get("CASPR_CNF_OUT_NODE", "1") != "0"      # 0: the output layer's epilogue in torch element-wise ops
-HIDDEN_NODE = __import__("os").environ.get("CASPR_CNF_NODE", "1") != "0"      # 0: CnfLayer + CnfLayerOut (A/B timing, debugging)
-LATENT_NODE = __import__("os").environ.get("CASPR_LATENT_NODE", "1") != "0"     # 0: the per-layer form (A/B timing, debugging)
+from ..config import config as _cfg     # (A/B timing and debugging switches: caspr_amd/config.py, environment only under CASPR_DEBUG=1)
+OUT_NODE = _cfg.train_cnf_out_node          # False: the output layer's epilogue in torch element-wise ops
+HIDDEN_NODE = _cfg.train_cnf_hidden_node    # False: CnfLayer + CnfLayerOut
+LATENT_NODE = _cfg.train_latent_node        # False: the per-layer form
 
 
 def latent_solve_train(lat, z0, times):

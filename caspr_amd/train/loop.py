@@ -6,7 +6,7 @@ mean(L1 tnocs) (train_utils.py:151-165), Adam, periodic checkpoints `time_model_
 
 Multi-GPU: instead of nn.DataParallel (one process, scatter/gather, train.py:131-132) each rank owns a
 contiguous block of the batch's sequences; the only collective is ONE all-reduce (RCCL over xGMI on the GPU box) of a
-flat bucket holding every gradient, after which each rank applies the same Adam step.  The bucket carries each rank's
+flat bucket holding every gradient (and one touched-flag per parameter), after which each rank applies the same Adam step.  The bucket carries each rank's
 gradient of its LOCAL mean weighted by its shard size (plus the shard size itself in one extra slot), so the reduced
 gradient is the gradient of the reference's mean over the GLOBAL batch (train_utils.py:154,163) for any split --
 including a rank whose shard is empty (a last batch shorter than the world size): it contributes zeros, still enters
@@ -57,18 +57,33 @@ class GradBucket:
         self.views = None
         # Which parameters the loss reaches.  With .grad bound to a zeroed view EVERY parameter has a gradient tensor, also the
         # ones no loss term touches; the reference (optimizer.zero_grad(): set_to_none) leaves those at None and Adam skips them
-        # -- no state, no weight decay.  A post-accumulate hook marks the parameters autograd wrote to; drop_untouched() gives the
-        # others their None back before the optimizer step.  The set is a property of the model configuration, so it is
-        # agreed between the ranks ONCE (one small collective, at the first step) and re-checked locally afterwards.
+        # -- no state, no weight decay.  A post-accumulate hook marks the parameters autograd wrote to THIS step; the marks ride in
+        # the gradient all-reduce itself (one flag per parameter behind the gradients: SUM > 0 = some rank's loss reached it), so
+        # the decision is collective by construction -- every rank enters the same ONE collective every step, whatever its local
+        # marks are (a rank without data, a loss-weight schedule that switches a term on later, layers unfrozen mid-run) -- and it
+        # is taken per step, like the reference's zero_grad(): a parameter touched once is NOT kept alive afterwards.
         self._touched = set()
-        self._mask = None
+        self._mask = None          # the reduced flags of the last all_reduce_mean (None: no collective ran -> the local marks decide)
         self._hooks = [p.register_post_accumulate_grad_hook(lambda t, i=i: self._touched.add(i)) for i, p in enumerate(self.params)]
 
+    def close(self):
+        """Remove the hooks (a second GradBucket on the same model would otherwise stack its own on top of these)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def attach(self):
-        """(Re)bind every .grad to its slice of the flat buffer; gradient values already present are kept."""
+        """(Re)bind every .grad to its slice of the flat buffer; gradient values already present are kept.
+        Layout: [gradients (sum of sizes) | one touched-flag per parameter | this rank's weight]."""
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(sum(self.sizes) + 1, device=dev, dtype=torch.float32)   # last slot: this rank's weight
+            self.flat = torch.zeros(sum(self.sizes) + len(self.params) + 1, device=dev, dtype=torch.float32)
             self.views, off = [], 0
             for p, n in zip(self.params, self.sizes):
                 self.views.append(self.flat[off:off + n].view_as(p))
@@ -87,38 +102,41 @@ class GradBucket:
         self.attach()
         self.flat.zero_()
         self._touched.clear()
+        self._mask = None
 
     def drop_untouched(self):
-        """After backward (and the all-reduce): parameters no rank's loss reached get .grad = None, as in the reference, so that
-        the optimizer skips them (zero() re-binds the views).  A rank without data this step contributes nothing to the set."""
-        local = torch.zeros(len(self.params), dtype=torch.float32)
-        local[list(self._touched)] = 1.0
-        if self._mask is None or bool((local > self._mask).any()):
-            mask = local.clone()
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                m = mask.to(self.params[0].device)
-                dist.all_reduce(m, op=dist.ReduceOp.MAX)
-                mask = m.cpu()
-            self._mask = mask if self._mask is None else torch.maximum(self._mask, mask)
-        for p, keep in zip(self.params, self._mask.tolist()):
-            if not keep:
+        """After backward (and the all-reduce): parameters no rank's loss reached THIS step get .grad = None, as in the reference, so
+        that the optimizer skips them (zero() re-binds the views).  No collective here: with several ranks the flags were reduced
+        inside all_reduce_mean; alone, the local marks are the answer."""
+        if self._mask is not None:
+            keep = self._mask
+        else:
+            keep = [i in self._touched for i in range(len(self.params))]
+        for p, k in zip(self.params, keep):
+            if not k:
                 p.grad = None
 
     def all_reduce_mean(self, weight=1.0):
         """Weighted average of the gradients over the ranks: sum_r weight_r * grad_r / sum_r weight_r, with weight = the
         number of sequences behind this rank's (mean-reduced) loss; weight 0 = a rank without data (its gradients are
-        taken as zero whatever .grad holds).  ONE collective, in place on the gradients.  No-op without an initialised
-        process group."""
+        taken as zero whatever .grad holds).  ONE collective, in place on the gradients, carrying the touched-flags too (every
+        rank enters it every step).  No-op without an initialised process group."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         flat = self.attach()
+        ng, npar = sum(self.sizes), len(self.params)
         if weight == 0:
             flat.zero_()
         else:
-            flat[:-1].mul_(float(weight))
+            flat[:ng].mul_(float(weight))
+            flags = torch.zeros(npar, dtype=torch.float32)
+            if self._touched:
+                flags[sorted(self._touched)] = 1.0
+            flat[ng:ng + npar].copy_(flags, non_blocking=True)
             flat[-1] = float(weight)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat[:-1].div_(flat[-1].clamp_min(1e-30))
+        flat[:ng].div_(flat[-1].clamp_min(1e-30))
+        self._mask = (flat[ng:ng + npar] > 0).cpu().tolist()
 
 
 def broadcast_model(model, src=0):

@@ -12,8 +12,17 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _coll_device(device):
+    """Where the small bookkeeping collectives of this module run: on `device` under RCCL ("nccl"), on the host under gloo (whose
+    all_gather does not take device tensors; bench.py --share-gpu and the CPU tests)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device
+
+
 def max_over_ranks(value, device):
     """Max of a python float over all ranks (used for the bench's max-over-ranks step time)."""
+    device = _coll_device(device)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -21,6 +30,7 @@ def max_over_ranks(value, device):
 
 
 def sum_over_ranks(value, device):
+    device = _coll_device(device)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -42,6 +52,7 @@ def gather_sharded(local, total, rank, world):
 
 def per_rank_values(value, device):
     """Every rank's python float, in rank order (self-diagnosing multi-GPU bench lines: which rank was the slow one)."""
+    device = _coll_device(device)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if not (dist.is_available() and dist.is_initialized()):
         return [float(value)]

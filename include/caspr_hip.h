@@ -79,6 +79,16 @@ int caspr_group_points_f32(const float *xyz, const float *new_xyz, const float *
  *   from the difference of two rounded squares -- same function, closer to its exact value.                       */
 #define CASPR_FEAT_QUAD 1
 #define CASPR_FEAT_PAIRS 2
+/* Low parts (round 5; the register kernel's shapes only: all three widths <= 64).  A ball that holds ONE point yields the GroupNorm
+ * chain of that point's features alone, and a group of two channels that differ by ~1e-4 multiplies the f32 ROUNDING OF THE INPUT
+ * by up to 1 / (2 sqrt(eps)) = 158; so a level may hand its output to the next one as an unevaluated sum hi + lo:
+ *   CASPR_FEAT_LO_OUT: out rows are [channels (ldo / 2) | their low parts (ldo / 2)]; out[.., ldo / 2 + out_off + c] receives what
+ *     the f32 value lacks of the kernel's internal f64 result (meaningful where that result is f64: balls of <= 4 distinct points);
+ *   CASPR_FEAT_LO_IN: feat rows are [C channels .. | low parts at column ldf / 2 ..]; the f64 reference column and the f64
+ *     re-evaluation of small balls read hi + lo (the MFMA's deviation columns read hi).  Not with QUAD / PAIRS (those take the exact
+ *     f64 products of the coordinates for the same purpose).                                                                        */
+#define CASPR_FEAT_LO_IN 4
+#define CASPR_FEAT_LO_OUT 8
 int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
                          const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind,
                          const float *w1p, const float *b1, const float *g1, const float *be1, int C1,

@@ -254,6 +254,111 @@ def test_two_ranks_with_different_seeds_train_identical_replicas_gloo(tmp_path):
     assert out.returncode == 0 and "SEED_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+ORACLE_WORKER = r'''
+import os, sys, torch, torch.nn as nn, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import model as O
+from caspr_amd.models import CaSPR
+from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences
+from caspr_amd.train.loop import GradBucket, training_loss, shard_batch
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.set_num_threads(3)
+
+
+class OracleCaSPR(nn.Module):
+    """CaSPR's FULL parameter surface (the 238 state-dict keys of caspr.py, aliases and buffers included) with the CPU oracle's
+    differentiable mode as its forward: what the sharded step sees on the GPU box, minus the kernels."""
+    def __init__(self, sd):
+        super().__init__()
+        self.keys = [k for k, v in sd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "_num_evals", "step"))]
+        self.fixed = {k: v for k, v in sd.items() if k not in self.keys}
+        self.plist = nn.ParameterList([nn.Parameter(sd[k].clone()) for k in self.keys])
+
+    def forward(self, x, sp, e=None):
+        # f32 parameters, f64 arithmetic: on these sparse clouds an f32 forward flips ReLU / max-pool selections with the batch size
+        # (1e-2 of the gradient, DESIGN.md section 7), which is not what this test is about
+        sd = {k: (v.double() if v.is_floating_point() else v) for k, v in self.fixed.items()}
+        sd.update({k: p.double() for k, p in zip(self.keys, self.plist)})
+        prev, O.GRAD_MODE = O.GRAD_MODE, True
+        try:
+            r, t = O.forward_nll(sd, x.double(), sp.double(), e.double(), "rk4", 2, 1)
+            return r.float(), t.float()
+        finally:
+            O.GRAD_MODE = prev
+
+
+sd = seeded_state_dict(CaSPR().state_dict(), 0)
+B, T, N = 2, 2, 96
+x, sp = car_sequences(B, T, N, seed=21)
+torch.manual_seed(4)
+e = torch.randn(B * T, N, 3)
+
+def grads(xs, sps, es, weight=None):
+    m = OracleCaSPR(sd)
+    bucket = GradBucket(m.parameters()) if weight is not None else None
+    if bucket is not None:
+        bucket.zero()
+    loss, _, _ = training_loss(m(xs, sps, e=es), 0.01, 100.0)
+    loss.backward()
+    if bucket is not None:
+        bucket.all_reduce_mean(weight=weight)
+        bucket.drop_untouched()
+    return {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in zip(m.keys, m.plist)}
+
+full = grads(x, sp, e)                                  # one process: the whole batch
+xs, sps = shard_batch(x, sp)
+lo = rank * (B // world)
+mine = grads(xs, sps, e[lo * T:(lo + xs.shape[0]) * T], weight=xs.shape[0])
+num = den = 0.0
+untouched = 0
+for k, g in full.items():
+    h = mine[k]
+    assert (g is None) == (h is None), "parameter %s: touched in one run only" % k
+    if g is None:
+        untouched += 1
+        continue
+    num += float((g.double() - h.double()).pow(2).sum())
+    den += float(g.double().pow(2).sum())
+rel = (num / den) ** 0.5
+assert rel <= 1e-4, "rank %d: |sharded - global| / |global| = %.3e" % (rank, rel)
+assert untouched >= 8, "the aliases latent_ode.solver.ode_func.* are parameters no loss term reaches: %d untouched" % untouched
+dist.barrier()
+if rank == 0:
+    print("ORACLE_RANKS_OK rel=%.3e untouched=%d" % (rel, untouched))
+'''
+
+
+def test_two_rank_train_step_full_parameter_surface_gloo(tmp_path):
+    """CPU twin of tests/test_multi_gpu.py::test_two_rank_train_step_of_the_real_model: CaSPR's full parameter surface with the
+    CPU oracle's differentiable mode as the forward, one sequence per rank, backward + ONE flat all-reduce carrying gradients and
+    touched-flags -- against the one-process gradient of the two-sequence batch; parameters no loss term reaches (the solver.*
+    aliases) end with grad None on every rank."""
+    script = tmp_path / "oracle_worker.py"
+    script.write_text(ORACLE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29538", str(script), ROOT], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "ORACLE_RANKS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_config_reads_the_environment_only_in_debug_mode():
+    """Round-4 review: ten A/B switches were read from the environment at import; a stray CASPR_MATMUL=f32 silently changed
+    kernels.  Now: defaults unless CASPR_DEBUG=1, and a knob found without it is reported, not obeyed."""
+    import warnings
+    from caspr_amd import config as C
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        c = C.load({"CASPR_MATMUL": "f32", "CASPR_LATENT_TEAM": "0"})
+    assert c == C.KernelConfig() and any("ignored" in str(x.message) for x in w)
+    c = C.load({"CASPR_DEBUG": "1", "CASPR_MATMUL": "f32", "CASPR_LATENT_TEAM": "0", "CASPR_EARLY_LATENT": "single", "CASPR_X6W_MIN_CIN": "1024"})
+    assert (c.matmul, c.latent_team, c.early_latent, c.early_latent_team, c.x6w_min_cin) == ("f32", False, True, False, 1024)
+    with pytest.raises(ValueError):
+        C.load({"CASPR_DEBUG": "1", "CASPR_MATMUL": "bf16"})
+    a = C.active()
+    assert a["matmul"] == {"conv": "bf16x6", "cnf": "bf16x6"} and a["debug_env"] is False and a["sa_lo_parts"] is True
+
+
 LAUNCH_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
