@@ -389,7 +389,24 @@ def sub_blocks(args, dev, ops, timed_steps, x_headline, ts_headline):
                          "steps": targs.steps, "warmup": targs.warmup, "ms_per_step": round(tms, 3), "value": round(8 * targs.steps / tm["elapsed"], 3),
                          "unit": "sequences/sec", "roofline": troof, "loss_first": tm["losses"][0], "loss_last": tm["losses"][-1],
                          "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    first_loss = tm["losses"][0]
     del tm
+    torch.cuda.empty_cache()
+    # the same step with the CNF's tape kept per RK4 step and recomputed in the backward pass (config.train_cnf_checkpoint; the
+    # reference's adjoint is O(1) memory too, cnf.py:100): what the memory costs in time
+    from caspr_amd.train import flow_grad
+    targs2 = types.SimpleNamespace(batch=8, seq_len=10, num_pts=1024, cnf_steps=8, latent_steps=2, mode="full", steps=2, warmup=1)
+    prev_ck, flow_grad.CHECKPOINT_STEPS = flow_grad.CHECKPOINT_STEPS, True
+    try:
+        torch.cuda.reset_peak_memory_stats()
+        tm2 = bench_train.measure(targs2, dev, 0, 1)
+        out["train_cfg3"]["checkpointed_steps"] = {"ms_per_step": round(1e3 * tm2["elapsed"] / targs2.steps, 3),
+                                                   "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                                                   "loss_first_identical": bool(tm2["losses"][0] == first_loss),
+                                                   "what": "caspr_amd.config.train_cnf_checkpoint = True: state per RK4 step only, the step's four evaluations recomputed in the backward pass"}
+        del tm2
+    finally:
+        flow_grad.CHECKPOINT_STEPS = prev_ck
     torch.cuda.empty_cache()
 
     # ---- stress dynamics: the headline workload on weights whose flow is HARD to integrate (synthetic.stress_state_dict); the step

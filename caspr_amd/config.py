@@ -24,6 +24,8 @@ class KernelConfig:
     train_cnf_out_node: bool = True     # training: the ODE function's output epilogue as one node (train/flow_grad.py)
     train_cnf_hidden_node: bool = True  # training: the hidden layers with the activation backward in the data-gradient conv
     train_latent_node: bool = True      # training: the latent solve as one autograd node (team tape + team adjoint)
+    train_cnf_checkpoint: bool = False  # training: keep the CNF's state per RK4 step only, recompute the step in the backward pass
+                                        # (63 GB -> ~1/8 of tape at the cfg-3 shard for one more forward of the block)
 
 
 # environment name -> (field, parser); read only under CASPR_DEBUG=1
@@ -38,6 +40,7 @@ _ENV = {
     "CASPR_CNF_OUT_NODE": ("train_cnf_out_node", lambda v: v != "0"),
     "CASPR_CNF_NODE": ("train_cnf_hidden_node", lambda v: v != "0"),
     "CASPR_LATENT_NODE": ("train_latent_node", lambda v: v != "0"),
+    "CASPR_CNF_CHECKPOINT": ("train_cnf_checkpoint", lambda v: v != "0"),
 }
 
 

@@ -24,6 +24,7 @@ struct SaArgs {
     int ldf, n, M, C;
     int feat_kind;     // CASPR_FEAT_QUAD | CASPR_FEAT_PAIRS: feat = quadratic augmentation of xyz (caspr_prep_input_f32)
     int lo_in, lo_out; // CASPR_FEAT_LO_IN: feat rows carry low parts at column ldf / 2; CASPR_FEAT_LO_OUT: the low part of the output goes to column ldo / 2 + out_off
+    int repair_kmax;   // balls of 1 .. repair_kmax distinct samples are evaluated by sa_repair_f64_kernel behind the register kernel (0: none)
     SaLayer L[3];
     float *out;
     int ldo, out_off;
@@ -345,11 +346,16 @@ __device__ __forceinline__ double sa_rows_allreduce(double x)
 // Between a lane's write to the wave's own LDS window (s_a0 / s_mu) and another lane's read of it: LDS operations of one wave issue in
 // order, so no hardware barrier is needed -- but the COMPILER must keep the ds_write in front of the ds_read; the fence pair + the wave
 // barrier (a scheduling fence, no instruction) make that a contract instead of an observation (round-4 advice).
+#ifndef SA_EXP
+#define SA_EXP 0     // timing experiments (tools/sa_repair_cost.py --lib): 1 no window sync, 2 no low-part pass
+#endif
 __device__ __forceinline__ void sa_window_sync()
 {
+#if !(SA_EXP & 1)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 template <int NS, int C1, int C2, int C3>
@@ -395,6 +401,24 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
     int rrow[NCEN];
 #pragma unroll
     for (int cen = 0; cen < NCEN; ++cen) rrow[cen] = __builtin_amdgcn_readlane(nrow[cen * TPC], 0);
+    // Balls of 1 .. repair_kmax distinct samples are evaluated in f64 by sa_repair_f64_kernel behind this kernel, which overwrites
+    // whatever is stored here: a wave ALL of whose centres are such balls has nothing to contribute (on sparse clouds that is most
+    // waves of the first level's small scale).  The test is sa_row_distinct's, on the same index rows: the samples that differ from
+    // sample 0 occupy exactly the positions 1 .. K - 1 (ball query's layout).  Wave-uniform.
+    if (a.repair_kmax > 0) {
+        bool all_small = true;
+#pragma unroll
+        for (int cen = 0; cen < NCEN; ++cen) {
+            unsigned long long diff = 0ull;
+#pragma unroll
+            for (int t = 0; t < TPC; ++t)
+                diff |= (__builtin_amdgcn_ballot_w64(nrow[cen * TPC + t] != rrow[cen]) & 0xFFFFull) << (16 * t);      // lanes g = 0: samples 16 t + j
+            const int K = __builtin_popcountll(diff) + 1;
+            const bool layout = diff == ((1ull << K) - 2ull);
+            all_small = all_small && (!cval[cen * TPC] || (layout && K <= a.repair_kmax));
+        }
+        if (all_small) return;
+    }
     const bool refl = j == 0;                   // column 0 of a neighbourhood's first tile carries its reference (sample 0, absolute)
     SA_STAMP(1)
 
@@ -444,44 +468,6 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
     };
     // B fragments of chunk kc straight from global memory: deviations from the neighbourhood's sample 0, and in sample 0's own column
     // (lane j = 0 of the neighbourhood's first tile, whose deviation is zero) the reference itself
-    // THE LOW PART OF THE REFERENCE INPUT (round 5).  The reference column is f64 from layer 1 on, but its INPUT was f32: the first
-    // level's quadratic features as caspr_prep_input_f32 rounds them (x^2 ~ 6 carries 4e-7), the deeper levels' features as the previous
-    // level stored them.  In a ball that holds ONE point the whole output is the GroupNorm chain of that input, and a two-channel group
-    // whose channels differ by ~1e-4 multiplies the input rounding by up to 158: 4e-4 on cfg-5's clouds.  rlo = what the f32 quad lacks:
-    // the exact f64 products of the coordinates minus the rounded feature (feat_kind), or the low part the previous level stored next to
-    // its output (lo_in); its product with the weights joins the f64 partials of mu behind the product loop.
-    // Only a ball that holds ONE point needs it: balls of 2..8 distinct points are re-evaluated in f64 behind this kernel
-    // (sa_repair_f64_kernel), larger ones carry the f32 rounding of their deviation columns anyway.  Wave-uniform.
-    bool single = false;
-#pragma unroll
-    for (int cen = 0; cen < NCEN; ++cen) {
-        bool same = true;
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) same = same && __builtin_amdgcn_ballot_w64(nrow[cen * TPC + t] != rrow[cen]) == 0ull;
-        single = single || same;
-    }
-    const bool want_lo = (a.feat_kind != 0 || a.lo_in != 0) && single;
-    auto ref_lo = [&](int cen, int k, const f32x4 &ref) -> f32x4 {
-        f32x4 lo = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a.feat_kind) {
-            if (k < C4) {
-                const float *q = a.xyz + ((long)b * a.n + rrow[cen]) * 3;
-                const double x0 = (double)q[0], y0 = (double)q[1], z0 = (double)q[2];
-                const bool qd = a.feat_kind & CASPR_FEAT_QUAD, both = qd && (a.feat_kind & CASPR_FEAT_PAIRS);
-                const double xz = x0 * z0, xy = x0 * y0, zy = z0 * y0;
-                const double f0 = qd ? x0 * x0 : xz, f1 = qd ? y0 * y0 : xy, f2 = qd ? z0 * z0 : zy;
-                const double e0 = k == 0 ? f0 : (both ? xy : 0.0), e1 = k == 0 ? f1 : (both ? zy : 0.0);
-                const double e2 = k == 0 ? f2 : 0.0, e3 = k == 0 ? (both ? xz : 0.0) : 0.0;
-                lo[0] = (float)(e0 - (double)ref[0]);
-                lo[1] = (float)(e1 - (double)ref[1]);
-                lo[2] = (float)(e2 - (double)ref[2]);
-                lo[3] = (float)(e3 - (double)ref[3]);
-            }
-        } else if (k < C4) {
-            lo = ld4(a.feat + ((long)b * a.n + rrow[cen]) * a.ldf + (a.ldf >> 1) + k);
-        }
-        return lo;
-    };
     auto gather = [&](f32x4(&bf)[CT], int kc) {
         const int k = kc * 16 + 4 * g;
         f32x4 ref[NCEN];
@@ -560,29 +546,6 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
         if (kcu & 1) {            // the last chunk of an odd count sits in set 0
             mask(b0, kcu - 1);
             mma1(b0, w0);
-        }
-        // the low part of the reference input, behind the product loop (its registers are free again): P1 += W lo in f64, this lane's
-        // weight row against the low parts of ITS k quads -- one more pass over the weight fragments (L1) and, with lo_in, one 16-byte
-        // load per centre and chunk
-        if (want_lo) {
-#pragma unroll 1
-            for (int kc = 0; kc < kcu; ++kc) {
-                const int k = kc * 16 + 4 * g;
-                f32x4 wl[C1 / 16];
-                load_a1(wl, kc);
-#pragma unroll
-                for (int cen = 0; cen < NCEN; ++cen) {
-                    f32x4 ref = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (a.feat_kind) ref = in_quad(rrow[cen], k, cx[cen * TPC], cy[cen * TPC], cz[cen * TPC]);
-                    f32x4 lo = ref_lo(cen, k, ref);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) lo[q] = k + q < a.C ? lo[q] : 0.f;
-#pragma unroll
-                    for (int rt = 0; rt < C1 / 16; ++rt)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) P1[rt][cen] = __builtin_fma((double)wl[rt][q], (double)lo[q], P1[rt][cen]);
-                }
-            }
         }
     }
     // the four k-rows of the partials summed, then row ar of tile rt -> the window (every lane row writes the same value)
@@ -762,7 +725,10 @@ __global__ __launch_bounds__(256, 3) void sa_small_kernel_w3(SaArgs a) { sa_smal
 // multiplicity ns - K + 1 for column 0, 1 for the others), and overwrites the register kernel's output rows.  16 lanes own one
 // neighbourhood: lane r the output rows 16 rt + r of every row tile (GroupNorm groups of 1 / 2 / 4 channels = 1 / 2 / 4 adjacent lanes);
 // the activations of a layer pass through a wave-private LDS window (f64), the weights come from the same A-pack the MFMA kernel reads.
-// K = 1 (all copies of one point) stays with the register kernel, whose reference column is f64 already.
+// K = 1 (all copies of one point) is a single column here (instantiation <1, 1>): the register kernel's reference column is f64 too,
+// but its INPUT is f32 -- the first level's quadratic features as caspr_prep_input_f32 rounds them (x^2 ~ 6 carries 4e-7), the second
+// level's features as the first stored them -- and a two-channel group whose channels differ by ~1e-4 multiplies that rounding by up
+// to 158 (4e-4 on cfg-5's clouds); here the features are the exact f64 products of the coordinates (feat_kind) or hi + lo (lo_in).
 // ---------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ int sa_row_bcast_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
@@ -788,19 +754,22 @@ __device__ __forceinline__ int sa_row_distinct(const int32_t *row, int ns, int r
     return bad == 0 ? K : 0;
 }
 
-// KLO <= K <= KHI distinct samples.  A workgroup surveys 64 neighbourhoods, lists the ones in its range in LDS, and its 16 lane groups
+// KLO <= K <= KHI distinct samples.  A workgroup surveys 128 neighbourhoods, lists the ones in its range in LDS, and its 16 lane groups
 // walk that list: on dense clouds the kernel is the index read, on sparse ones the lane groups stay busy whatever the pattern of
 // small balls (with a fixed neighbourhood per lane group a wave paid for four whenever one of them was small).
-template <int KLO, int KHI>
-__global__ __launch_bounds__(256) void sa_repair_f64_kernel(SaArgs a, int ns)
+template <int KLO, int KHI, int WMAX>
+__global__ __launch_bounds__(256, KHI > 4 ? 3 : 4) void sa_repair_f64_kernel(SaArgs a, int ns)
 {
     constexpr int KMAX = KHI;
-    constexpr int CMAX = 64;                              // widest LAST layer (register budget: CMAX / 16 x KMAX doubles)
     constexpr int CACT = 32;                              // widest first / second layer: what passes through the LDS window
-    constexpr int RTM = CMAX / 16;
-    constexpr int NBW = 64;                               // neighbourhoods surveyed per workgroup
+    constexpr int RTA = CACT / 16;                        // their row tiles, all kept in registers at once (RTA x KMAX doubles)
+    constexpr int NBW = 128;                              // neighbourhoods surveyed per workgroup
     constexpr int STR = KMAX * CACT + 2;                  // + 2 doubles: the 16 windows of a workgroup start in different banks
+    // WMAX: floats of the three A-packs together (2048 / 4096 at the first level's two scales, 7168 at the second level's): the LDS a
+    // workgroup takes decides how many neighbourhoods a CU keeps in flight, and this kernel is all latency
     __shared__ double s_act[16 * STR];
+    __shared__ __attribute__((aligned(16))) float s_w[WMAX];
+    __shared__ float s_par[3][3][64];                     // [layer][bias | gamma | beta][channel]
     __shared__ int s_list[NBW];
     __shared__ int s_cnt;
     const int tid = threadIdx.x, r = tid & 15, nb = tid >> 4;
@@ -808,7 +777,8 @@ __global__ __launch_bounds__(256) void sa_repair_f64_kernel(SaArgs a, int ns)
     double *act = s_act + nb * STR;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-#pragma unroll 1
+    // (unrolled: the eight index rows of a lane group are eight independent loads, not a chain of eight round trips)
+#pragma unroll
     for (int i = 0; i < NBW / 16; ++i) {
         const int m = blockIdx.x * NBW + nb + 16 * i;
         const int mm = m < a.M ? m : a.M - 1;
@@ -818,6 +788,63 @@ __global__ __launch_bounds__(256) void sa_repair_f64_kernel(SaArgs a, int ns)
     }
     __syncthreads();
     const int nlist = s_cnt;
+    if (nlist == 0) return;                               // dense clouds: the kernel was the index read
+    const int C4 = (a.C + 3) & ~3;
+    // The three A-packs (the ones the MFMA kernel reads) and the per-channel parameters, once per workgroup into LDS: a neighbourhood
+    // is a chain of ~20 dependent weight reads, and out of L2 each of them was a microsecond
+    int woff[3];
+    {
+        int o = 0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            woff[l] = o;
+            const int nf = (a.L[l].cout >> 4) * a.L[l].kc * 256;
+            for (int i = tid * 4; i < nf; i += 1024) st4(s_w + o + i, ld4(a.L[l].wp + i));
+            o += nf;
+            if (tid < a.L[l].cout) {
+                s_par[l][0][tid] = a.L[l].bias[tid];
+                s_par[l][1][tid] = a.L[l].gamma[tid];
+                s_par[l][2][tid] = a.L[l].beta[tid];
+            }
+        }
+    }
+    __syncthreads();
+    // the weight quad W[row 16 rt + r][k = 4 kq .. 4 kq + 3] of this lane
+    auto wquad = [&](int l, const SaLayer &L, int rt, int kq) -> f32x4 {
+        return ld4(s_w + woff[l] + ((rt * L.kc + (kq >> 2)) * 64 + (kq & 3) * 16 + r) * 4);
+    };
+    // bias + GroupNorm(16) of row tile rt (channels per group = RT = adjacent lanes of the tile) with the columns' multiplicities, two
+    // passes in f64; on return y holds the normalised values (no activation)
+    auto norm_tile = [&](double (&y)[KMAX], int l, int rt, int RT, const double (&mult)[KMAX]) {
+        const int ch = rt * 16 + r;
+        const double bias = (double)s_par[l][0][ch], ga = (double)s_par[l][1][ch], be = (double)s_par[l][2][ch];
+        const double inv_cnt = 1.0 / (double)(RT * ns);
+        double s1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+            y[c] += bias;
+            s1 += mult[c] * y[c];
+        }
+        if (RT >= 2) s1 += dpp_mov<0xB1>(s1);
+        if (RT >= 4) s1 += dpp_mov<0x4E>(s1);
+        const double mean = s1 * inv_cnt;
+        double s2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+            const double d = y[c] - mean;
+            s2 += mult[c] * d * d;
+        }
+        if (RT >= 2) s2 += dpp_mov<0xB1>(s2);
+        if (RT >= 4) s2 += dpp_mov<0x4E>(s2);
+        // 1 / sqrt(var + eps): v_rsq_f64 (~27 bits) + two Newton steps r <- r (1.5 - 0.5 v r^2) (54+ bits) -- a dozen f64 operations
+        // where the correctly rounded sqrt + division are ~100 dependent ones, three to twelve times per neighbourhood
+        const double vv = s2 * inv_cnt + 1e-5;
+        double rstd = __builtin_amdgcn_rsq(vv);
+        rstd = rstd * (1.5 - 0.5 * vv * rstd * rstd);
+        rstd = rstd * (1.5 - 0.5 * vv * rstd * rstd);
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) y[c] = (y[c] - mean) * (rstd * ga) + be;
+    };
 #pragma unroll 1
     for (int li = nb; li < nlist; li += 16) {
         const int m = s_list[li];
@@ -838,139 +865,129 @@ __global__ __launch_bounds__(256) void sa_repair_f64_kernel(SaArgs a, int ns)
 #pragma unroll
         for (int c = 0; c < KMAX; ++c) mult[c] = c == 0 ? (double)(ns - K + 1) : (c < K ? 1.0 : 0.0);
 
-        const int C4 = (a.C + 3) & ~3;
-        double y[RTM][KMAX];
-        // ---- layer 1 from global memory: K order [feat (C, padded to C4) | dx dy dz 0]
+        // ---- layer 1 from global memory: K order [feat (C, padded to C4) | dx dy dz 0]; both row tiles at once (the inputs are loaded once)
+        double y[RTA][KMAX];
         {
             const SaLayer L = a.L[0];
             const int RT = L.cout >> 4;
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt)
+            for (int rt = 0; rt < RTA; ++rt)
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c) y[rt][c] = 0.0;
             const float *cen = a.new_xyz + ((long)b * a.M + m) * 3;
             const float ccx = cen[0], ccy = cen[1], ccz = cen[2];
             const int nkq = (C4 >> 2) + 1;
             for (int kq = 0; kq < nkq; ++kq) {
-                double x[KMAX][4];
+                f32x4 w[RTA];
+#pragma unroll
+                for (int rt = 0; rt < RTA; ++rt) w[rt] = wquad(0, L, rt < RT ? rt : 0, kq);
+                // one column at a time (its four inputs live only across its own products: the register budget decides how many
+                // neighbourhoods a CU keeps in flight, and this kernel is all latency)
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c) {
+                    double x[4];
                     const float *p = a.xyz + ((long)b * a.n + rows[c]) * 3;
                     if (kq * 4 == C4) {
-                        x[c][0] = (double)(p[0] - ccx);           // the grouper's f32 subtraction (pointnet2.py:391-398)
-                        x[c][1] = (double)(p[1] - ccy);
-                        x[c][2] = (double)(p[2] - ccz);
-                        x[c][3] = 0.0;
+                        x[0] = (double)(p[0] - ccx);              // the grouper's f32 subtraction (pointnet2.py:391-398)
+                        x[1] = (double)(p[1] - ccy);
+                        x[2] = (double)(p[2] - ccz);
+                        x[3] = 0.0;
                     } else if (a.feat_kind) {
                         // the first level's quadratic augmentation (tpointnet2.py:79-90) from the coordinates, in f64
                         const double px = (double)p[0], py = (double)p[1], pz = (double)p[2];
                         const bool qd = a.feat_kind & CASPR_FEAT_QUAD, both = qd && (a.feat_kind & CASPR_FEAT_PAIRS);
                         const double xz = px * pz, xy = px * py, zy = pz * py;
                         const double f0 = qd ? px * px : xz, f1 = qd ? py * py : xy, f2 = qd ? pz * pz : zy;
-                        x[c][0] = kq == 0 ? f0 : (both ? xy : 0.0);
-                        x[c][1] = kq == 0 ? f1 : (both ? zy : 0.0);
-                        x[c][2] = kq == 0 ? f2 : 0.0;
-                        x[c][3] = kq == 0 ? (both ? xz : 0.0) : 0.0;
+                        x[0] = kq == 0 ? f0 : (both ? xy : 0.0);
+                        x[1] = kq == 0 ? f1 : (both ? zy : 0.0);
+                        x[2] = kq == 0 ? f2 : 0.0;
+                        x[3] = kq == 0 ? (both ? xz : 0.0) : 0.0;
                     } else {
                         const float *fr = a.feat + ((long)b * a.n + rows[c]) * a.ldf + kq * 4;
                         const f32x4 v = ld4(fr);
                         const f32x4 vl = a.lo_in ? ld4(fr + (a.ldf >> 1)) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) x[c][q] = kq * 4 + q < a.C ? (double)v[q] + (double)vl[q] : 0.0;
+                        for (int q = 0; q < 4; ++q) x[q] = kq * 4 + q < a.C ? (double)v[q] + (double)vl[q] : 0.0;
                     }
-                }
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) {
-                    if (rt < RT) {
-                        const f32x4 w = ld4(L.wp + (((long)rt * L.kc + (kq >> 2)) * 64 + (kq & 3) * 16 + r) * 4);
+                    for (int rt = 0; rt < RTA; ++rt)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int c = 0; c < KMAX; ++c) y[rt][c] = __builtin_fma((double)w[q], x[c][q], y[rt][c]);
-                    }
+                        for (int q = 0; q < 4; ++q) y[rt][c] = __builtin_fma((double)w[rt][q], x[q], y[rt][c]);
                 }
             }
         }
 #pragma unroll 1
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < 2; ++l) {
             const SaLayer L = a.L[l];
-            const int RT = L.cout >> 4;                   // = channels per GroupNorm(16) group
-            if (l > 0) {
-                // ---- layers 2, 3 from the window
-                const int nkq = a.L[l - 1].cout >> 2;
+            const int RT = L.cout >> 4;
+            if (l == 1) {
+                // ---- layer 2 from the window (written by layer 1 below)
+                const int nkq = a.L[0].cout >> 2;
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt)
+                for (int rt = 0; rt < RTA; ++rt)
 #pragma unroll
                     for (int c = 0; c < KMAX; ++c) y[rt][c] = 0.0;
                 for (int kq = 0; kq < nkq; ++kq) {
-                    double x[KMAX][4];
+                    f32x4 w[RTA];
 #pragma unroll
-                    for (int c = 0; c < KMAX; ++c)
+                    for (int rt = 0; rt < RTA; ++rt) w[rt] = wquad(1, L, rt < RT ? rt : 0, kq);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) x[c][q] = act[c * CACT + kq * 4 + q];
+                    for (int c = 0; c < KMAX; ++c) {
+                        double x[4];
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) {
-                        if (rt < RT) {
-                            const f32x4 w = ld4(L.wp + (((long)rt * L.kc + (kq >> 2)) * 64 + (kq & 3) * 16 + r) * 4);
+                        for (int q = 0; q < 4; ++q) x[q] = act[c * CACT + kq * 4 + q];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
+                        for (int rt = 0; rt < RTA; ++rt)
 #pragma unroll
-                                for (int c = 0; c < KMAX; ++c) y[rt][c] = __builtin_fma((double)w[q], x[c][q], y[rt][c]);
-                        }
+                            for (int q = 0; q < 4; ++q) y[rt][c] = __builtin_fma((double)w[rt][q], x[q], y[rt][c]);
                     }
                 }
-                // every lane of the neighbourhood has read the window before the next layer's activations overwrite it
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                // every lane of the neighbourhood has read the window before layer 2's activations overwrite it
+                sa_window_sync();
             }
-            // ---- bias, GroupNorm(16) over (RT channels x ns samples) with the columns' multiplicities, two passes in f64
-            const double inv_cnt = 1.0 / (double)(RT * ns);
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) {
+            for (int rt = 0; rt < RTA; ++rt) {
                 if (rt < RT) {
-                    const int ch = rt * 16 + r;
-                    const double bias = (double)L.bias[ch], ga = (double)L.gamma[ch], be = (double)L.beta[ch];
-                    double s1 = 0.0;
+                    norm_tile(y[rt], l, rt, RT, mult);
 #pragma unroll
-                    for (int c = 0; c < KMAX; ++c) {
-                        y[rt][c] += bias;
-                        s1 += mult[c] * y[rt][c];
-                    }
-                    if (RT >= 2) s1 += dpp_mov<0xB1>(s1);
-                    if (RT >= 4) s1 += dpp_mov<0x4E>(s1);
-                    const double mean = s1 * inv_cnt;
-                    double s2 = 0.0;
-#pragma unroll
-                    for (int c = 0; c < KMAX; ++c) {
-                        const double d = y[rt][c] - mean;
-                        s2 += mult[c] * d * d;
-                    }
-                    if (RT >= 2) s2 += dpp_mov<0xB1>(s2);
-                    if (RT >= 4) s2 += dpp_mov<0x4E>(s2);
-                    const double rstd = 1.0 / sqrt(s2 * inv_cnt + 1e-5);
-                    double mx = -INFINITY;
-#pragma unroll
-                    for (int c = 0; c < KMAX; ++c) {
-                        double v = (y[rt][c] - mean) * (rstd * ga) + be;
-                        if (l < 2) {
-                            v = v > 0.0 ? v : 0.0;
-                            act[c * CACT + ch] = v;
-                        } else if (c < K) {
-                            mx = v > mx ? v : mx;
-                        }
-                    }
-                    if (l == 2) {
-                        float *o = a.out + ((long)b * a.M + m) * a.ldo + a.out_off + ch;
-                        const float hi = (float)mx;
-                        o[0] = hi;
-                        if (a.lo_out) o[a.ldo >> 1] = (float)(mx - (double)hi);
-                    }
+                    for (int c = 0; c < KMAX; ++c) act[c * CACT + rt * 16 + r] = y[rt][c] > 0.0 ? y[rt][c] : 0.0;      // ReLU
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            sa_window_sync();
         }
+        // ---- layer 3 one row tile at a time (up to four: kept together they were half of this kernel's registers), GroupNorm without
+        // activation, max over the columns (each occurs at least once), stored as hi (+ lo)
+        {
+            const SaLayer L = a.L[2];
+            const int RT = L.cout >> 4;
+            const int nkq = a.L[1].cout >> 2;
+#pragma unroll 1
+            for (int rt = 0; rt < RT; ++rt) {
+                double y3[KMAX];
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) y3[c] = 0.0;
+                for (int kq = 0; kq < nkq; ++kq) {
+                    const f32x4 w = wquad(2, L, rt, kq);
+#pragma unroll
+                    for (int c = 0; c < KMAX; ++c) {
+                        double x[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] = act[c * CACT + kq * 4 + q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y3[c] = __builtin_fma((double)w[q], x[q], y3[c]);
+                    }
+                }
+                norm_tile(y3, 2, rt, RT, mult);
+                double mx = y3[0];
+#pragma unroll
+                for (int c = 1; c < KMAX; ++c) mx = (c < K && y3[c] > mx) ? y3[c] : mx;
+                float *o = a.out + ((long)b * a.M + m) * a.ldo + a.out_off + rt * 16 + r;
+                const float hi = (float)mx;
+                o[0] = hi;
+                if (a.lo_out) o[a.ldo >> 1] = (float)(mx - (double)hi);
+            }
+        }
+        sa_window_sync();          // the window is free for this lane group's next neighbourhood
     }
 }
 
@@ -1036,7 +1053,14 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
     if (a.rowsB < C1 / 4) a.rowsB = C1 / 4;
     hipStream_t st = (hipStream_t)stream;
     const bool no_small = CASPR_DEBUG_ENV_INT("CASPR_SA_NO_SMALL") != 0;   // debug build only: force the LDS kernel
+    a.repair_kmax = 0;
     if (!no_small && ldo % 4 == 0 && out_off % 4 == 0 && ((uintptr_t)out % 16) == 0) {
+        {   // which balls the f64 re-evaluation behind the register kernel will take (the register kernel skips waves made of those only)
+            const int rk_ = CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K");
+            const int wf_ = ((C1 >> 4) * a.L[0].kc + (C2 >> 4) * a.L[1].kc + (C3 >> 4) * a.L[2].kc) * 256;
+            const bool small_shape = (C1 == 16 || C1 == 32) && C1 == C2 && C3 == 2 * C1;
+            if (small_shape && rk_ >= 0 && wf_ <= 7168) a.repair_kmax = ((rk_ == 0 || rk_ >= 8) && a.feat_kind != 0 && wf_ <= 4096) ? 8 : 4;
+        }
         const int cpb = 4 * (64 / ns);   // centres per 256-thread block (4 waves x 64 columns)
         dim3 grid(ceil_div(M, cpb), B);
         bool done = true;
@@ -1051,11 +1075,21 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
             // (the window of sa_repair_f64_kernel holds first / second layers of <= 32 channels: every shape of this branch)
             // 5..8 at the FIRST level only (feat_kind set): its outputs are what the second level's small balls amplify; the second
             // level's own outputs go to the wide levels, whose groups of >= 4 channels do not (tools/sa_repair_sweep.py)
-            const int rk = CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K"), rk1 = CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K1");
-            const dim3 rgrid(ceil_div(M, 64), B);
-            if (rk >= 0) {
-                sa_repair_f64_kernel<2, 4><<<rgrid, dim3(256), 0, st>>>(a, ns);
-                if ((rk == 0 || rk >= 8) && (a.feat_kind != 0 || rk1 >= 8)) sa_repair_f64_kernel<5, 8><<<rgrid, dim3(256), 0, st>>>(a, ns);
+            const int wfloats = ((C1 >> 4) * a.L[0].kc + (C2 >> 4) * a.L[1].kc + (C3 >> 4) * a.L[2].kc) * 256;      // the kernel keeps the three packs in LDS
+            CASPR_REQUIRE(a.repair_kmax > 0 || CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K") < 0, "sa_mlp_max: the f64 re-evaluation keeps %d weight floats in LDS (> its window)", wfloats);
+            const dim3 rgrid(ceil_div(M, 128), B);
+            if (a.repair_kmax > 0) {
+                const bool wide = a.repair_kmax > 4;
+#define SA_REPAIR(W)                                                                                          \
+    do {                                                                                                      \
+        sa_repair_f64_kernel<1, 1, W><<<rgrid, dim3(256), 0, st>>>(a, ns); /* one point: the chain of its features alone, f64 from exact / hi + lo inputs */ \
+        sa_repair_f64_kernel<2, 4, W><<<rgrid, dim3(256), 0, st>>>(a, ns);                                    \
+        if (wide) sa_repair_f64_kernel<5, 8, (W > 4096 ? 4096 : W)><<<rgrid, dim3(256), 0, st>>>(a, ns);      \
+    } while (0)
+                if (wfloats <= 2048) SA_REPAIR(2048);
+                else if (wfloats <= 4096) SA_REPAIR(4096);
+                else SA_REPAIR(7168);
+#undef SA_REPAIR
                 CASPR_CHECK_LAUNCH("sa_mlp_max(repair)");
             }
             return CASPR_OK;

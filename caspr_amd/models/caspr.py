@@ -102,7 +102,8 @@ class CaSPR(nn.Module):
         # the step count on `check_points` samples per frame (the latent solve: all of it, on one compute unit) on a side stream, the
         # results are compared on the device, and the Richardson estimate of the delivered solution's error is examined through
         # ops.check_deferred_errors() / at the next guarded call: CasprAccuracyError (check_action "raise") or a RuntimeWarning
-        # ("warn") when it exceeds check_tol (latent: latent_check_tol, default 100 x check_tol = the reference's ratio).
+        # ("warn") when it exceeds check_tol x (1 + max |x|) -- torchdiffeq's atol + rtol |x| with atol = rtol = check_tol, as the
+        # reference sets them (latent: latent_check_tol, default 100 x check_tol = the reference's ratio).
         self.check_tol = check_tol
         self.latent_check_tol = latent_check_tol
         self.check_action = check_action
@@ -239,7 +240,7 @@ class CaSPR(nn.Module):
                 plan = self.latent_ode.plan_times(time_tensor)
             zc = ops.latent_rk4(z_init, plan["sorted_t"], L2, self.latent_ode._weights(), team=False)[plan["rows"], plan["pos"], :]
             diff = (sample_feats - zc).abs().amax()
-            ops.guard_track(diff, {"name": "latent", "tol": float(tol), "factor": factor, "steps": L, "other_steps": L2, "action": self.check_action,
+            ops.guard_track(diff, sample_feats.abs().amax(), {"name": "latent", "tol": float(tol), "factor": factor, "steps": L, "other_steps": L2, "action": self.check_action,
                                    "what": "latent ODE (latent_ode_model.py:45-70; reference: dopri5 at rtol = atol = 1e-3)"})
         for t_ in (z_init, sample_feats, time_tensor):
             t_.record_stream(gs)
@@ -265,7 +266,7 @@ class CaSPR(nn.Module):
                 for b, st in saved:
                     b.rk4_steps, b._count_evals = st, True
             diff = (x[:, :g] - xh).abs().amax()
-            ops.guard_track(diff, {"name": "cnf", "tol": float(self.check_tol), "factor": factor, "steps": S, "other_steps": S2, "action": self.check_action,
+            ops.guard_track(diff, x[:, :g].abs().amax(), {"name": "cnf", "tol": float(self.check_tol), "factor": factor, "steps": S, "other_steps": S2, "action": self.check_action,
                                    "what": "point CNF (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"})
         for t_ in (y, z, x):
             t_.record_stream(gs)

@@ -621,14 +621,16 @@ def reset_guard():
     GUARD_HISTORY_MAX = 0.0
 
 
-def guard_track(diff, meta):
-    """diff: 0-dim float32 device tensor = max |x_S - x_S'| of a check (on the CURRENT stream); meta: {"name", "tol", "factor",
-    "steps", "other_steps", "action", "what"} -- estimate = factor * diff is compared with tol when the copy has arrived."""
+def guard_track(diff, scale, meta):
+    """diff: 0-dim float32 device tensor = max |x_S - x_S'| of a check, scale: 0-dim = max |x_S| (both on the CURRENT stream); meta:
+    {"name", "tol", "factor", "steps", "other_steps", "action", "what"} -- estimate = factor * diff is compared with
+    tol * (1 + scale), i.e. torchdiffeq's  atol + rtol |x|  with atol = rtol = tol (what the reference sets: flow.py:96-99,
+    latent_ode_model.py:83), when the copy has arrived."""
     if len(_guard_ring) >= 64:                      # nobody drained for 64 checks: bound the backlog (blocks on the oldest)
         _guard_ring[0][1].synchronize()
     _guard_drain(wait=False)
-    host = _guard_pool.pop() if _guard_pool else torch.zeros(1, dtype=torch.float32).pin_memory()
-    host.copy_(diff.reshape(1), non_blocking=True)
+    host = _guard_pool.pop() if _guard_pool else torch.zeros(2, dtype=torch.float32).pin_memory()
+    host.copy_(torch.stack([diff.reshape(()), scale.reshape(())]), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
     _guard_ring.append((host, ev, meta))
@@ -646,16 +648,19 @@ def _guard_drain(wait=False):
         if not ev.query():
             break
         _guard_ring.pop(0)
-        d = float(host[0])
+        d, xmax = float(host[0]), float(host[1])
         _guard_pool.append(host)
         est = meta["factor"] * d
-        ok = math.isfinite(est) and est <= meta["tol"]
-        GUARD_LAST[meta["name"]] = {"diff": d, "estimate": est, "tol": meta["tol"], "steps": meta["steps"], "other_steps": meta["other_steps"], "ok": ok}
-        GUARD_HISTORY_MAX = max(GUARD_HISTORY_MAX, est / meta["tol"] if math.isfinite(est) else float("inf"))
+        bound = meta["tol"] * (1.0 + xmax) if math.isfinite(xmax) else meta["tol"]
+        ok = math.isfinite(est) and est <= bound
+        GUARD_LAST[meta["name"]] = {"diff": d, "estimate": est, "tol": meta["tol"], "solution_absmax": xmax, "bound": bound, "steps": meta["steps"],
+                                    "other_steps": meta["other_steps"], "ok": ok}
+        GUARD_HISTORY_MAX = max(GUARD_HISTORY_MAX, est / bound if math.isfinite(est) else float("inf"))
         if not ok:
             msg = ("%s: RK4 with %d steps is not converged to the tolerance asked for: max |x_%d - x_%d| = %.3e on the checked subsample -> "
-                   "error estimate %.3e > check_tol %.1e.  Raise the step count (CaSPR.calibrate_rk4_steps picks it by step doubling) or "
-                   "the tolerance." % (meta["what"], meta["steps"], meta["steps"], meta["other_steps"], d, est, meta["tol"]))
+                   "error estimate %.3e > %.3e = check_tol %.1e x (1 + max |x| %.2f).  Raise the step count (CaSPR.calibrate_rk4_steps picks "
+                   "it by step doubling) or the tolerance." % (meta["what"], meta["steps"], meta["steps"], meta["other_steps"], d, est, bound,
+                                                              meta["tol"], xmax))
             if meta["action"] == "warn":
                 warnings.warn(msg, RuntimeWarning, stacklevel=3)
             else:

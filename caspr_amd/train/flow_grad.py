@@ -587,6 +587,7 @@ from ..config import config as _cfg     # (A/B timing and debugging switches: ca
 OUT_NODE = _cfg.train_cnf_out_node          # False: the output layer's epilogue in torch element-wise ops
 HIDDEN_NODE = _cfg.train_cnf_hidden_node    # False: CnfLayer + CnfLayerOut
 LATENT_NODE = _cfg.train_latent_node        # False: the per-layer form
+CHECKPOINT_STEPS = _cfg.train_cnf_checkpoint   # True: the CNF's tape per RK4 step, recomputed in the backward pass (cnf_block_train)
 
 
 def latent_solve_train(lat, z0, times):
@@ -674,15 +675,25 @@ def cnf_block_train(block, x, context, logpx, e):
     t_end = block.sqrt_end_time * block.sqrt_end_time if block.train_T else torch.tensor(float(block.T), device=x.device)
     steps = block.rk4_steps
     hstep = t_end / steps
-    y, lp = x, logpx
-    for s in range(steps):
-        t = hstep * s
+    def rk4_step(t, y, lp):
         k1 = func(t, y, lp)
         k2 = func(t + 0.5 * hstep, y + 0.5 * hstep * k1[0], lp)
         k3 = func(t + 0.5 * hstep, y + 0.5 * hstep * k2[0], lp)
         k4 = func(t + hstep, y + hstep * k3[0], lp)
-        y = y + (hstep / 6.0) * (k1[0] + 2.0 * k2[0] + 2.0 * k3[0] + k4[0])
-        lp = lp + (hstep / 6.0) * (k1[1] + 2.0 * k2[1] + 2.0 * k3[1] + k4[1])
+        return (y + (hstep / 6.0) * (k1[0] + 2.0 * k2[0] + 2.0 * k3[0] + k4[0]),
+                lp + (hstep / 6.0) * (k1[1] + 2.0 * k2[1] + 2.0 * k3[1] + k4[1]))
+
+    # CHECKPOINT_STEPS (config.train_cnf_checkpoint; off by default): keep only the state (y, logp) at the RK4 step boundaries and
+    # recompute a step's four evaluations when the backward pass reaches it -- what the reference's adjoint does too (cnf.py:100-110:
+    # O(1) memory, the trajectory re-integrated backwards).  The tape of ALL 4 S evaluations is 63 GB at the cfg-3 shard; of one
+    # step, 1 / S of that.  Costs one more forward of the block (same kernels, same bits: the step is a pure function of its inputs).
+    ckpt = CHECKPOINT_STEPS and torch.is_grad_enabled()
+    if ckpt:
+        from torch.utils.checkpoint import checkpoint
+    y, lp = x, logpx
+    for s in range(steps):
+        t = hstep * s
+        y, lp = checkpoint(rk4_step, t, y, lp, use_reentrant=False) if ckpt else rk4_step(t, y, lp)
     block.odefunc._num_evals.fill_(4 * steps)
     return y, lp
 

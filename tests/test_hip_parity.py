@@ -1478,7 +1478,7 @@ def test_accuracy_guard(dev, seeded_sd, stress_sd):
     ops.check_deferred_errors()
     rep = dict(ops.GUARD_LAST)
     assert rep["cnf"]["ok"] and rep["latent"]["ok"] and rep["cnf"]["other_steps"] == 4 and rep["latent"]["other_steps"] == 1, rep
-    assert rep["cnf"]["estimate"] <= 1e-6 and rep["latent"]["estimate"] <= 1e-3, rep
+    assert rep["cnf"]["estimate"] <= 1e-6 and rep["latent"]["estimate"] <= rep["latent"]["bound"] <= 1e-2, rep    # (T = 4: intervals of 1/3, three times the headline's)
     m.check_tol = None
     ref = m.reconstruct(x.to(dev), num_points=256, timestamps=ts, y=yb)
     assert nfe == [int(v) for v in m.get_nfe()] == [4 * 2 * 3, 32]

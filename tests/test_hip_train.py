@@ -658,6 +658,43 @@ def test_full_model_gradients_are_bit_reproducible(seeded_sd, golden):
     assert not bad, "gradients differ between two identical passes: %s" % bad[:5]
 
 
+def test_cnf_step_checkpointing_gives_the_same_bits(seeded_sd, golden):
+    """config.train_cnf_checkpoint: the CNF's tape kept per RK4 step and the step recomputed in the backward pass (the reference's
+    adjoint re-integrates too, cnf.py:100-110).  A step is a pure function of its inputs on deterministic kernels: loss and every
+    gradient are bit-identical to the taped form, and the peak memory of the step is smaller."""
+    from caspr_amd.models import CaSPR
+    from caspr_amd.train import flow_grad
+    dev = torch.device("cuda:0")
+    m = CaSPR(cnf_rk4_steps=4, latent_rk4_steps=2)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).train()
+    x, sp = torch.from_numpy(golden["train_x"]).to(dev), torch.from_numpy(golden["train_sp"]).to(dev)
+    e = torch.from_numpy(golden["train_e"]).to(dev)
+    stats = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or k.endswith(".step")}
+
+    def grads(ck):
+        prev, flow_grad.CHECKPOINT_STEPS = flow_grad.CHECKPOINT_STEPS, ck
+        try:
+            m.load_state_dict(stats, strict=False)
+            m.zero_grad()
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            nll, tl = m(x, sp, e=e)
+            loss = 0.01 * nll.sum(2).mean() + 100.0 * tl[:, :, :, :4].mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss), [None if p.grad is None else p.grad.detach().clone() for p in m.parameters()], torch.cuda.max_memory_allocated()
+        finally:
+            flow_grad.CHECKPOINT_STEPS = prev
+    la, ga, ma = grads(False)
+    lb, gb, mb = grads(True)
+    assert la == lb
+    bad = [n for (n, _), u, v in zip(m.named_parameters(), ga, gb) if (u is None) != (v is None) or (u is not None and not torch.equal(u, v))]
+    assert not bad, "checkpointed and taped gradients differ: %s" % bad[:5]
+    REPORT["cnf_step_checkpoint_peak_bytes"] = {"taped": ma, "checkpointed": mb}
+    assert mb < ma
+
+
 def test_eval_mode_forward_is_differentiable_and_cnf_forward_draws_fresh_noise(seeded_sd, golden):
     """The reference's forward stays differentiable in eval() (its callers add torch.no_grad() themselves): same loss values
     as under no_grad, a graph when grad mode is on, no MovingBatchNorm statistics update.  CNF.forward (cnf.py:100) clears

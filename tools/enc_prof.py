@@ -1,11 +1,19 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python
+"""Six cfg-2 encoder passes (car clouds, 16 x 10 x 2048) for rocprofv3 --kernel-trace --stats; optional argument: the library's file name."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from caspr_amd import lib
+if len(sys.argv) > 1:
+    lib.SO_PATH = lib.SO_PATH.replace("libcaspr_hip.so", sys.argv[1])
 import torch
 from caspr_amd.models import CaSPR
 from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences
 dev = torch.device("cuda:0")
-m = CaSPR(); m.load_state_dict(seeded_state_dict(m.state_dict(), 0)); m = m.to(dev).eval()
-x, _ = car_sequences(16, 10, 2048, seed=1234); x = x.to(dev)
+m = CaSPR()
+m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+m = m.to(dev).eval()
+x, _ = car_sequences(16, 10, 2048, seed=1234)
+x = x.to(dev)
 with torch.no_grad():
     for _ in range(6):
         m.encode(x)

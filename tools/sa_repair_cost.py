@@ -5,12 +5,14 @@ into each range.   (GPU)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from caspr_amd import lib
-lib.SO_PATH = lib.SO_PATH.replace("libcaspr_hip.so", "libcaspr_hip_debug.so")
+lib.SO_PATH = lib.SO_PATH.replace("libcaspr_hip.so", sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else "libcaspr_hip_debug.so")
 import torch
 from caspr_amd import ops
 from caspr_amd.models import CaSPR
 from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences
 
+import caspr_amd.models.pointnet2 as P2
+P2.SCALE_STREAMS = False          # one scale at a time: a launch's own duration, not its share of an overlap
 dev = torch.device("cuda:0")
 m = CaSPR()
 m.load_state_dict(seeded_state_dict(m.state_dict(), 0))

@@ -53,7 +53,7 @@ def sa_ms(x):
     return tot / 3
 
 
-for rk, rk1 in (("-1", "0"), ("4", "0"), ("0", "0"), ("0", "8")):
+for rk, rk1 in (("-1", "0"), ("4", "0"), ("0", "0")):
     os.environ["CASPR_SA_REPAIR_K"] = rk
     os.environ["CASPR_SA_REPAIR_K1"] = rk1
     errs = []
