@@ -55,7 +55,7 @@ def measure(args, dev, rank=0, world=1):
     bucket = GradBucket(model.parameters()) if world > 1 else None
     x_all, sp_all = car_sequences(world * B, T, N, seed=1234)
     x, sp = x_all[rank * B:(rank + 1) * B].to(dev), sp_all[rank * B:(rank + 1) * B].to(dev)
-    e = torch.randn(B * T, N, 3, device=dev) if full else None
+    e = torch.randn(B * T, N, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(4321 + rank)) if full else None   # fixed Hutchinson noise: repeatable losses
 
     losses = []
     for _ in range(args.warmup):

@@ -501,11 +501,13 @@ extern "C" int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int l
     a.trace = nullptr;
     CASPR_IF_DEBUG(a.trace = g_x6_trace;)
     a.diag = CASPR_DEBUG_ENV_INT("CASPR_X6_DIAG");   // timing experiments, debug build only
+    const bool narrow = (reverse & CASPR_CNF_NARROW) != 0;      // the caller asks for the 64-point sampling kernel (include/caspr_hip.h)
+    reverse &= 1;
     a.y_out = y_out; a.ldh = ldh; a.n = n; a.steps = steps; a.reverse = reverse; a.t_end = t_end;
     // Kernel choice by the presence of e only, never by BT or n: a frame's result does not depend on the batch around it.
     // Sampling (no divergence): the 128-point kernel of ode_bf16x6w.hip; the debug build can force the 64-point one
     // (CASPR_X6_NARROW=1) for A/B timing (tools/cnf_x6w_trace.py).
-    if (!e && CASPR_DEBUG_ENV_INT("CASPR_X6_NARROW") == 0) {
+    if (!e && !narrow && CASPR_DEBUG_ENV_INT("CASPR_X6_NARROW") == 0) {
         a.w1x += XC_PACK;
         a.w2x += XC_PACK;
         const int rc = caspr_cnf_x6w_launch(a, BT, (hipStream_t)stream);

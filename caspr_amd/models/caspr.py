@@ -245,31 +245,50 @@ class CaSPR(nn.Module):
         for t_ in (z_init, sample_feats, time_tensor):
             t_.record_stream(gs)
 
-    def _guard_cnf(self, y, z, x):
-        """The point CNF once more on the first `check_points` samples of every frame at half (or twice) the step count, on the guard
-        stream (it needs y and z only, so it runs beside the tail of the main launch); max |x_S - x_S'| goes to the deferred channel."""
+    def _guard_cnf_begin(self, y, z):
+        """Queue the point CNF once more on the first `check_points` samples of every frame at half (or twice) the step count on the
+        guard stream, BEHIND AN EVENT RECORDED BEFORE THE MAIN SOLVE IS LAUNCHED: the check needs y and z only, so its 160 small
+        workgroups run beside the main launch instead of after it.  -> what _guard_cnf_end needs."""
         from .cnf import CNF
         blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
+        for b in blocks:               # weight packs / end time are built on first use: on the MAIN stream, before the guard stream reads them
+            b._weights()
+            if ops.CNF_BF16X6:
+                b._weights_x6()
+            b.end_time()
         S = blocks[0].rk4_steps
         S2, factor = _other_steps(S)
         g = min(int(self.check_points), y.shape[1])
         main = torch.cuda.current_stream()
         gs = _guard_stream(y.device)
-        gs.wait_stream(main)
+        ready = torch.cuda.Event()
+        ready.record(main)
         saved = [(b, b.rk4_steps) for b in blocks]
         with torch.cuda.stream(gs), ops.untimed():
+            gs.wait_event(ready)
             try:
                 for b in blocks:
-                    b.rk4_steps, b._count_evals = _other_steps(b.rk4_steps)[0], False
+                    b.rk4_steps, b._count_evals, b.odefunc._count_evals, b._narrow = _other_steps(b.rk4_steps)[0], False, False, g <= 64
                 xh = self.point_cnf(y[:, :g].contiguous(), z, reverse=True)
             finally:
                 for b, st in saved:
-                    b.rk4_steps, b._count_evals = st, True
-            diff = (x[:, :g] - xh).abs().amax()
-            ops.guard_track(diff, x[:, :g].abs().amax(), {"name": "cnf", "tol": float(self.check_tol), "factor": factor, "steps": S, "other_steps": S2, "action": self.check_action,
-                                   "what": "point CNF (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"})
-        for t_ in (y, z, x):
+                    b.rk4_steps, b._count_evals, b.odefunc._count_evals, b._narrow = st, True, True, False
+        for t_ in (y, z):
             t_.record_stream(gs)
+        return {"xh": xh, "g": g, "S": S, "S2": S2, "factor": factor, "stream": gs}
+
+    def _guard_cnf_end(self, ctx, x):
+        """max |x_S - x_S'| on the checked samples -> the deferred channel (ops.guard_track); nothing on the current stream waits."""
+        gs, g = ctx["stream"], ctx["g"]
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
+        with torch.cuda.stream(gs), ops.untimed():
+            gs.wait_event(done)
+            diff = (x[:, :g] - ctx["xh"]).abs().amax()
+            ops.guard_track(diff, x[:, :g].abs().amax(), {"name": "cnf", "tol": float(self.check_tol), "factor": ctx["factor"], "steps": ctx["S"],
+                                                          "other_steps": ctx["S2"], "action": self.check_action,
+                                                          "what": "point CNF (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"})
+        x.record_stream(gs)
 
     def gen_latent(self, z0, timestamps):
         """caspr.py:185-196."""
@@ -353,9 +372,10 @@ class CaSPR(nn.Module):
         else:
             logp_y = standard_normal_logprob(y).view(B * T, num_points, -1).sum(2)
         z = z.reshape((B * T, H))
+        guard = self._guard_cnf_begin(y, z) if (self.check_tol is not None and y.is_cuda and not torch.is_grad_enabled()) else None
         x = self.point_cnf(y, z, reverse=True)
-        if self.check_tol is not None and x.is_cuda and not torch.is_grad_enabled():
-            self._guard_cnf(y, z, x)
+        if guard is not None:
+            self._guard_cnf_end(guard, x)
         return y.view((B, T, num_points, input_dim)), logp_y.view((B, T, num_points)), x.view((B, T, num_points, input_dim))
 
     def reconstruct(self, x, num_points=1024, constant_in_time=False, timestamps=None, max_timestamp=5.0,

@@ -36,6 +36,7 @@ class CNF(nn.Module):
         self.conditional = conditional
         self.rk4_steps = rk4_steps
         self._count_evals = True      # False while the accuracy guard repeats a solve (CaSPR._guard_cnf): get_nfe() counts the real one only
+        self._narrow = False          # True while the guard runs its check solve: the 64-point sampling kernel (ops.cnf_rk4(narrow=True))
         self._cache = WeightCache()
 
     def _weights(self):
@@ -98,7 +99,7 @@ class CNF(nn.Module):
         w1x, w2x = self._weights_x6() if ops.CNF_BF16X6 else (None, None)
         res = ops.cnf_rk4(x.contiguous(), hyper, w["tcol"], w["w0"], w["b0"], w["w1p"], w["b1"], w["w2p"], w["b2"], w["w3"], w["b3"],
                           self.end_time(), self.rk4_steps, reverse, mbn_in, mbn_out, e=e,
-                          logp=None if logpx is None else logpx.contiguous(), w1x=w1x, w2x=w2x)
+                          logp=None if logpx is None else logpx.contiguous(), w1x=w1x, w2x=w2x, narrow=self._narrow)
         if self._count_evals:
             self.odefunc._num_evals += 4 * self.rk4_steps
         return res

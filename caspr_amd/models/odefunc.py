@@ -33,8 +33,10 @@ class ODEfunc(nn.Module):
         self.diffeq = diffeq
         self.register_buffer("_num_evals", torch.tensor(0.))
         self._e = None
+        self._count_evals = True      # False while the accuracy guard repeats a solve: the counter then keeps the real solve's value
 
     def before_odeint(self, e=None):
         """odefunc.py:115-117: fix (or clear) the Hutchinson noise for the next solve."""
         self._e = e
-        self._num_evals.fill_(0)
+        if self._count_evals:
+            self._num_evals.fill_(0)

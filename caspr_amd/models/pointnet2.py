@@ -188,15 +188,19 @@ class PointNet2SetAbstraction(nn.Module):
         events=True (called on a side stream): "scale_ready"[i] is recorded behind ball query i, so that scale i's kernel can start
         while the next query still runs (at the first level the consumer is waiting: 0.24 ms of the step)."""
         fps_idx, new_xyz = ops.furthest_point_sampling(xyz, self.num_points_out, return_xyz=True)   # pointnet2.py:384-387
-        ball, ready = [], []
-        for g, ns in zip(self.grouper_modules, self.layers):
-            ball.append(ops.ball_query(g.radius, ns, xyz, new_xyz))                                 # :391
+        # the query of the scale with the MOST samples first: its point MLP is the long one of the level (twice the columns), and with
+        # the scales on two streams (run()) the level ends when that one does -- it should not wait behind the other scale's query
+        ball, ready = [None] * len(self.layers), [None] * len(self.layers)
+        order = sorted(range(len(self.layers)), key=lambda i_: -self.layers[i_])
+        for i in order:
+            ball[i] = ops.ball_query(self.grouper_modules[i].radius, self.layers[i], xyz, new_xyz)  # :391
             if events:
-                ready.append(torch.cuda.Event())
-                ready[-1].record()
+                ready[i] = torch.cuda.Event()
+                ready[i].record()
         d = {"fps_idx": fps_idx, "new_xyz": new_xyz, "ball_idx": ball}
         if events:
             d["scale_ready"] = ready
+            d["last_scale"] = order[-1]
         return d
 
     @staticmethod
@@ -406,7 +410,7 @@ class PointNet2feat(nn.Module):
         for sa in self.set_abstractions:
             d = sa.indices(xyz_list[-1], events=events)
             if events:
-                d["ready"] = d["scale_ready"][-1]          # the whole level: its last ball query
+                d["ready"] = d["scale_ready"][d["last_scale"]]          # the whole level: its last ball query
             sa_idx.append(d)
             xyz_list.append(d["new_xyz"])
         nn = []

@@ -730,10 +730,14 @@ def pack_cnf_x6(w):
     return out
 
 
+CNF_NARROW = 2        # include/caspr_hip.h: CASPR_CNF_NARROW
+
+
 def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reverse, mbn_in=None, mbn_out=None,
-            e=None, logp=None, w1x=None, w2x=None):
+            e=None, logp=None, w1x=None, w2x=None, narrow=False):
     """Fixed-step RK4 of one CNF block (cnf.py:70-128).  y (BT,n,3); hyper (BT,ldh).  Returns x or (x, logp).
-    w1x / w2x (pack_cnf_x6): when given, the bf16x6 kernel runs the solve (with or without the divergence)."""
+    w1x / w2x (pack_cnf_x6): when given, the bf16x6 kernel runs the solve (with or without the divergence).
+    narrow: the 64-point sampling kernel (a launch that does not fill the chip lasts as long as one workgroup: the accuracy guard)."""
     _chk_f32(y, hyper, tcol, w0, b0, b1, b2, w3, b3, mbn_in, mbn_out, e, logp)
     BT, n, _ = y.shape
     if y.dim() != 3 or y.shape[2] != 3:
@@ -752,7 +756,8 @@ def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reve
     if w1x is not None and w2x is not None:
         with timed("cnf_rk4"):
             _lib.check(_lib.load().caspr_cnf_rk4_x6_f32(_p(y), _p(hyper), hyper.shape[1], _p(tcol), _p(w0), _p(b0), _p(w1x), _p(b1), _p(w2x),
-                                                        _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps), int(bool(reverse)),
+                                                        _p(b2), _p(w3), _p(b3), w0.shape[0], float(t_end), int(steps),
+                                                        int(bool(reverse)) | (CNF_NARROW if (narrow and e is None) else 0),
                                                         _p(mbn_in), _p(mbn_out), _p(e), _p(logp), _p(lp_out), _p(out), BT, n, _stream()),
                        "caspr_cnf_rk4_x6_f32")
         return out if e is None else (out, lp_out)

@@ -268,7 +268,12 @@ int caspr_cnf_rk4_f32(const float *y_in, const float *hyper, int ldh, const floa
  * In both the hidden activation never leaves the registers of its lane (accumulator fragments are the next layer's operand
  * fragments) and LDS only stages the shared weight pieces.  w1x / w2x = the (512,512) hidden weights packed by
  * caspr_pack_weight_cnf_x6 (caspr_cnf_x6_packed_bytes() bytes each: the images of both kernels); every other argument as
- * caspr_cnf_rk4_f32, including e / logp_in / logp_out (NULL together, or given together).                              */
+ * caspr_cnf_rk4_f32, including e / logp_in / logp_out (NULL together, or given together).
+ * reverse | CASPR_CNF_NARROW (sampling only): the 64-point kernel of csrc/ode_bf16x6.hip (a wave owns 16 points) instead of the
+ *   128-point one -- for launches that do not fill the chip, where a solve lasts as long as ONE workgroup does: the accuracy
+ *   guard's check solve (64 samples per frame at half the steps, models/caspr.py) takes half the time on it.  The caller's
+ *   choice, per call: never made from BT or n inside the library.                                                       */
+#define CASPR_CNF_NARROW 2
 long caspr_cnf_x6_packed_bytes(void);
 int caspr_pack_weight_cnf_x6(const float *w, int ldw, void *packed, void *stream);
 int caspr_cnf_rk4_x6_f32(const float *y_in, const float *hyper, int ldh, const float *tcol,

@@ -35,7 +35,7 @@ if big:
                                                             % (B * T * N, B * T * N * 1600 * 4 / 1e9, B * T * N * 1600 * 4 / 1e9)}
 # the fused set-abstraction launches (sa_small_kernel / sa_mlp_kernel, every instantiation): HBM-side KB per STEP = sum over the kernels
 # of (average per launch x launches per step); the passes above ran `--steps 2 --warmup 1` = 3 steps + 2 detail steps = 5 steps
-sa = [(k, v) for k, v in rows.items() if ("sa_small_kernel" in k or "sa_mlp_kernel" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+sa = [(k, v) for k, v in rows.items() if ("sa_small_kernel" in k or "sa_mlp_kernel" in k or "sa_repair_f64_kernel" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
 if sa:
     steps_run = int(os.environ.get("CASPR_PMC_STEPS", "5"))
     f = sum(v["FETCH_SIZE"]["avg"] * v["FETCH_SIZE"]["n"] for _, v in sa) / steps_run

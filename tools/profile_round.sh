@@ -9,33 +9,42 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 python $REPO/bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?" >> $OUT/${TAG}_bench.err
-rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats -d /tmp/pk -o r -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-subblock --no-sub-blocks > $OUT/${TAG}_prof_bench.json 2> /tmp/pk.err
+rm -rf /tmp/pk && rocprofv3 --kernel-trace --stats -d /tmp/pk -o r -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-f32-subblock --no-sub-blocks --no-guard-subblock > $OUT/${TAG}_prof_bench.json 2> /tmp/pk.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/pk -name "*results.db" | head -1) $OUT/${TAG}_kernel_stats.txt
 python $REPO/tools/rocprof_timeline.py $(find /tmp/pk -name "*results.db" | head -1) $OUT/${TAG}_step_timeline.txt
 : > $OUT/${TAG}_traffic_pmc.txt
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pp && rocprofv3 --kernel-trace --pmc $C -d /tmp/pp -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-sub-blocks > /dev/null 2> /tmp/pp.err
+  rm -rf /tmp/pp && rocprofv3 --kernel-trace --pmc $C -d /tmp/pp -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-sub-blocks --no-guard-subblock > /dev/null 2> /tmp/pp.err
   python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pp -name "*results.db" | head -1) /tmp/pmc_$C.txt
-  grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w|sa_mlp|sa_small|gn_partial" /tmp/pmc_$C.txt >> $OUT/${TAG}_traffic_pmc.txt
+  grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w|sa_mlp|sa_small|sa_repair|gn_partial" /tmp/pmc_$C.txt >> $OUT/${TAG}_traffic_pmc.txt
   rm -f /tmp/pmc_$C.txt
 done
-rm -rf /tmp/pm && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d /tmp/pm -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-sub-blocks > /dev/null 2> /tmp/pm.err
+rm -rf /tmp/pm && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d /tmp/pm -o r -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-sub-blocks --no-guard-subblock > /dev/null 2> /tmp/pm.err
 python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pm -name "*results.db" | head -1) /tmp/pmc_sq.txt
 grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w" /tmp/pmc_sq.txt > $OUT/${TAG}_sq_pmc.txt
 # the traffic table bench.py reads (profiles/kernel_traffic.json): cfg-2
 python $REPO/tools/make_traffic_table.py $OUT/${TAG}_traffic_pmc.txt 16x10x2048 8 ${TAG}_traffic_pmc.txt
 # cfg-5 shape (BASELINE.json configs[4], one GPU's share): 64 sequences x 20 x 4096, random clouds
 python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 3 --warmup 1 --no-f32-subblock > $OUT/${TAG}_cfg5_bench.json 2> $OUT/${TAG}_cfg5_bench.err; echo "cfg5 rc=$?" >> $OUT/${TAG}_cfg5_bench.err
-rm -rf /tmp/p5 && rocprofv3 --kernel-trace --stats -d /tmp/p5 -o r -- python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/p5.err
+rm -rf /tmp/p5 && rocprofv3 --kernel-trace --stats -d /tmp/p5 -o r -- python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-guard-subblock > /dev/null 2> /tmp/p5.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/p5 -name "*results.db" | head -1) $OUT/${TAG}_cfg5_kernel_stats.txt
 : > $OUT/${TAG}_cfg5_traffic_pmc.txt
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pq && rocprofv3 --kernel-trace --pmc $C -d /tmp/pq -o r -- python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 1 --warmup 1 --no-cpu-baseline --no-f32-subblock > /dev/null 2> /tmp/pq.err
+  rm -rf /tmp/pq && rocprofv3 --kernel-trace --pmc $C -d /tmp/pq -o r -- python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 1 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-guard-subblock > /dev/null 2> /tmp/pq.err
   python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pq -name "*results.db" | head -1) /tmp/pmq_$C.txt
   grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w" /tmp/pmq_$C.txt >> $OUT/${TAG}_cfg5_traffic_pmc.txt
   rm -f /tmp/pmq_$C.txt
 done
 python $REPO/tools/make_traffic_table.py $OUT/${TAG}_cfg5_traffic_pmc.txt 64x20x4096 8 ${TAG}_cfg5_traffic_pmc.txt
+# the stress regime's step count (S = 64: bench.py's stress_dynamics sub-block prices the same kernel at that count)
+: > $OUT/${TAG}_s64_traffic_pmc.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/ps && rocprofv3 --kernel-trace --pmc $C -d /tmp/ps -o r -- python $REPO/bench.py --cnf-steps 64 --steps 1 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-sub-blocks --no-guard-subblock > /dev/null 2> /tmp/ps.err
+  python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/ps -name "*results.db" | head -1) /tmp/pms_$C.txt
+  grep -E "counter|cnf_rk4" /tmp/pms_$C.txt >> $OUT/${TAG}_s64_traffic_pmc.txt
+  rm -f /tmp/pms_$C.txt
+done
+python $REPO/tools/make_traffic_table.py $OUT/${TAG}_s64_traffic_pmc.txt 16x10x2048 64 ${TAG}_s64_traffic_pmc.txt
 # training step (cfg-3 shard)
 python $REPO/bench_train.py --steps 3 --warmup 1 > $OUT/${TAG}_bench_train_full.json 2> $OUT/${TAG}_bench_train.err
 python $REPO/bench_train.py --steps 3 --warmup 1 --mode pretrain --no-cpu-baseline > $OUT/${TAG}_bench_train_pretrain.json 2>> $OUT/${TAG}_bench_train.err
