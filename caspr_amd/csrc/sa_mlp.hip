@@ -1059,7 +1059,8 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
             const int rk_ = CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K");
             const int wf_ = ((C1 >> 4) * a.L[0].kc + (C2 >> 4) * a.L[1].kc + (C3 >> 4) * a.L[2].kc) * 256;
             const bool small_shape = (C1 == 16 || C1 == 32) && C1 == C2 && C3 == 2 * C1;
-            if (small_shape && rk_ >= 0 && wf_ <= 7168) a.repair_kmax = ((rk_ == 0 || rk_ >= 8) && a.feat_kind != 0 && wf_ <= 4096) ? 8 : 4;
+            const int wide16 = CASPR_DEBUG_ENV_INT("CASPR_SA_WIDE_NS16_ONLY");      // experiment: 5..8 at the 16-sample scale only
+            if (small_shape && rk_ >= 0 && wf_ <= 7168) a.repair_kmax = ((rk_ == 0 || rk_ >= 8) && a.feat_kind != 0 && wf_ <= 4096 && !(wide16 && ns != 16)) ? 8 : 4;
         }
         const int cpb = 4 * (64 / ns);   // centres per 256-thread block (4 waves x 64 columns)
         dim3 grid(ceil_div(M, cpb), B);

@@ -617,6 +617,49 @@ def test_sa_mlp_max(dev, seeded_sd, model, level, scale):
     assert float(out[:, :, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("level,scale", [(0, 0), (0, 1), (1, 0)])
+def test_sa_small_balls_with_foreign_index_layouts(dev, seeded_sd, model, level, scale):
+    """The f64 re-evaluation of small balls (sa_repair_f64_kernel) and the register kernel's early exit for waves made of such balls both
+    recognise them by ball query's row layout (entry 0 the first hit, entries 1..K-1 the other hits, then copies of entry 0).  An index
+    row with ANOTHER layout -- here: the same samples shuffled behind entry 0, which is a legal input of the grouping layer
+    (pointnet2.py:340-342 takes any index tensor) -- must fall to the register kernel, not between the two: every output finite and
+    equal to the oracle's on the same rows (to the register kernel's f32 accuracy on such balls; the point is that no row is skipped
+    by both), and rows that keep the layout still get the f64 treatment (1e-5)."""
+    from caspr_amd import ops
+    sa = model.encoder.local_extract.set_abstractions[level]
+    n_in, C = [2048, 1024][level], [6, 96][level]
+    M = sa.num_points_out
+    c = clouds(2, n_in, seed=level) * [1, 1.5][level]
+    feat = rnd(level + 7, 2, n_in, C, scale=0.7)
+    idx = P.furthest_point_sampling(c, M)
+    ctr = torch.gather(c, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    g = sa.grouper_modules[scale]
+    bidx = P.ball_query(g.radius, g.num_samples, c, ctr)
+    ns = g.num_samples
+    gen = torch.Generator().manual_seed(11)
+    shuffled = torch.zeros(2, M, dtype=torch.bool)
+    for b_ in range(2):
+        for m_ in range(0, M, 3):                       # every third row: entries 1.. shuffled (entry 0 stays the reference sample)
+            perm = 1 + torch.randperm(ns - 1, generator=gen)
+            bidx[b_, m_, 1:] = bidx[b_, m_, perm]
+            shuffled[b_, m_] = True
+    grouped = P.group(c, ctr, feat.transpose(1, 2).contiguous(), bidx)
+    pre = "encoder.local_extract.set_abstractions.%d.pointnet_modules.%d" % (level, scale)
+    sd64 = {k: v.double() for k, v in seeded_sd.items() if k.startswith(pre)}
+    want64 = O.feature_extractor(sd64, pre, grouped.view(-1, C + 3, ns).double()).view(2, M, -1)
+    ldf = (C + 3) // 4 * 4
+    fpad = torch.zeros(2, n_in, ldf)
+    fpad[:, :, :C] = feat
+    out = torch.full((2, M, want64.shape[2]), float("nan"), device=dev)
+    ops.sa_mlp_max(c.to(dev), ctr.to(dev), fpad.to(dev), bidx.to(dev), C, sa.pointnet_modules[scale].kernel_layers(), out, 0)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all(), "a neighbourhood was left to neither kernel"
+    err = (got - want64).abs().amax(dim=2)
+    REPORT["sa_foreign_layout_l%d_s%d" % (level, scale)] = {"shuffled_rows_max_err": float(err[shuffled].max()), "ball_query_rows_max_err": float(err[~shuffled].max())}
+    assert float(err[shuffled].max()) <= 2e-3, float(err[shuffled].max())
+    assert float(err[~shuffled].max()) <= 1e-5, float(err[~shuffled].max())
+
+
 # ---------------------------------------------------------------------------------------------
 # latent ODE and CNF
 # ---------------------------------------------------------------------------------------------

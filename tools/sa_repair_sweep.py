@@ -53,9 +53,10 @@ def sa_ms(x):
     return tot / 3
 
 
-for rk, rk1 in (("-1", "0"), ("4", "0"), ("0", "0")):
+for rk, rk1 in (("-1", "0"), ("4", "0"), ("0", "0"), ("0", "ns16")):
     os.environ["CASPR_SA_REPAIR_K"] = rk
-    os.environ["CASPR_SA_REPAIR_K1"] = rk1
+    os.environ["CASPR_SA_REPAIR_K1"] = "0"
+    os.environ["CASPR_SA_WIDE_NS16_ONLY"] = "1" if rk1 == "ns16" else "0"
     errs = []
     for name, xx in cases.items():
         with torch.no_grad():
