@@ -54,6 +54,14 @@ def test_two_rank_rccl_bucket_and_timing(tmp_path):
     assert out.returncode == 0 and "NCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def _free_parent_cache():
+    """The pytest process may hold tens of GB in torch's caching allocator from earlier tests (cfg-3 at size: 64 GB); the ranks started
+    below share this device."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
 def _clean_env():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -63,6 +71,7 @@ def _clean_env():
 
 def _bench_two_ranks(extra):
     import json
+    _free_parent_cache()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-sub-blocks",
                           "--no-cpu-baseline", "--no-f32-subblock"] + extra, capture_output=True, text=True, timeout=900, env=_clean_env(), cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -136,14 +145,22 @@ full, loss_full = grads(x, sp, e)                                   # every rank
 lo, hi = shard_range(B, rank, world)
 mine, loss_mine = grads(x[lo:hi], sp[lo:hi], e[lo * T:hi * T], bucket_weight=hi - lo)     # the sharded step: backward + ONE RCCL all-reduce
 num = den = 0.0
+per = []
+# the bias of a conv in front of GroupNorm(16, 16) (one channel per group: the first set-abstraction scale's first two layers,
+# pointnet2.py:649-703) cannot change the output: its gradient is mathematically zero and what f32 arithmetic returns for it is rounding
+# noise of whatever order the batch was summed in (tests/test_hip_train_cfg3.py records it the same way)
+zero_grad = {"encoder.local_extract.set_abstractions.0.pointnet_modules.0.conv_layers.%d.bias" % i for i in (0, 1)}
 for n, g in full.items():
     h = mine[n]
     assert (g is None) == (h is None), "parameter %s: touched in one run only" % n
-    if g is not None:
-        num += float((g.double() - h.double()).pow(2).sum())
+    if g is not None and n not in zero_grad:
+        d2 = float((g.double() - h.double()).pow(2).sum())
+        num += d2
         den += float(g.double().pow(2).sum())
+        per.append((d2, n, float(g.double().pow(2).sum())))
 rel = (num / den) ** 0.5
-assert rel <= 2e-4, "rank %d: |sharded - global| / |global| = %.3e over the whole gradient" % (rank, rel)
+worst = ", ".join("%s %.2e of its norm" % (n, (d2 / max(g2, 1e-300)) ** 0.5) for d2, n, g2 in sorted(per, reverse=True)[:6])
+assert rel <= 2e-4, "rank %d: |sharded - global| / |global| = %.3e over the whole gradient (loss %r vs shard %r); largest contributions: %s" % (rank, rel, loss_full, loss_mine, worst)
 dist.barrier()
 torch.cuda.synchronize()
 if rank == 0:
@@ -153,6 +170,7 @@ dist.destroy_process_group()
 
 
 def _real_model_two_ranks(tmp_path, backend):
+    _free_parent_cache()
     script = tmp_path / "model_worker.py"
     script.write_text(MODEL_WORKER)
     out = subprocess.run([sys.executable, str(script), ROOT, backend], capture_output=True, text=True, timeout=900, env=_clean_env())
