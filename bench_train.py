@@ -112,6 +112,16 @@ def summarize(args, m, world=1):
     fx, ff = pipes["bf16x6"], pipes["f32_mfma"]
     roof_ms = fx[0] / (PEAK_X6 * 1e12) * 1e3 + ff[0] / (PEAK_MFMA_F32_TFLOPS * 1e12) * 1e3
 
+    # HBM-side bytes per step from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes restricted to the
+    # matrix / activation kernels by --kernel-include-regex; profiles/kernel_traffic.json), or null
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath)).get("train_matrix_kernels:%dx%dx%d" % (B, T, N))
+        if tj and full:
+            traffic = int(1024 * (tj["fetch_size_kb_per_step"] * tj["fetch_correction"] + tj["write_size_kb_per_step"]))
+            traffic_src = tj["source"]
+
     def pipe(v, peak):
         return {"flop_per_step": v[0], "launches_per_step": v[2], "kernel_ms_per_step": round(v[1], 3),
                 "achieved": round(v[0] / (v[1] * 1e-3) / 1e12, 3) if v[1] > 0 else None, "peak": round(peak, 1),
@@ -121,7 +131,8 @@ def summarize(args, m, world=1):
                 "frac": round(roof_ms / ms, 4),
                 "frac_note": "(FLOP_bf16x6 / 416.7 + FLOP_f32 / 157.3 TFLOP/s) / step time: the share of the step the matrix pipes would need at their peaks",
                 "pipes": {"bf16x6": pipe(fx, PEAK_X6), "f32_mfma": pipe(ff, PEAK_MFMA_F32_TFLOPS)},
-                "matrix_kernel_ms_per_step": round(fx[1] + ff[1], 3), "traffic": None,
+                "matrix_kernel_ms_per_step": round(fx[1] + ff[1], 3), "traffic": traffic, "traffic_unit": "bytes/step over the matrix / activation kernels of the CNF block and the convs",
+                "traffic_source": traffic_src,
                 "flop_per_step_model": flop}
     return ms, roofline
 

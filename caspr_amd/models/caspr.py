@@ -98,7 +98,7 @@ class CaSPR(nn.Module):
         super(CaSPR, self).__init__()
         # Run-time accuracy guard of the fixed-step integrators (off by default).  The reference's dopri5 controls its error at every
         # call (CNF atol = rtol = 1e-5, flow.py:96-99; latent ODE 1e-3, latent_ode_model.py:38,83); a fixed step count does not.  With
-        # check_tol set, every inference solve (reconstruct / decode / aggregate_and_solve_latent under no_grad) is repeated at half
+        # check_tol set, every inference solve (reconstruct / decode / forward / aggregate_and_solve_latent under no_grad) is repeated at half
         # the step count on `check_points` samples per frame (the latent solve: all of it, on one compute unit) on a side stream, the
         # results are compared on the device, and the Richardson estimate of the delivered solution's error is examined through
         # ops.check_deferred_errors() / at the next guarded call: CasprAccuracyError (check_action "raise") or a RuntimeWarning
@@ -149,7 +149,14 @@ class CaSPR(nn.Module):
             z = sample_feats.reshape(B * T, ode_feat_dim)
             pts = sample_points.reshape(B * T, N, 4)[:, :, :3].contiguous()                     # :112
             init_logprob = torch.zeros(B * T, N, 1, device=pts.device, dtype=pts.dtype)
+            guard = None
+            if self.check_tol is not None and pts.is_cuda and not self.training:
+                if e is None:
+                    e = torch.randn_like(pts)                                                   # what the solve would draw (odefunc.py:127-128)
+                guard = self._guard_cnf_begin(pts, z, init_logprob, e.reshape(B * T, N, -1))
             cnf_result = self.point_cnf(pts, z, init_logprob, e=e)
+            if guard is not None:
+                self._guard_cnf_end(guard, cnf_result)
             recon_loss = self.get_nll_loss(cnf_result, B, T)
             return tuple([recon_loss, tnocs_loss])
 
@@ -245,10 +252,12 @@ class CaSPR(nn.Module):
         for t_ in (z_init, sample_feats, time_tensor):
             t_.record_stream(gs)
 
-    def _guard_cnf_begin(self, y, z):
+    def _guard_cnf_begin(self, y, z, logpx=None, e=None):
         """Queue the point CNF once more on the first `check_points` samples of every frame at half (or twice) the step count on the
         guard stream, BEHIND AN EVENT RECORDED BEFORE THE MAIN SOLVE IS LAUNCHED: the check needs y and z only, so its 160 small
-        workgroups run beside the main launch instead of after it.  -> what _guard_cnf_end needs."""
+        workgroups run beside the main launch instead of after it.  -> what _guard_cnf_end needs.
+        logpx / e given: the density direction of forward() (cnf.py:70-128 with the Hutchinson divergence, same noise on the same
+        samples); otherwise the sampling direction of decode()."""
         from .cnf import CNF
         blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
         for b in blocks:               # weight packs / end time are built on first use: on the MAIN stream, before the guard stream reads them
@@ -269,12 +278,16 @@ class CaSPR(nn.Module):
             try:
                 for b in blocks:
                     b.rk4_steps, b._count_evals, b.odefunc._count_evals, b._narrow = _other_steps(b.rk4_steps)[0], False, False, g <= 64
-                xh = self.point_cnf(y[:, :g].contiguous(), z, reverse=True)
+                if logpx is None:
+                    xh = self.point_cnf(y[:, :g].contiguous(), z, reverse=True)
+                else:
+                    xh = self.point_cnf(y[:, :g].contiguous(), z, logpx[:, :g].contiguous(), e=e[:, :g].contiguous())
             finally:
                 for b, st in saved:
                     b.rk4_steps, b._count_evals, b.odefunc._count_evals, b._narrow = st, True, True, False
-        for t_ in (y, z):
-            t_.record_stream(gs)
+        for t_ in (y, z, logpx, e):
+            if t_ is not None:
+                t_.record_stream(gs)
         return {"xh": xh, "g": g, "S": S, "S2": S2, "factor": factor, "stream": gs}
 
     def _guard_cnf_end(self, ctx, x):
@@ -284,11 +297,16 @@ class CaSPR(nn.Module):
         done.record(torch.cuda.current_stream())
         with torch.cuda.stream(gs), ops.untimed():
             gs.wait_event(done)
-            diff = (x[:, :g] - ctx["xh"]).abs().amax()
-            ops.guard_track(diff, x[:, :g].abs().amax(), {"name": "cnf", "tol": float(self.check_tol), "factor": ctx["factor"], "steps": ctx["S"],
-                                                          "other_steps": ctx["S2"], "action": self.check_action,
-                                                          "what": "point CNF (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"})
-        x.record_stream(gs)
+            meta = {"tol": float(self.check_tol), "factor": ctx["factor"], "steps": ctx["S"], "other_steps": ctx["S2"], "action": self.check_action}
+            if torch.is_tensor(x):
+                diff = (x[:, :g] - ctx["xh"]).abs().amax()
+                ops.guard_track(diff, x[:, :g].abs().amax(), dict(meta, name="cnf", what="point CNF (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"))
+            else:               # density direction: the state is (y, logp), both integrated (cnf.py:112-126)
+                for i, (nm, what) in enumerate((("cnf_fwd_y", "point CNF, density direction, y"), ("cnf_fwd_logp", "point CNF, density direction, log-density"))):
+                    diff = (x[i][:, :g] - ctx["xh"][i]).abs().amax()
+                    ops.guard_track(diff, x[i][:, :g].abs().amax(), dict(meta, name=nm, what=what + " (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"))
+        for t_ in ((x,) if torch.is_tensor(x) else x):
+            t_.record_stream(gs)
 
     def gen_latent(self, z0, timestamps):
         """caspr.py:185-196."""

@@ -1553,6 +1553,27 @@ def test_accuracy_guard(dev, seeded_sd, stress_sd):
         ops.check_deferred_errors()
     ops.check_deferred_errors()                                             # drain whatever the interrupted call had queued behind it
     REPORT["accuracy_guard_stress_latent_2"] = dict(ops.GUARD_LAST)
+    # --- the density direction (forward(): y AND the log-density are integrated, cnf.py:112-126): quiet on seeded weights with the same
+    # loss values as without the guard, raises on the stress weights at S = 8
+    ops.reset_guard()
+    sp_ = sp.to(dev)
+    e_ = torch.randn(2 * 4, 1024, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    m.check_tol = 1e-5
+    nll_g, tl_g = m(x.to(dev), sp_, e=e_)
+    ops.check_deferred_errors()
+    rep = dict(ops.GUARD_LAST)
+    assert rep["cnf_fwd_y"]["ok"] and rep["cnf_fwd_logp"]["ok"] and rep["latent"]["ok"], rep
+    m.check_tol = None
+    nll_r, tl_r = m(x.to(dev), sp_, e=e_)
+    exact("guard_does_not_change_nll", nll_g, nll_r)
+    REPORT["accuracy_guard_forward_seeded"] = rep
+    ops.reset_guard()
+    ms.check_tol, ms.check_action = 1e-5, "raise"
+    with pytest.raises(ops.CasprAccuracyError, match="density direction"):
+        ms(x.to(dev), sp_, e=e_)
+        ops.check_deferred_errors()
+    ops.check_deferred_errors()
+    REPORT["accuracy_guard_forward_stress_8"] = dict(ops.GUARD_LAST)
     # --- calibrated counts: quiet
     ops.reset_guard()
     mc = model(stress_sd, cnf_rk4_steps=64, latent_rk4_steps=16, check_tol=1e-5)

@@ -42,5 +42,16 @@ if sa:
     w = sum(v["WRITE_SIZE"]["avg"] * v["WRITE_SIZE"]["n"] for _, v in sa) / steps_run
     tab["sa_all:%s" % wl] = {"fetch_size_kb_per_step": f, "write_size_kb_per_step": w, "fetch_correction": 2.0, "launches_counted": sum(v["FETCH_SIZE"]["n"] for _, v in sa),
                              "steps_in_the_pass": steps_run, "source": "profiles/%s" % committed, "note": note + "; all fused set-abstraction launches of one step together"}
+# training step (tools/profile_round.sh: counters collected for the matrix / activation kernels of the CNF block and the convs only,
+# --kernel-include-regex; `bench_train.py --steps 1 --warmup 1` = 3 steps with the detail pass): HBM-side KB per STEP over those kernels
+if os.environ.get("CASPR_PMC_TRAIN"):
+    steps_run = int(os.environ.get("CASPR_PMC_STEPS", "3"))
+    ok = [(k, v) for k, v in rows.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+    if ok:
+        tab["train_matrix_kernels:%s" % wl] = {"fetch_size_kb_per_step": sum(v["FETCH_SIZE"]["avg"] * v["FETCH_SIZE"]["n"] for _, v in ok) / steps_run,
+                                               "write_size_kb_per_step": sum(v["WRITE_SIZE"]["avg"] * v["WRITE_SIZE"]["n"] for _, v in ok) / steps_run,
+                                               "fetch_correction": 2.0, "launches_counted": sum(v["FETCH_SIZE"]["n"] for _, v in ok), "steps_in_the_pass": steps_run,
+                                               "kernels": sorted(k[:60] for k, _ in ok), "source": "profiles/%s" % committed,
+                                               "note": note.replace("bench.py --steps 2 --warmup 1", "bench_train.py --steps 1 --warmup 1 --no-cpu-baseline") + "; only the kernels listed (rocprofv3 --kernel-include-regex): a counter pass over all ~4,000 launches of a step does not finish in the box's time"}
 json.dump(tab, open(path, "w"), indent=1, sort_keys=True)
 print("wrote %s: %s" % (path, sorted(tab)))

@@ -50,6 +50,15 @@ python $REPO/bench_train.py --steps 3 --warmup 1 > $OUT/${TAG}_bench_train_full.
 python $REPO/bench_train.py --steps 3 --warmup 1 --mode pretrain --no-cpu-baseline > $OUT/${TAG}_bench_train_pretrain.json 2>> $OUT/${TAG}_bench_train.err
 rm -rf /tmp/pt && rocprofv3 --kernel-trace --stats -d /tmp/pt -o r -- python $REPO/bench_train.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/pt.err
 python $REPO/tools/rocprof_summary.py $(find /tmp/pt -name "*results.db" | head -1) $OUT/${TAG}_train_full_kernel_stats.txt
+# HBM-side traffic of the training step's matrix / activation kernels (a counter pass over ALL ~4,000 launches of a step does not finish)
+: > $OUT/${TAG}_train_traffic_pmc.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pz && timeout 900 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "conv1x1_bf16x6_kernel|conv1x1_wgrad_bf16x6_kernel|conv1x1_x6w_kernel|cnf_act_bwd_kernel|cnf_in_.*_rows_kernel|conv1x1_stream_kernel" -d /tmp/pz -o r -- python $REPO/bench_train.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/pz.err
+  python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pz -name "*results.db" | head -1) /tmp/pmz_$C.txt
+  grep -E "counter|conv1x1|cnf_" /tmp/pmz_$C.txt >> $OUT/${TAG}_train_traffic_pmc.txt
+  rm -f /tmp/pmz_$C.txt
+done
+CASPR_PMC_TRAIN=1 python $REPO/tools/make_traffic_table.py $OUT/${TAG}_train_traffic_pmc.txt 8x10x1024 8 ${TAG}_train_traffic_pmc.txt
 # the CNF kernel alone (kernel stats + SQ counters) and the two micro-benchmarks behind DESIGN.md's power / filler discussion
 (cd $REPO && bash tools/profile_cnf.sh ${TAG} > /dev/null 2>&1)
 [ -x $REPO/tools/micro/mfma_power ] && $REPO/tools/micro/mfma_power > $OUT/${TAG}_mfma_power.txt 2>&1
