@@ -61,6 +61,7 @@ class _EarlyLatent:
 
 
 # the latent solve beside the encoder's last layer (config.early_latent = False: in front of the flow, as in rounds 1-3)
+JOIN_TNOCS_LATE = True        # reconstruct(): join the deferred T-NOCS regression behind the flow's launch (False: in front of it, rounds 2-4)
 EARLY_LATENT = _cfg.early_latent
 EARLY_LATENT_TEAM = _cfg.early_latent_team
 _EARLY_STREAM = {}
@@ -441,10 +442,14 @@ class CaSPR(nn.Module):
             with ops.timed("latent"):
                 z = self.aggregate_and_solve_latent(z0, all_times, plan, early_lat)
             self._early_latent_used = bool(early_lat is not None and early_lat.event is not None)     # for tests / tools
-            if defer:
+            if defer and not JOIN_TNOCS_LATE:
                 self.encoder.join()
             with ops.timed("decode"):
                 y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y, _early=early)
+            if defer and JOIN_TNOCS_LATE:
+                # the T-NOCS regression (a 0.5 ms HBM-bound conv on the side stream) is joined BEHIND the flow's launch, not in front of
+                # it: nothing of the flow reads it, and its workgroups drain while the flow's first ones start
+                self.encoder.join()
             return y, logp_y, x, tnocs_pred
 
     def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16, 32, 64, 128), num_points=512, timestamps=None, max_timestamp=5.0,

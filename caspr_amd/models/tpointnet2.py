@@ -17,6 +17,9 @@ from .pointnet import PointNetfeat
 from .pointnet2 import PointNet2feat as PointNet2
 
 
+TAIL_BESIDE = True     # the last head layer's 64-channel remainder on the early solve's stream / compute units (ops.conv1x1_gn_early)
+
+
 def _tensors(obj):
     if torch.is_tensor(obj):
         yield obj
@@ -176,7 +179,8 @@ class TPointNet2(nn.Module):
                                         in_shift=in_shift, in_relu=True, in_relu_from=L)
         if early is not None and self.record is None and ops.conv1x1_gn_early_ok(p2, B, P, 16, early.channels):
             y2, s2, t2, z0 = ops.conv1x1_gn_early(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, early, in_scale=s1, in_shift=t1,
-                                                  in_relu=True, reserve_cus=early.reserve_cus(B))   # :99-100, 111
+                                                  in_relu=True, reserve_cus=early.reserve_cus(B),
+                                                  tail_stream=early.stream if TAIL_BESIDE else None)   # :99-100, 111
         else:
             y2, s2, t2, z0 = ops.conv1x1_gn(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, want_max=True,
                                             in_scale=s1, in_shift=t1, in_relu=True)               # :99-100, 111

@@ -475,12 +475,16 @@ def conv1x1_gn_early_ok(pw, B, P, groups, early_channels):
 
 
 def conv1x1_gn_early(pw, bias, x, gamma, beta, on_early, groups=16, eps=1e-5, in_scale=None, in_shift=None, in_relu=False, in_relu_from=0,
-                     reserve_cus=1):
+                     reserve_cus=1, tail_stream=None):
     """conv1x1_gn(..., want_max=True) in two pieces (caspr_conv1x1_x6w_part_f32 / caspr_conv_gn_finalize_f32): after the FIRST 512-channel
     tile the statistics of GroupNorm group 0 are final -- `on_early(pmax)` is called with the (B, C) max-over-points tensor whose
     group-0 columns are valid, on the current stream, and may queue work on another stream behind an event (the latent solve: it
     starts from pmax[:, :64], caspr.py:169) -- then the remaining tiles run on all but `reserve_cus` compute units, and the full
-    finalize follows.  Returns (y, scale, shift, pmax) with the values of conv1x1_gn, bit for bit."""
+    finalize follows.  Returns (y, scale, shift, pmax) with the values of conv1x1_gn, bit for bit.
+    tail_stream: the stream on_early queued its work on.  The < 512-channel remainder of the layer (a pass of its own kind over the whole
+    input, bound by reading it once: 0.6 ms at cfg-2) is then queued THERE, behind that work, instead of behind the main tiles: the
+    compute units reserved for the early kernel are free again long before the main tiles finish (the solve takes 2.6 of their 4.8 ms),
+    and the remainder runs on them beside the tiles instead of after them."""
     _chk_f32(bias, in_scale, in_shift, gamma, beta)
     B, P, _ = x.shape
     C = pw.cout
@@ -510,7 +514,22 @@ def conv1x1_gn_early(pw, bias, x, gamma, beta, on_early, groups=16, eps=1e-5, in
         part(0, 1, False, 0)
         finalize(0, 1)
         on_early(pmax)
-        part(1, mt_all, True, reserve_cus)
+        if tail_stream is not None and tail is not None and reserve_cus > 0:
+            main_stream = torch.cuda.current_stream()
+            issued = torch.cuda.Event()
+            issued.record(main_stream)               # the remainder reads x and writes its own columns of y / of the partials: nothing of tile 0's
+            with torch.cuda.stream(tail_stream):
+                tail_stream.wait_event(issued)
+                part(mt_all, mt_all, True, 0)        # the remainder only, behind whatever on_early queued on that stream
+                tail_done = torch.cuda.Event()
+                tail_done.record(tail_stream)
+            part(1, mt_all, False, reserve_cus)
+            main_stream.wait_event(tail_done)
+            for t_ in (x, y, ws, in_scale, in_shift):
+                if t_ is not None:
+                    t_.record_stream(tail_stream)
+        else:
+            part(1, mt_all, True, reserve_cus)
         finalize(1, groups)         # group 0 is final already (and the side stream may be reading its pmax / scale / shift right now)
     return y, scale, shift, pmax
 
