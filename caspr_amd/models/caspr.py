@@ -444,8 +444,13 @@ class CaSPR(nn.Module):
             self._early_latent_used = bool(early_lat is not None and early_lat.event is not None)     # for tests / tools
             if defer and not JOIN_TNOCS_LATE:
                 self.encoder.join()
-            with ops.timed("decode"):
-                y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y, _early=early)
+            if defer and JOIN_TNOCS_LATE:
+                ops.BEFORE_CNF_LAUNCH = self.encoder.launch_tnocs        # queued between the flow's hyper conv and the flow (tpointnet2.py)
+            try:
+                with ops.timed("decode"):
+                    y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y, _early=early)
+            finally:
+                ops.BEFORE_CNF_LAUNCH = None
             if defer and JOIN_TNOCS_LATE:
                 # the T-NOCS regression (a 0.5 ms HBM-bound conv on the side stream) is joined BEHIND the flow's launch, not in front of
                 # it: nothing of the flow reads it, and its workgroups drain while the flow's first ones start

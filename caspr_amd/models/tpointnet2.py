@@ -17,6 +17,11 @@ from .pointnet import PointNetfeat
 from .pointnet2 import PointNet2feat as PointNet2
 
 
+# True: the deferred T-NOCS regression is queued only when the caller says (reconstruct(): right in front of the flow's launch, through
+# ops.BEFORE_CNF_LAUNCH) instead of behind the head's last layer.  Measured and NOT adopted (tools/head_ab.py, profiles/r05_head_ab.txt): queued
+# early, this HBM-bound conv holds back the three small kernels the flow waits for (0.7 ms between the encoder's last statistics and the flow's
+# first workgroup) -- but queued late it runs entirely in front of the flow: 69.64 -> 69.97 ms.  Early it is.
+LATE_TNOCS_LAUNCH = False
 TAIL_BESIDE = True     # the last head layer's 64-channel remainder on the early solve's stream / compute units (ops.conv1x1_gn_early)
 
 
@@ -101,9 +106,29 @@ class TPointNet2(nn.Module):
                                  lambda: ops.PackedWeight(self.conv3.weight.detach()[:, :, 0].contiguous()))
         return p1, p2, p3
 
+    def launch_tnocs(self):
+        """Queue the T-NOCS regression that forward(x, defer_tnocs=True) prepared (:105-106) on the side stream, behind everything the
+        current stream holds NOW.  reconstruct() calls it through ops.BEFORE_CNF_LAUNCH, i.e. between the flow's hyper-network conv and the
+        flow's launch: queued earlier, this HBM-bound conv (2,560 workgroups on every compute unit for 0.5 ms) held back the three small
+        kernels the flow waits for -- a 1 MB cat took 166 us, the hyper conv 105 us, 0.2 ms of nothing in front of them."""
+        pend = getattr(self, "_tnocs_pending", None)
+        if pend is None:
+            return
+        self._tnocs_pending = None
+        p3, y2, s2, t2, out, side = pend
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1, out=out)  # :105-106
+            self._tnocs_ready = torch.cuda.Event()
+            self._tnocs_ready.record()
+        for t_ in (y2, s2, t2, out):
+            t_.record_stream(side)          # main-stream allocations the side stream still reads / writes
+
     def join(self):
-        """Make the current stream wait for a T-NOCS regression that forward(x, defer_tnocs=True) left running on the side
-        stream.  No-op when nothing is pending."""
+        """Make the current stream wait for a T-NOCS regression that forward(x, defer_tnocs=True) left to the side stream (queueing it
+        now if nobody has).  No-op when nothing is pending."""
+        self.launch_tnocs()
         ev = getattr(self, "_tnocs_ready", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -187,14 +212,11 @@ class TPointNet2(nn.Module):
         del y1
         tnocs_regression = None
         if self.regress_tnocs and defer_tnocs and self.record is None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                t = ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1)  # :105-106
-                self._tnocs_ready = torch.cuda.Event()
-                self._tnocs_ready.record()
-            for t_ in (y2, s2, t2):
-                t_.record_stream(side)          # main-stream allocations the side stream still reads
-            t.record_stream(main)
+            # prepared here, queued by launch_tnocs() (the caller's choice of moment; join() at the latest)
+            t = torch.empty(B, P, (p3.cout + 3) // 4 * 4, device=x.device, dtype=torch.float32)
+            self._tnocs_pending = (p3, y2, s2, t2, t, side)
+            if not LATE_TNOCS_LAUNCH:
+                self.launch_tnocs()
             tnocs_regression = t[:, :, :self.tnocs_point_size].reshape(B, T, N, self.tnocs_point_size)
         elif self.regress_tnocs:
             t = ops.conv1x1(p3, self.conv3.bias, y2, in_scale=s2, in_shift=t2, in_relu=True, act=1)  # :105-106

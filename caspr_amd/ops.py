@@ -750,6 +750,8 @@ def pack_cnf_x6(w):
 
 
 CNF_NARROW = 2        # include/caspr_hip.h: CASPR_CNF_NARROW
+BEFORE_CNF_LAUNCH = None      # one-shot callable run between a CNF block's hyper-network conv and its launch (models/cnf.py: CNF.integrate);
+                              # reconstruct() hands the encoder's deferred T-NOCS regression to it
 
 
 def cnf_rk4(y, hyper, tcol, w0, b0, w1p, b1, w2p, b2, w3, b3, t_end, steps, reverse, mbn_in=None, mbn_out=None,

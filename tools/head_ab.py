@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B in one process on one box: the last head layer's 64-channel remainder beside the main tiles (models/tpointnet2.py: TAIL_BESIDE) and the
-T-NOCS regression joined behind the flow's launch (models/caspr.py: JOIN_TNOCS_LATE); cfg-2 reconstruct(), 10 steps each, 3 rounds; outputs
+T-NOCS regression joined behind the flow's launch (models/caspr.py: JOIN_TNOCS_LATE) and queued right in front of it (models/tpointnet2.py: LATE_TNOCS_LAUNCH); cfg-2 reconstruct(), 10 steps each, 3 rounds; outputs
 compared bit for bit with the serial order.   (GPU)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -34,10 +34,11 @@ def run(k=10):
 
 ref = None
 for rnd in range(3):
-    for tail, late in ((False, False), (True, False), (False, True), (True, True)):
-        TP.TAIL_BESIDE, C.JOIN_TNOCS_LATE = tail, late
+    for tail, late, launch in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+        TP.TAIL_BESIDE, C.JOIN_TNOCS_LATE, TP.LATE_TNOCS_LAUNCH = tail, late, launch
         el, o = run()
         if ref is None:
             ref = o
         same = torch.equal(o[2], ref[2]) and torch.equal(o[3], ref[3])
-        print("round %d  remainder beside the tiles %-5s  T-NOCS joined late %-5s : step %.2f ms   outputs %s" % (rnd, tail, late, el, "identical" if same else "DIFFER"), flush=True)
+        print("round %d  remainder beside the tiles %-5s  T-NOCS joined late %-5s  queued in front of the flow's launch %-5s : step %.2f ms   outputs %s"
+              % (rnd, tail, late, launch, el, "identical" if same else "DIFFER"), flush=True)
