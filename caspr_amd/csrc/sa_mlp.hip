@@ -25,6 +25,7 @@ struct SaArgs {
     int feat_kind;     // CASPR_FEAT_QUAD | CASPR_FEAT_PAIRS: feat = quadratic augmentation of xyz (caspr_prep_input_f32)
     int lo_in, lo_out; // CASPR_FEAT_LO_IN: feat rows carry low parts at column ldf / 2; CASPR_FEAT_LO_OUT: the low part of the output goes to column ldo / 2 + out_off
     int repair_kmax;   // balls of 1 .. repair_kmax distinct samples are evaluated by sa_repair_f64_kernel behind the register kernel (0: none)
+    const int32_t *order, *count;   // the register kernel's list of the OTHER balls, per cloud (sa_list_kernel); NULL: every ball, in order
     SaLayer L[3];
     float *out;
     int ldo, out_off;
@@ -358,8 +359,9 @@ __device__ __forceinline__ void sa_window_sync()
 #endif
 }
 
+// mcen[cen]: the neighbourhood (centre index) of this wave's centre slot cen, -1 for an empty slot (wave-uniform): see sa_small_entry
 template <int NS, int C1, int C2, int C3>
-__device__ __forceinline__ void sa_small_body(const SaArgs &a)
+__device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)[64 / NS])
 {
     constexpr int CT = 4;                 // 64 columns per wave
     constexpr int TPC = NS / 16;          // column tiles per centre
@@ -368,8 +370,6 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
     const int b = blockIdx.y;
-    const int m0 = (blockIdx.x * 4 + wave) * NCEN;
-    if (m0 >= a.M) return;                // wave-uniform; no barriers in this kernel
     // the wave's own LDS window of the f64 reference column: a_0 of the layer input [centre][k], mu of the layer output [row tile][centre][row]
     __shared__ double s_a0[4][4][64], s_mu[4][4][4][16];
     double (&a0s)[4][64] = s_a0[wave];
@@ -389,8 +389,8 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int cen = ct / TPC;
-        const int m = (m0 + cen) < a.M ? (m0 + cen) : (a.M - 1);
-        cval[ct] = (m0 + cen) < a.M;
+        cval[ct] = mcen[cen] >= 0;
+        const int m = cval[ct] ? mcen[cen] : mcen[0];      // an empty slot computes slot 0's neighbourhood once more and stores nothing
         const int s = (ct % TPC) * 16 + j;
         nrow[ct] = a.idx[((long)b * a.M + m) * NS + s];
         const float *c = a.new_xyz + ((long)b * a.M + m) * 3;
@@ -401,24 +401,6 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
     int rrow[NCEN];
 #pragma unroll
     for (int cen = 0; cen < NCEN; ++cen) rrow[cen] = __builtin_amdgcn_readlane(nrow[cen * TPC], 0);
-    // Balls of 1 .. repair_kmax distinct samples are evaluated in f64 by sa_repair_f64_kernel behind this kernel, which overwrites
-    // whatever is stored here: a wave ALL of whose centres are such balls has nothing to contribute (on sparse clouds that is most
-    // waves of the first level's small scale).  The test is sa_row_distinct's, on the same index rows: the samples that differ from
-    // sample 0 occupy exactly the positions 1 .. K - 1 (ball query's layout).  Wave-uniform.
-    if (a.repair_kmax > 0) {
-        bool all_small = true;
-#pragma unroll
-        for (int cen = 0; cen < NCEN; ++cen) {
-            unsigned long long diff = 0ull;
-#pragma unroll
-            for (int t = 0; t < TPC; ++t)
-                diff |= (__builtin_amdgcn_ballot_w64(nrow[cen * TPC + t] != rrow[cen]) & 0xFFFFull) << (16 * t);      // lanes g = 0: samples 16 t + j
-            const int K = __builtin_popcountll(diff) + 1;
-            const bool layout = diff == ((1ull << K) - 2ull);
-            all_small = all_small && (!cval[cen * TPC] || (layout && K <= a.repair_kmax));
-        }
-        if (all_small) return;
-    }
     const bool refl = j == 0;                   // column 0 of a neighbourhood's first tile carries its reference (sample 0, absolute)
     SA_STAMP(1)
 
@@ -637,8 +619,8 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
                     }
                 }
                 if (FINAL && refl && cval[cen * TPC]) {
-                    st4(a.out + ((long)b * a.M + m0 + cen) * a.ldo + a.out_off + rt * 16 + 4 * g, mx);
-                    if (a.lo_out) st4(a.out + ((long)b * a.M + m0 + cen) * a.ldo + (a.ldo >> 1) + a.out_off + rt * 16 + 4 * g, mlo);
+                    st4(a.out + ((long)b * a.M + mcen[cen]) * a.ldo + a.out_off + rt * 16 + 4 * g, mx);
+                    if (a.lo_out) st4(a.out + ((long)b * a.M + mcen[cen]) * a.ldo + (a.ldo >> 1) + a.out_off + rt * 16 + 4 * g, mlo);
                 }
             }
         }
@@ -706,12 +688,84 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a)
     SA_STAMP(8)
 }
 
+// WHICH NEIGHBOURHOODS THE REGISTER KERNEL COMPUTES.  With the f64 re-evaluation behind it (repair_kmax > 0) every neighbourhood of
+// 1 .. repair_kmax distinct samples is overwritten by sa_repair_f64_kernel; round 5 skipped a wave only when ALL of its centres were such
+// balls (most waves of the first level's 16-sample scale, few elsewhere).  Now sa_list_kernel lists, per cloud and in ascending order,
+// the neighbourhoods that kernel will NOT overwrite -- more than repair_kmax distinct samples, or an index row that is not in ball
+// query's layout: the very test of sa_row_distinct -- into the caller's workspace (a.order: B x M entries, a.count: B), and the register
+// kernel's waves take their centres from that list: no MFMA runs for a result the f64 kernel replaces (29 % of the first level's
+// 32-sample scale, 25 % of the second level's 16-sample scale on the car clouds).  A neighbourhood's arithmetic does not depend on the
+// slot it is computed in, so the outputs are the same bits as with the identity list (test_sa_register_kernel_is_slot_invariant).
+// (A list per WORKGROUP, surveyed inside the kernel, was measured first: the partial last round of a 32-ball span and the loop's
+// registers -- 168 -> 194 -- gave back more than the skipped balls saved on the second level.)
+__global__ __launch_bounds__(1024) void sa_list_kernel(const int32_t *__restrict__ idx, int M, int ns, int kmax, int32_t *__restrict__ order,
+                                                       int32_t *__restrict__ count)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int m0 = 0; m0 < M; m0 += 1024) {
+        const int m = m0 + tid;
+        bool big = false;
+        if (m < M) {
+            const int32_t *row = idx + ((long)b * M + m) * ns;
+            const int first = row[0];
+            unsigned diff = 0u;
+            for (int q = 0; q < ns; q += 4) {
+                const int4 v = *reinterpret_cast<const int4 *>(row + q);
+                diff |= (v.x != first ? 1u : 0u) << q;
+                diff |= (v.y != first ? 2u : 0u) << q;
+                diff |= (v.z != first ? 4u : 0u) << q;
+                diff |= (v.w != first ? 8u : 0u) << q;
+            }
+            const int K = __builtin_popcount(diff) + 1;
+            const bool layout = diff == (unsigned)((1ull << K) - 2ull);      // the other hits occupy exactly the entries 1 .. K - 1
+            big = !(layout && K <= kmax);
+        }
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(big);
+        if (lane == 0) s_wave[wave] = __builtin_popcountll(mk);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (big) order[(long)b * M + off + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = m;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += s_wave[w];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) count[b] = s_base;
+}
+
 template <int NS, int C1, int C2, int C3>
-__global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
+__device__ __forceinline__ void sa_small_entry(const SaArgs &a)
+{
+    constexpr int NCEN = 64 / NS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int slot0 = (blockIdx.x * 4 + wave) * NCEN;
+    const int n = a.order ? a.count[b] : a.M;
+    if (slot0 >= n) return;               // wave-uniform; no barriers in this kernel
+    int mcen[NCEN];
+#pragma unroll
+    for (int cen = 0; cen < NCEN; ++cen) {
+        const int at = slot0 + cen < n ? slot0 + cen : slot0;
+        const int m = a.order ? a.order[(long)b * a.M + at] : at;
+        mcen[cen] = slot0 + cen < n ? __builtin_amdgcn_readfirstlane(m) : -1;
+    }
+    sa_small_body<NS, C1, C2, C3>(a, mcen);
+}
+
 template <int NS, int C1, int C2, int C3>
-__global__ __launch_bounds__(256, 2) void sa_small_kernel_w2(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
+__global__ __launch_bounds__(256) void sa_small_kernel(SaArgs a) { sa_small_entry<NS, C1, C2, C3>(a); }
 template <int NS, int C1, int C2, int C3>
-__global__ __launch_bounds__(256, 3) void sa_small_kernel_w3(SaArgs a) { sa_small_body<NS, C1, C2, C3>(a); }
+__global__ __launch_bounds__(256, 2) void sa_small_kernel_w2(SaArgs a) { sa_small_entry<NS, C1, C2, C3>(a); }
+template <int NS, int C1, int C2, int C3>
+__global__ __launch_bounds__(256, 3) void sa_small_kernel_w3(SaArgs a) { sa_small_entry<NS, C1, C2, C3>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // SMALL NEIGHBOURHOODS IN f64 (round 5).  What the centred form with an f64 reference column could not reach: a ball that holds 2..4
@@ -1014,12 +1068,12 @@ static unsigned long long *g_sa_trace = nullptr;
 extern "C" void caspr_debug_set_sa_trace(unsigned long long *dev_buf) { g_sa_trace = dev_buf; }   // debug build only
 #endif
 
-extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
-                                    const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind, const float *w1p,
-                                    const float *b1, const float *g1, const float *be1, int C1, const float *w2p,
-                                    const float *b2, const float *g2, const float *be2, int C2, const float *w3p,
-                                    const float *b3, const float *g3, const float *be3, int C3, float *out, int ldo,
-                                    int out_off, void *stream)
+static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                           const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind, const float *w1p,
+                           const float *b1, const float *g1, const float *be1, int C1, const float *w2p,
+                           const float *b2, const float *g2, const float *be2, int C2, const float *w3p,
+                           const float *b3, const float *g3, const float *be3, int C3, float *out, int ldo,
+                           int out_off, int32_t *workspace, void *stream)
 {
     CASPR_REQUIRE(xyz && new_xyz && idx && out && w1p && w2p && w3p && b1 && b2 && b3 && g1 && g2 && g3 && be1 && be2 && be3,
                   "sa_mlp_max: null pointer");
@@ -1064,6 +1118,14 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
         }
         const int cpb = 4 * (64 / ns);   // centres per 256-thread block (4 waves x 64 columns)
         dim3 grid(ceil_div(M, cpb), B);
+        const bool small_shape_ = (C1 == 16 || C1 == 32) && C1 == C2 && C3 == 2 * C1;
+        a.order = a.count = nullptr;
+        if (workspace && a.repair_kmax > 0 && small_shape_ && !CASPR_DEBUG_ENV_INT("CASPR_SA_NO_LIST")) {
+            // the neighbourhoods the f64 kernel will not overwrite, listed per cloud: the register kernel computes those only (sa_list_kernel)
+            sa_list_kernel<<<dim3(B), dim3(1024), 0, st>>>(idx, M, ns, a.repair_kmax, workspace + B, workspace);
+            a.order = workspace + B;
+            a.count = workspace;
+        }
         bool done = true;
         if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 16) sa_small_kernel_w3<16, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
         else if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 32) sa_small_kernel_w3<32, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
@@ -1109,4 +1171,28 @@ extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, cons
     if (rc != CASPR_OK) return rc;
     CASPR_CHECK_LAUNCH("sa_mlp_max");
     return CASPR_OK;
+}
+
+extern "C" int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                                    const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind, const float *w1p,
+                                    const float *b1, const float *g1, const float *be1, int C1, const float *w2p,
+                                    const float *b2, const float *g2, const float *be2, int C2, const float *w3p,
+                                    const float *b3, const float *g3, const float *be3, int C3, float *out, int ldo,
+                                    int out_off, void *stream)
+{
+    return sa_mlp_max_impl(xyz, new_xyz, feat, ldf, idx, B, n, M, C, ns, feat_kind, w1p, b1, g1, be1, C1, w2p, b2, g2, be2, C2, w3p, b3, g3,
+                           be3, C3, out, ldo, out_off, nullptr, stream);
+}
+
+extern "C" long caspr_sa_mlp_max_workspace_ints(int B, int M) { return (long)B * ((long)M + 1); }
+
+extern "C" int caspr_sa_mlp_max_ws_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                                       const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind, const float *w1p,
+                                       const float *b1, const float *g1, const float *be1, int C1, const float *w2p,
+                                       const float *b2, const float *g2, const float *be2, int C2, const float *w3p,
+                                       const float *b3, const float *g3, const float *be3, int C3, float *out, int ldo,
+                                       int out_off, int32_t *workspace, void *stream)
+{
+    return sa_mlp_max_impl(xyz, new_xyz, feat, ldf, idx, B, n, M, C, ns, feat_kind, w1p, b1, g1, be1, C1, w2p, b2, g2, be2, C2, w3p, b3, g3,
+                           be3, C3, out, ldo, out_off, workspace, stream);
 }

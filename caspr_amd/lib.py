@@ -30,6 +30,12 @@ SIGNATURES = {
                                      c_fp, c_fp, c_fp, c_fp, c_int,
                                      c_fp, c_fp, c_fp, c_fp, c_int,
                                      c_fp, c_int, c_int, c_stream]),
+    "caspr_sa_mlp_max_workspace_ints": (c_long, [c_int, c_int]),
+    "caspr_sa_mlp_max_ws_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_fp, c_fp, c_fp, c_fp, c_int,
+                                        c_fp, c_fp, c_fp, c_fp, c_int,
+                                        c_fp, c_fp, c_fp, c_fp, c_int,
+                                        c_fp, c_int, c_int, c_ip, c_stream]),
     "caspr_three_nn_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_ip, c_fp, c_stream]),
     "caspr_three_interp_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_packed_size": (c_long, [c_int, c_int]),

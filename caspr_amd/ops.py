@@ -555,8 +555,13 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0):
     # 2 FLOP per multiply-add of the three layers over every gathered sample (C + 3 input channels: xyz first)
     flop = 2.0 * B * M * ns * ((C + 3) * layers[0][0].cout + layers[0][0].cout * layers[1][0].cout + layers[1][0].cout * layers[2][0].cout)
     with timed("k:sa_mlp_max:%d:%d:%d:%d" % (C + 3, layers[2][0].cout, B * M * ns, int(flop // 1000000)), 2):
-        _lib.check(_lib.load().caspr_sa_mlp_max_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, int(feat_kind), *args,
-                                                    _p(out), out.shape[2], out_off, _stream()), "caspr_sa_mlp_max_f32")
+        # scratch for the register kernel's list of the neighbourhoods the f64 re-evaluation leaves to it (include/caspr_hip.h); the
+        # wider shapes take the LDS kernel and no scratch
+        ws = None
+        if max(l_[0].cout for l_ in layers) <= 64:
+            ws = torch.empty(_lib.load().caspr_sa_mlp_max_workspace_ints(B, M), dtype=torch.int32, device=xyz.device)
+        _lib.check(_lib.load().caspr_sa_mlp_max_ws_f32(_p(xyz), _p(new_xyz), _p(feat), ldf, _p(idx), B, n, M, C, ns, int(feat_kind), *args,
+                                                       _p(out), out.shape[2], out_off, _p(ws), _stream()), "caspr_sa_mlp_max_ws_f32")
     return out
 
 

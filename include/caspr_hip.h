@@ -95,6 +95,17 @@ int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *fe
                          const float *w2p, const float *b2, const float *g2, const float *be2, int C2,
                          const float *w3p, const float *b3, const float *g3, const float *be3, int C3,
                          float *out, int ldo, int out_off, void *stream);
+/* The same call with a scratch of caspr_sa_mlp_max_workspace_ints(B, M) 32-bit integers (device memory, contents irrelevant on entry,
+ * undefined on return; must stay valid until the call's kernels have run on `stream`).  On the register kernel's shapes (all widths
+ * <= 64) the neighbourhoods whose result the f64 re-evaluation of small balls replaces anyway are listed there first and the MFMA
+ * kernel computes only the others -- same outputs, bit for bit (a NULL workspace = caspr_sa_mlp_max_f32).                          */
+long caspr_sa_mlp_max_workspace_ints(int B, int M);
+int caspr_sa_mlp_max_ws_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
+                            const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind,
+                            const float *w1p, const float *b1, const float *g1, const float *be1, int C1,
+                            const float *w2p, const float *b2, const float *g2, const float *be2, int C2,
+                            const float *w3p, const float *b3, const float *g3, const float *be3, int C3,
+                            float *out, int ldo, int out_off, int32_t *workspace, void *stream);
 
 /* ---------------- Kaolin three_nn + inverse-distance weights: models/pointnet2.py:514-518
  * unknown (B,n,3), known (B,m,3) -> dist (B,n,3) [sqrt], idx (B,n,3), weight (B,n,3) (may be NULL) */

@@ -660,6 +660,38 @@ def test_sa_small_balls_with_foreign_index_layouts(dev, seeded_sd, model, level,
     assert float(err[~shuffled].max()) <= 1e-5, float(err[~shuffled].max())
 
 
+@pytest.mark.parametrize("level,scale", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_sa_register_kernel_is_slot_invariant(dev, seeded_sd, model, level, scale):
+    """The register kernel lists, per workgroup, the neighbourhoods the f64 re-evaluation will NOT overwrite and walks that list
+    (csrc/sa_mlp.hip: sa_small_entry), so the wave slot a neighbourhood is computed in depends on how many small balls precede it.
+    Its arithmetic must not: with the centres (and their index rows) in another order every output row is the SAME BITS, moved."""
+    from caspr_amd import ops
+    sa = model.encoder.local_extract.set_abstractions[level]
+    n_in, C = [2048, 1024][level], [6, 96][level]
+    M = sa.num_points_out
+    c = clouds(2, n_in, seed=level + 20) * [1, 1.5][level]
+    feat = rnd(level + 9, 2, n_in, C, scale=0.7)
+    idx = P.furthest_point_sampling(c, M)
+    ctr = torch.gather(c, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    g = sa.grouper_modules[scale]
+    bidx = P.ball_query(g.radius, g.num_samples, c, ctr)
+    distinct = torch.tensor([[len(set(r.tolist())) for r in bb] for bb in bidx])
+    ldf = (C + 3) // 4 * 4
+    fpad = torch.zeros(2, n_in, ldf)
+    fpad[:, :, :C] = feat
+    layers = sa.pointnet_modules[scale].kernel_layers()
+    cout = sa.pointnet_layer_dims_list[scale][-1]
+    out = torch.full((2, M, cout), float("nan"), device=dev)
+    ops.sa_mlp_max(c.to(dev), ctr.to(dev), fpad.to(dev), bidx.to(dev), C, layers, out, 0)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(5))
+    out_p = torch.full((2, M, cout), float("nan"), device=dev)
+    ops.sa_mlp_max(c.to(dev), ctr[:, perm].contiguous().to(dev), fpad.to(dev), bidx[:, perm].contiguous().to(dev), C, layers, out_p, 0)
+    assert torch.isfinite(out).all() and torch.isfinite(out_p).all()
+    assert torch.equal(out.cpu()[:, perm], out_p.cpu())
+    REPORT["sa_slot_invariance_l%d_s%d" % (level, scale)] = {"neighbourhoods": int(distinct.numel()), "with_at_most_8_distinct_samples": int((distinct <= 8).sum()),
+                                                             "with_at_most_4": int((distinct <= 4).sum())}
+
+
 # ---------------------------------------------------------------------------------------------
 # latent ODE and CNF
 # ---------------------------------------------------------------------------------------------
