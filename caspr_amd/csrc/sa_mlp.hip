@@ -1159,7 +1159,9 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
         }
     }
     CASPR_REQUIRE(!a.lo_in && !a.lo_out, "sa_mlp_max: low parts (CASPR_FEAT_LO_IN / _OUT) exist for the register kernel's shapes only (widths <= 64)");
-    const int bigK = (K0 > 160) || (C3 > 128);
+    // 32 columns per workgroup from 128 input channels up (round 5, second part: the third level too -- 37 KB of LDS, four workgroups per
+    // CU instead of two of 75 KB: 0.505 -> 0.474 and 1.219 -> 1.187 ms for its two scales, A/B in one box)
+    const int bigK = (K0 > 128) || (C3 > 128);
     const int ncol = bigK ? 32 : 64;
     const size_t shmem = (size_t)(a.rowsA + a.rowsB) * ncol * 16 + (3 * 64 + 16 + 64) * 4 + 64;
     CASPR_REQUIRE(shmem <= 160 * 1024, "sa_mlp_max: needs %zu bytes of LDS (> 160 KiB)", shmem);
