@@ -517,6 +517,31 @@ def test_train_loop_checkpoint_resume(tmp_path, seeded_sd):
     rel("resume_flush", torch.zeros(1), torch.zeros(1), 1.0)
 
 
+def test_train_checkpoint_reconstruct_end_to_end(tmp_path):
+    """The whole surface in one go (tools/train_and_eval.py, which profiles/ keeps a 300-step and a 2000-step record of): 40 full training
+    steps on fresh synthetic car sequences (the reference's loss and Adam settings), the checkpoint in the reference's format, loaded back
+    the way test.py:104-107 / `bench.py --weights` load one, and then on the TRAINED weights: better held-out Chamfer and T-NOCS error than
+    before training, the run-time accuracy guard quiet at the default step counts, and reconstruct() within 1e-5 of the f64 oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_and_eval", os.path.join(ROOT, "tools", "train_and_eval.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.main(["--steps", "40", "--eval-seqs", "1", "--ckpt", str(tmp_path / "time_model_0.pth"), "--no-dopri5", "--no-headline"])
+    curve = rep["train"]["curve"]
+    assert rep["train"]["finite"]
+    assert curve[-1]["loss"] < 0.5 * curve[0]["loss"], curve
+    assert rep["checkpoint"]["round_trip_bitwise"] and rep["checkpoint"]["keys"] == 238
+    before, after = rep["held_out_before"], rep["held_out_after"]
+    assert after["chamfer_x1000"]["mean"] < 0.5 * before["chamfer_x1000"]["mean"], (before, after)
+    assert after["tnocs_space_l2"]["mean"] < before["tnocs_space_l2"]["mean"], (before, after)
+    assert rep["guard_at_8_and_2_steps"]["verdict"] == "quiet", rep["guard_at_8_and_2_steps"]
+    par = rep["parity_trained_weights"]["hip_vs_f64_oracle_same_rk4_map"]
+    REPORT["end_to_end_trained_weights"] = {"loss_first": curve[0]["loss"], "loss_last": curve[-1]["loss"], "chamfer_x1000_before": before["chamfer_x1000"]["mean"],
+                                            "chamfer_x1000_after": after["chamfer_x1000"]["mean"], "hip_vs_f64_x": par["x"], "hip_vs_f64_tnocs": par["tnocs"]}
+    rel("end_to_end_flush", torch.zeros(1), torch.zeros(1), 1.0)
+    assert par["ok"], par
+
+
 @pytest.mark.parametrize("kw", [dict(regress_tnocs=False), dict(cnf_blocks=2), dict(augment_quad=False, augment_pairs=False)])
 def test_training_variants_step(kw, seeded_sd):
     """Constructor variants the reference configs use (cfg-4: regress_tnocs=False; cnf_blocks; no input augmentation):
