@@ -16,6 +16,7 @@ struct SaLayer {
     const float *wp, *bias, *gamma, *beta;
     int cout;  // multiple of 16
     int kc;    // packed 16-wide K chunks (even)
+    int kcr;   // chunks that carry inputs (<= kc; the pack's trailing all-zero chunk is neither staged nor multiplied by the LDS kernel)
 };
 
 struct SaArgs {
@@ -30,6 +31,7 @@ struct SaArgs {
     float *out;
     int ldo, out_off;
     int rowsA, rowsB;  // kq rows of the two ping-pong B-tiles
+    int split_last;    // LDS kernel: the last layer in two halves of cout / 2 channels (8 GroupNorm groups each) through a half-size tile
     unsigned long long *trace;   // debug stamps (NULL in production)
 };
 
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     // ---- gather: K order = [feat (C, padded to C4) | dx dy dz 0 | zeros ...]
     {
         const int C4 = (a.C + 3) & ~3;
-        const int nkq = a.L[0].kc * 4;
+        const int nkq = a.L[0].kcr * 4;
         const int qfeat = C4 >> 2;
         // feature quads: four independent rows in flight per thread, no branch around the loads -- with one load per iteration
         // the loop was a chain of dependent L2 round trips (16.5k of the kernel's 60k cycles at 64 + 3 input channels,
@@ -119,19 +121,27 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     SAM_STAMP(1)
     float *bin = bufA, *bout = bufB;
 #pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
+    for (int pass = 0; pass < 4; ++pass) {
+        // passes 0, 1: layers 1, 2; pass 2: layer 3 (or its first half); pass 3: layer 3's second half (split_last only)
+        const int l = pass < 2 ? pass : 2;
+        const int half = pass == 3 ? 1 : 0;
+        if (pass == 3 && !a.split_last) break;
+        const bool halved = l == 2 && a.split_last;
         const SaLayer L = a.L[l];
-        const int RT = L.cout >> 4;
+        const int RTall = L.cout >> 4;
+        const int RT = halved ? RTall >> 1 : RTall;          // row tiles of this pass
+        const int rt0 = halved ? half * RT : 0;              // ... starting at
         // ---- MFMA: work items (row tile, column group)
         if (RT >= 4) {
-            for (int rt = wave; rt < RT; rt += 4) {
+            for (int rtl = wave; rtl < RT; rtl += 4) {
+                const int rt = rt0 + rtl;
                 f32x4 acc[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float *wrow = L.wp + ((long)rt * L.kc) * 256 + lane * 4;
                 // weight fragments two chunks ahead (two static registers, K chunk counts are even; clamped re-loads at the end
                 // keep the loop free of branches -- with a branch hipcc waits for ALL outstanding loads at every chunk)
-                const int klast = L.kc - 1;
+                const int klast = L.kcr - 1;
                 f32x4 aq[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) aq[d] = ld4(wrow + (long)(d < klast ? d : klast) * 256);
@@ -148,27 +158,27 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(af[q], bf[ct][q], acc[ct]);
                 };
-                const int k4 = L.kc & ~3;
+                const int k4 = L.kcr & ~3;
                 for (int kc = 0; kc < k4; kc += 4) {
                     step(0, kc);
                     step(1, kc + 1);
                     step(2, kc + 2);
                     step(3, kc + 3);
                 }
-                if (k4 < L.kc) {   // chunk counts are even: a tail of two
-                    step(0, k4);
-                    step(1, k4 + 1);
-                }
+                // the tail: one to three chunks (the run count of layer 1 may be odd: its pack's last chunk is all padding)
+                if (k4 < L.kcr) step(0, k4);
+                if (k4 + 1 < L.kcr) step(1, k4 + 1);
+                if (k4 + 2 < L.kcr) step(2, k4 + 2);
                 f32x4 bias4 = ld4(L.bias + rt * 16 + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) st4(bout + btile_off(rt * 4 + g, ct * 16 + j, NCOL), acc[ct] + bias4);
+                for (int ct = 0; ct < CT; ++ct) st4(bout + btile_off(rtl * 4 + g, ct * 16 + j, NCOL), acc[ct] + bias4);
             }
         } else {
             for (int item = wave; item < RT * CT; item += 4) {
                 const int rt = item / CT, ct = item % CT;
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float *wrow = L.wp + ((long)rt * L.kc) * 256 + lane * 4;
-                for (int kc = 0; kc < L.kc; ++kc) {
+                for (int kc = 0; kc < L.kcr; ++kc) {
                     const f32x4 af = ld4(wrow + (long)kc * 256);
                     const f32x4 bf = ld4(bin + btile_off(kc * 4 + g, ct * 16 + j, NCOL));
 #pragma unroll
@@ -187,18 +197,22 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
         // the mean.  f64 sums make mean/(x - mean) exact for such groups (the reference's f32 path is not).
         const int cpg = L.cout >> 4;
         const float inv_cpg = 1.0f / (float)cpg;
+        const int g0 = halved ? 8 * half : 0, g1 = halved ? g0 + 8 : 16;      // GroupNorm groups this pass's tile holds
+        const int q0 = (g0 * cpg) >> 2;                                       // ... whose first channel quad is row 0 of the tile
         {
             const int stat = tid / TPS, sub = tid % TPS;
             const int cen = stat >> 4, grp = stat & 15;
             const int cnt = cpg * NS;
+            const bool mine = grp >= g0 && grp < g1;      // (a halved pass leaves the lanes of the other half's groups idle)
             // One pass in f64 (sum and sum of squares: with 53 bits the cancellation in E[x^2] - mean^2 is ~1e-14 absolute,
             // nothing next to eps = 1e-5), 16-byte reads where a group is made of whole channel quads: the scalar two-pass
             // version was a quarter to a third of this kernel's time (4-way bank conflicts on 16-byte-strided b32 reads).
             double s = 0.0, ss = 0.0;
-            if ((cpg & 3) == 0) {
+            if (!mine) {
+            } else if ((cpg & 3) == 0) {
                 const int nq = cpg >> 2;
                 for (int e = sub; e < nq * NS; e += TPS) {
-                    const f32x4 x4 = ld4(bout + btile_off(grp * nq + e / NS, cen * NS + e % NS, NCOL));
+                    const f32x4 x4 = ld4(bout + btile_off(grp * nq - q0 + e / NS, cen * NS + e % NS, NCOL));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const double d = (double)x4[q];
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
             const double mean = s / (double)cnt;
             double v = ss / (double)cnt - mean * mean;
             v = v > 0.0 ? v * (double)cnt : 0.0;
-            if (sub == 0) {
+            if (sub == 0 && mine) {
                 s_mean[stat] = mean;
                 s_rstd[stat] = __builtin_amdgcn_rsqf((float)(v / (double)cnt) + 1e-5f);
             }
@@ -268,20 +282,22 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
         } else {
             // ---- last layer: GroupNorm (no ReLU) then max over the NS samples (pointnet2.py:690-698)
             // (four lanes per channel quad with 16-byte reads and a cross-lane max measured SLOWER than this scalar form: 5.9k vs 5.1k cycles)
-            const float inv_cout = 1.0f / (float)L.cout;
-            for (int it = tid; it < NCEN * L.cout; it += 256) {
-                const int cen = (int)(((float)it + 0.5f) * inv_cout), co = it - cen * L.cout;   // it < NCEN * cout <= 2048: exact
+            const int cpass = RT << 4, c0 = rt0 << 4;          // channels of this pass: c0 .. c0 + cpass - 1
+            const float inv_cout = 1.0f / (float)cpass;
+            for (int it = tid; it < NCEN * cpass; it += 256) {
+                const int cen = (int)(((float)it + 0.5f) * inv_cout), cl = it - cen * cpass, co = c0 + cl;   // it < NCEN * cout <= 2048: exact
                 if (m0 + cen >= a.M) continue;
                 const int st = cen * 16 + (int)(((float)co + 0.5f) * inv_cpg);
                 const float sc = s_rstd[st] * L.gamma[co], be = L.beta[co];
                 const double mean = s_mean[st];
                 float mx = -INFINITY;
                 for (int s = 0; s < NS; ++s) {
-                    const float y = (float)((double)bout[btile_off(co >> 2, cen * NS + s, NCOL) + (co & 3)] - mean) * sc + be;
+                    const float y = (float)((double)bout[btile_off(cl >> 2, cen * NS + s, NCOL) + (cl & 3)] - mean) * sc + be;
                     mx = y > mx ? y : mx;
                 }
                 a.out[((long)b * a.M + m0 + cen) * a.ldo + a.out_off + co] = mx;
             }
+            if (halved && half == 0) __syncthreads();          // the second half's products overwrite the tile this pass read
             SAM_STAMP(10)
         }
     }
@@ -1094,17 +1110,24 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
     CASPR_REQUIRE(!a.lo_in || (aug == 0 && feat && ldf % 8 == 0 && ldf / 2 >= ((C + 3) & ~3)), "sa_mlp_max: CASPR_FEAT_LO_IN needs feat rows of [C | low parts of C] (ldf=%d, C=%d)", ldf, C);
     CASPR_REQUIRE(!a.lo_out || (ldo % 8 == 0 && ldo / 2 >= out_off + C3), "sa_mlp_max: CASPR_FEAT_LO_OUT needs out rows of [channels | their low parts] (ldo=%d)", ldo);
     const int K0 = ((C + 3) & ~3) + 3;
-    a.L[0] = {w1p, b1, g1, be1, C1, 2 * ((K0 + 31) / 32)};
-    a.L[1] = {w2p, b2, g2, be2, C2, 2 * ((C1 + 31) / 32)};
-    a.L[2] = {w3p, b3, g3, be3, C3, 2 * ((C2 + 31) / 32)};
+    a.L[0] = {w1p, b1, g1, be1, C1, 2 * ((K0 + 31) / 32), (K0 + 1 + 15) / 16};      // inputs: K0 + 1 = [feat (C, padded to 4) | dx dy dz 0]
+    a.L[1] = {w2p, b2, g2, be2, C2, 2 * ((C1 + 31) / 32), 2 * ((C1 + 31) / 32)};
+    a.L[2] = {w3p, b3, g3, be3, C3, 2 * ((C2 + 31) / 32), 2 * ((C2 + 31) / 32)};
     a.out = out; a.ldo = ldo; a.out_off = out_off;
     a.trace = nullptr;
     CASPR_IF_DEBUG(a.trace = g_sa_trace;)
-    const int rA = a.L[0].kc * 4 > a.L[2].kc * 4 ? a.L[0].kc * 4 : a.L[2].kc * 4;
-    const int rB0 = a.L[1].kc * 4, rB1 = C3 / 4;
+    const int rA = a.L[0].kcr * 4 > a.L[2].kc * 4 ? a.L[0].kcr * 4 : a.L[2].kc * 4;
+    const int rB0 = a.L[1].kc * 4 > C1 / 4 ? a.L[1].kc * 4 : C1 / 4;
     a.rowsA = rA > C2 / 4 ? rA : C2 / 4;
+    // the last layer's output is the widest thing tile B ever holds: in two halves of 8 GroupNorm groups each (C3 a multiple of 32,
+    // >= 4 row tiles per half so that every wave has one) the tile needs half the rows -- 70 -> 52 KB at the fourth level: three
+    // workgroups per CU instead of two
+    // (only where it buys a workgroup: the third level -- 37 KB unsplit, four per CU -- lost 0.04 ms to the extra barriers and idle
+    // statistics lanes; the fourth went 0.536 -> 0.510 and 1.035 -> 0.995 ms, A/B in one box)
+    const size_t unsplit = (size_t)(a.rowsA + (rB0 > C3 / 4 ? rB0 : C3 / 4)) * 32 * 16;
+    a.split_last = (C3 / 4 > rB0 && C3 % 128 == 0 && unsplit > 56 * 1024) ? 1 : 0;
+    const int rB1 = a.split_last ? C3 / 8 : C3 / 4;
     a.rowsB = rB0 > rB1 ? rB0 : rB1;
-    if (a.rowsB < C1 / 4) a.rowsB = C1 / 4;
     hipStream_t st = (hipStream_t)stream;
     const bool no_small = CASPR_DEBUG_ENV_INT("CASPR_SA_NO_SMALL") != 0;   // debug build only: force the LDS kernel
     a.repair_kmax = 0;
