@@ -261,6 +261,9 @@ def main():
         cpu, parity_ok = None, None
         if extra.get("stress_dynamics") and not extra["stress_dynamics"]["parity"]["ok"]:
             rc = 1
+        tc_ = extra.get("trained_checkpoint")
+        if tc_ and not (tc_["parity_hip_vs_f64_oracle"]["ok"] and tc_["checkpoint_round_trip_bitwise"] and tc_["loss_last"] < tc_["loss_first"]):
+            rc = 1            # the trained-checkpoint leg: parity on the trained weights, the round trip, a loss that goes down
         if extra.get("cfg5") and not extra["cfg5"]["parity"]["ok"]:
             rc = 1
         if guard_block is not None and guard_block["verdict"] != "quiet":
@@ -291,7 +294,7 @@ def main():
                        "box": box_calibration() if (world == 1 and not args.no_cpu_baseline) else None,
                        "nfe": [int(v) for v in model.get_nfe()]},
             "roofline": roofline, "f32_mfma_path": f32_block, "cfg5": extra.get("cfg5"), "train_cfg3": extra.get("train_cfg3"),
-            "stress_dynamics": extra.get("stress_dynamics"), "accuracy_guard": guard_block, "cpu_baseline": cpu, "parity_ok": parity_ok, "stage_ms_per_step": breakdown,
+            "stress_dynamics": extra.get("stress_dynamics"), "trained_checkpoint": extra.get("trained_checkpoint"), "accuracy_guard": guard_block, "cpu_baseline": cpu, "parity_ok": parity_ok, "stage_ms_per_step": breakdown,
         }))
         sys.stdout.flush()
     ops.check_deferred_errors()
@@ -475,6 +478,32 @@ def sub_blocks(args, dev, ops, timed_steps, x_headline, ts_headline):
                    "cnf_hip_vs_converged_f64_rk4_256": e_conv, "oracle_dopri5_1e-5_vs_converged": e_dop,
                    "cnf_hip_vs_oracle_dopri5": float((g - dop).abs().max()), "ok": bool(ok)}}
     del ms_
+    torch.cuda.empty_cache()
+
+    # ---- a checkpoint that went through the whole surface (the pretrained caspr_weights_cars.pth cannot be fetched offline): 60 training
+    # steps on fresh synthetic car sequences with the HIP training tier, written in the reference's format, loaded back as `--weights` loads
+    # one, and evaluated held out (tools/train_and_eval.py; the 300- and 2000-step records: profiles/r05_trained_checkpoint_*.json)
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("train_and_eval", os.path.join(ROOT, "tools", "train_and_eval.py"))
+    tae = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tae)
+    with tempfile.TemporaryDirectory() as td:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            rep = tae.main(["--steps", "60", "--eval-seqs", "2", "--ckpt", os.path.join(td, "time_model_0.pth"), "--no-dopri5", "--no-headline"])
+    curve = rep["train"]["curve"]
+    out["trained_checkpoint"] = {
+        "what": "60 training steps (B=8, T=10, N=1024, fresh synthetic cars per step, train_utils.py's loss, Adam 1e-4) -> reference-format checkpoint "
+                "-> load -> held-out evaluation at 10 x 2048 (evaluations.py protocol); tools/train_and_eval.py",
+        "train_wall_s": rep["train"]["wall_s"], "loss_first": curve[0]["loss"], "loss_last": curve[-1]["loss"],
+        "checkpoint_round_trip_bitwise": rep["checkpoint"]["round_trip_bitwise"], "checkpoint_keys": rep["checkpoint"]["keys"],
+        "held_out_chamfer_x1000": {"before": rep["held_out_before"]["chamfer_x1000"]["mean"], "after": rep["held_out_after"]["chamfer_x1000"]["mean"]},
+        "held_out_tnocs_l2": {"before": rep["held_out_before"]["tnocs_space_l2"]["mean"], "after": rep["held_out_after"]["tnocs_space_l2"]["mean"]},
+        "calibration_tol_1e-5": rep["calibration_tol_1e-5"], "guard_at_8_and_2_steps": rep["guard_at_8_and_2_steps"],
+        "parity_hip_vs_f64_oracle": rep["parity_trained_weights"]["hip_vs_f64_oracle_same_rk4_map"],
+        "longer_runs": "profiles/r05_trained_checkpoint_300.json, profiles/r05_trained_checkpoint_2000.json"}
     torch.cuda.empty_cache()
     return out
 

@@ -714,15 +714,15 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)
 // slot it is computed in, so the outputs are the same bits as with the identity list (test_sa_register_kernel_is_slot_invariant).
 // (A list per WORKGROUP, surveyed inside the kernel, was measured first: the partial last round of a 32-ball span and the loop's
 // registers -- 168 -> 194 -- gave back more than the skipped balls saved on the second level.)
-__global__ __launch_bounds__(1024) void sa_list_kernel(const int32_t *__restrict__ idx, int M, int ns, int kmax, int32_t *__restrict__ order,
-                                                       int32_t *__restrict__ count)
+__global__ __launch_bounds__(256) void sa_list_kernel(const int32_t *__restrict__ idx, int M, int ns, int kmax, int32_t *__restrict__ order,
+                                                      int32_t *__restrict__ count)
 {
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
+    // (256 threads: a 1024-thread workgroup needs half a CU's wave slots at once, and beside the index chain's kernels on the other
+    // stream it waited for them -- 55 us on average inside the step against 6 us alone, profiles/r05b_kernel_stats.txt)
+    __shared__ int s_wave[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int m0 = 0; m0 < M; m0 += 1024) {
+    int base = 0;                                   // kept neighbourhoods so far (uniform)
+    for (int m0 = 0; m0 < M; m0 += 256) {
         const int m = m0 + tid;
         bool big = false;
         if (m < M) {
@@ -743,18 +743,17 @@ __global__ __launch_bounds__(1024) void sa_list_kernel(const int32_t *__restrict
         const unsigned long long mk = __builtin_amdgcn_ballot_w64(big);
         if (lane == 0) s_wave[wave] = __builtin_popcountll(mk);
         __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (big) order[(long)b * M + off + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = m;
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < 16; ++w) t += s_wave[w];
-            s_base += t;
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            off += w < wave ? s_wave[w] : 0;
+            tot += s_wave[w];
         }
-        __syncthreads();
+        if (big) order[(long)b * M + off + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = m;
+        base += tot;
+        __syncthreads();                            // s_wave is rewritten by the next round
     }
-    if (tid == 0) count[b] = s_base;
+    if (tid == 0) count[b] = base;
 }
 
 template <int NS, int C1, int C2, int C3>
@@ -1145,7 +1144,7 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
         a.order = a.count = nullptr;
         if (workspace && a.repair_kmax > 0 && small_shape_ && !CASPR_DEBUG_ENV_INT("CASPR_SA_NO_LIST")) {
             // the neighbourhoods the f64 kernel will not overwrite, listed per cloud: the register kernel computes those only (sa_list_kernel)
-            sa_list_kernel<<<dim3(B), dim3(1024), 0, st>>>(idx, M, ns, a.repair_kmax, workspace + B, workspace);
+            sa_list_kernel<<<dim3(B), dim3(256), 0, st>>>(idx, M, ns, a.repair_kmax, workspace + B, workspace);
             a.order = workspace + B;
             a.count = workspace;
         }
