@@ -538,7 +538,7 @@ def kernel_rooflines(cnf, detail, traffic_table, shape, sa_wall_ms=None):
                     "layers": [{"cin": ci_, "cout": co_, "rows": rows_, "launches_per_step": len(m_) // 2, "ms": round(sum(m_) / len(m_), 4),
                                 "frac": round(2.0 * ci_ * co_ * rows_ / (sum(m_) / len(m_) * 1e-3) / 1e12 / (PEAK_MFMA_BF16_TFLOPS / 6.0), 4)}
                                for (ci_, co_, rows_), m_ in sorted(convs.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2])]})
-    sa = [(float(k.split(":")[5]) * 1e6, ms) for k, ms in detail.items() if k.split(":")[1] == "sa_mlp_max"]
+    sa = [(float(k.split(":")[5]) * 1e6, ms) for k, ms in detail.items() if k.split(":")[1].startswith("sa_mlp_max")]     # (+ "_mfma" / "_f64": a scale's two halves on two streams)
     if sa:
         flop = sum(f * len(ms) for f, ms in sa)
         ms_all = sum(sum(ms) for _, ms in sa)

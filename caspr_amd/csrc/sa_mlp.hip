@@ -1102,7 +1102,9 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
     a.ldf = ldf; a.n = n; a.M = M; a.C = C;
     const int want_c = ((feat_kind & CASPR_FEAT_QUAD) ? 3 : 0) + ((feat_kind & CASPR_FEAT_PAIRS) ? 3 : 0);
     const int aug = feat_kind & (CASPR_FEAT_QUAD | CASPR_FEAT_PAIRS);
-    CASPR_REQUIRE(feat_kind >= 0 && feat_kind < 16 && (aug == 0 || C == want_c), "sa_mlp_max: feat_kind=%d does not describe C=%d channels", feat_kind, C);
+    CASPR_REQUIRE(feat_kind >= 0 && feat_kind < 64 && (aug == 0 || C == want_c), "sa_mlp_max: feat_kind=%d does not describe C=%d channels", feat_kind, C);
+    const bool only_mfma = (feat_kind & CASPR_SA_ONLY_MFMA) != 0, only_f64 = (feat_kind & CASPR_SA_ONLY_F64) != 0;
+    CASPR_REQUIRE(!(only_mfma && only_f64), "sa_mlp_max: CASPR_SA_ONLY_MFMA and CASPR_SA_ONLY_F64 exclude each other");
     a.feat_kind = aug;
     a.lo_in = (feat_kind & CASPR_FEAT_LO_IN) ? 1 : 0;
     a.lo_out = (feat_kind & CASPR_FEAT_LO_OUT) ? 1 : 0;
@@ -1144,12 +1146,18 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
         a.order = a.count = nullptr;
         if (workspace && a.repair_kmax > 0 && small_shape_ && !CASPR_DEBUG_ENV_INT("CASPR_SA_NO_LIST")) {
             // the neighbourhoods the f64 kernel will not overwrite, listed per cloud: the register kernel computes those only (sa_list_kernel)
-            sa_list_kernel<<<dim3(B), dim3(256), 0, st>>>(idx, M, ns, a.repair_kmax, workspace + B, workspace);
+            if (!only_f64) sa_list_kernel<<<dim3(B), dim3(256), 0, st>>>(idx, M, ns, a.repair_kmax, workspace + B, workspace);
             a.order = workspace + B;
             a.count = workspace;
         }
+        // The two halves of the call separately (CASPR_SA_ONLY_MFMA / _ONLY_F64: the caller runs them on two streams).  They write disjoint
+        // output rows only when the register kernel works from the list -- without it that kernel stores every row and the f64 kernel must
+        // come behind it.
+        CASPR_REQUIRE(!(only_mfma || only_f64) || a.repair_kmax == 0 || a.order != nullptr,
+                      "sa_mlp_max: CASPR_SA_ONLY_MFMA / _ONLY_F64 need the workspace (the list that makes the two halves' output rows disjoint)");
         bool done = true;
-        if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 16) sa_small_kernel_w3<16, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
+        if (only_f64) done = small_shape_;
+        else if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 16) sa_small_kernel_w3<16, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
         else if (C1 == 16 && C2 == 16 && C3 == 32 && ns == 32) sa_small_kernel_w3<32, 16, 16, 32><<<grid, dim3(256), 0, st>>>(a);
         else if (C1 == 32 && C2 == 32 && C3 == 64 && ns == 16) sa_small_kernel<16, 32, 32, 64><<<grid, dim3(256), 0, st>>>(a);
         else if (C1 == 32 && C2 == 32 && C3 == 64 && ns == 32) sa_small_kernel_w2<32, 32, 32, 64><<<grid, dim3(256), 0, st>>>(a);
@@ -1163,7 +1171,7 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
             const int wfloats = ((C1 >> 4) * a.L[0].kc + (C2 >> 4) * a.L[1].kc + (C3 >> 4) * a.L[2].kc) * 256;      // the kernel keeps the three packs in LDS
             CASPR_REQUIRE(a.repair_kmax > 0 || CASPR_DEBUG_ENV_INT("CASPR_SA_REPAIR_K") < 0, "sa_mlp_max: the f64 re-evaluation keeps %d weight floats in LDS (> its window)", wfloats);
             const dim3 rgrid(ceil_div(M, 128), B);
-            if (a.repair_kmax > 0) {
+            if (a.repair_kmax > 0 && !only_mfma) {
                 const bool wide = a.repair_kmax > 4;
 #define SA_REPAIR(W)                                                                                          \
     do {                                                                                                      \
@@ -1181,6 +1189,7 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
         }
     }
     CASPR_REQUIRE(!a.lo_in && !a.lo_out, "sa_mlp_max: low parts (CASPR_FEAT_LO_IN / _OUT) exist for the register kernel's shapes only (widths <= 64)");
+    if (only_f64) return CASPR_OK;        // the LDS kernel's shapes have no f64 half
     // 32 columns per workgroup from 128 input channels up (round 5, second part: the third level too -- 37 KB of LDS, four workgroups per
     // CU instead of two of 75 KB: 0.505 -> 0.474 and 1.219 -> 1.187 ms for its two scales, A/B in one box)
     const int bigK = (K0 > 128) || (C3 > 128);

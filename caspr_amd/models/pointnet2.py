@@ -23,11 +23,12 @@ from .lazy import Lazy
 NUM_GROUPS = 16  # for group norm (pointnet2.py:12)
 LO_PARTS = _cfg.sa_lo_parts  # the first set-abstraction level hands its output to the second as an unevaluated sum hi + lo (PointNet2feat.run)
 SCALE_STREAMS = _cfg.sa_scale_streams  # the two scales of a set-abstraction level on two streams (PointNet2SetAbstraction.run)
+F64_STREAMS = _cfg.sa_f64_streams      # ... and the f64 re-evaluation of each scale's small balls on a stream of its own, beside its MFMA kernel
 _SCALE_STREAM = {}
 
 
-def _scale_stream(device):
-    key = (device.type, device.index)
+def _scale_stream(device, which=0):
+    key = (device.type, device.index, which)
     if key not in _SCALE_STREAM:
         _SCALE_STREAM[key] = torch.cuda.Stream(device=device)
     return _SCALE_STREAM[key]
@@ -240,7 +241,14 @@ class PointNet2SetAbstraction(nn.Module):
         if SCALE_STREAMS and xyz.is_cuda and len(self.layers) > 1 and not torch.cuda.is_current_stream_capturing():
             side = _scale_stream(xyz.device)
             side.wait_stream(main)
-        off = 0
+        # On the register kernel's levels a scale is two independent halves since the kernel works from a list (csrc/sa_mlp.hip:
+        # sa_list_kernel): the MFMA kernel over the neighbourhoods the f64 re-evaluation does not take, and that re-evaluation (three
+        # latency-bound launches on the vector pipe).  F64_STREAMS puts the f64 half on a stream of its own per scale, beside the MFMA
+        # half.  OFF by default: measured (tools/sa_streams_ab.py, profiles/r05_sa_f64_streams_ab.txt) the five levels take 7.13-7.28 ms
+        # that way against 6.74-6.84 with the re-evaluation behind its kernel -- four resident kernels time-slice the wave slots the two
+        # scales already fill, and every extra stream costs its joins.
+        halves = side is not None and self.narrow() and F64_STREAMS
+        off, extra = 0, []
         for i, ns in enumerate(self.layers):
             on_side = side is not None and i == len(self.layers) - 1
             with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
@@ -250,10 +258,24 @@ class PointNet2SetAbstraction(nn.Module):
                     self._run_rows(xyz, new_xyz, feat, C, idx["ball_idx"][i], i, out, off)
                 else:
                     ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off,
-                                   feat_kind=feat_kind)  # :391-409
+                                   feat_kind=feat_kind, part="mfma" if halves else None)  # :391-409
+            if halves:
+                st = _scale_stream(xyz.device, 1 + i)
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    if "scale_ready" in idx:
+                        self._await(idx, i)
+                    ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off,
+                                   feat_kind=feat_kind, part="f64")
+                extra.append(st)
             off += self.pointnet_layer_dims_list[i][-1]
         if side is not None:
             main.wait_stream(side)
+        for st in extra:
+            main.wait_stream(st)
+            for t_ in (xyz, new_xyz, feat, out) + tuple(idx["ball_idx"]):
+                if t_ is not None:
+                    t_.record_stream(st)
         if record is not None:
             record.append(idx)
         return new_xyz, out

@@ -535,14 +535,21 @@ def conv1x1_gn_early(pw, bias, x, gamma, beta, on_early, groups=16, eps=1e-5, in
 
 
 FEAT_QUAD, FEAT_PAIRS, FEAT_LO_IN, FEAT_LO_OUT = 1, 2, 4, 8     # include/caspr_hip.h
+SA_ONLY_MFMA, SA_ONLY_F64 = 16, 32                              # the call in two halves (two streams): the MFMA kernel / the f64 re-evaluation
 
 
-def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0):
+def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0, part=None):
     """Fused grouper + 3-layer point MLP + GroupNorm + max (pointnet2.py:391-409,649-703).
     feat (B,n,ldf) point-major with C valid channels; layers = 3 x (PackedWeight, bias, gamma, beta).
     feat_kind: FEAT_QUAD | FEAT_PAIRS when feat is prep_input's quadratic augmentation of xyz (first level); FEAT_LO_OUT: `out` rows are
     [channels | their low parts] (the second half of the row receives what the f32 output lacks of the kernel's f64 result); FEAT_LO_IN:
-    `feat` rows are [C channels .. | low parts from column ldf / 2] as a FEAT_LO_OUT call wrote them (include/caspr_hip.h)."""
+    `feat` rows are [C channels .. | low parts from column ldf / 2] as a FEAT_LO_OUT call wrote them (include/caspr_hip.h).
+    part: None = the whole call; "mfma" / "f64" = one of its two halves (SA_ONLY_MFMA / SA_ONLY_F64: the MFMA kernel over the neighbourhoods
+    the f64 re-evaluation does not take / that re-evaluation alone), for a caller that runs them on two streams -- together they write what
+    the whole call writes, bit for bit."""
+    if part not in (None, "mfma", "f64"):
+        raise ValueError("sa_mlp_max: part must be None, 'mfma' or 'f64'")
+    feat_kind = int(feat_kind) | (SA_ONLY_MFMA if part == "mfma" else (SA_ONLY_F64 if part == "f64" else 0))
     _chk_f32(xyz, new_xyz, feat, out)
     _chk_i32(idx)
     B, n, _ = xyz.shape
@@ -554,7 +561,7 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0):
         args += [_p(pw.data), _p(b), _p(g), _p(be), pw.cout]
     # 2 FLOP per multiply-add of the three layers over every gathered sample (C + 3 input channels: xyz first)
     flop = 2.0 * B * M * ns * ((C + 3) * layers[0][0].cout + layers[0][0].cout * layers[1][0].cout + layers[1][0].cout * layers[2][0].cout)
-    with timed("k:sa_mlp_max:%d:%d:%d:%d" % (C + 3, layers[2][0].cout, B * M * ns, int(flop // 1000000)), 2):
+    with timed("k:sa_mlp_max%s:%d:%d:%d:%d" % ("" if part is None else "_" + part, C + 3, layers[2][0].cout, B * M * ns, int(flop // 1000000) if part != "f64" else 0), 2):
         # scratch for the register kernel's list of the neighbourhoods the f64 re-evaluation leaves to it (include/caspr_hip.h); the
         # wider shapes take the LDS kernel and no scratch
         ws = None

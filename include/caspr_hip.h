@@ -89,6 +89,12 @@ int caspr_group_points_f32(const float *xyz, const float *new_xyz, const float *
  *     f64 products of the coordinates for the same purpose).                                                                        */
 #define CASPR_FEAT_LO_IN 4
 #define CASPR_FEAT_LO_OUT 8
+/* The call in two halves, for a caller that wants them on two streams (caspr_sa_mlp_max_ws_f32 with a workspace only: the list in it is what
+ * makes the halves' output rows disjoint): CASPR_SA_ONLY_MFMA = the list + the MFMA kernel (every neighbourhood the f64 re-evaluation does
+ * not take; on the LDS kernel's shapes: everything), CASPR_SA_ONLY_F64 = the f64 re-evaluation of the small balls alone (a no-op on shapes
+ * that have none).  The two calls together write exactly what the plain call writes, bit for bit, in any order.                        */
+#define CASPR_SA_ONLY_MFMA 16
+#define CASPR_SA_ONLY_F64 32
 int caspr_sa_mlp_max_f32(const float *xyz, const float *new_xyz, const float *feat, int ldf,
                          const int32_t *idx, int B, int n, int M, int C, int ns, int feat_kind,
                          const float *w1p, const float *b1, const float *g1, const float *be1, int C1,

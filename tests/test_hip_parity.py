@@ -692,6 +692,36 @@ def test_sa_register_kernel_is_slot_invariant(dev, seeded_sd, model, level, scal
                                                              "with_at_most_4": int((distinct <= 4).sum())}
 
 
+@pytest.mark.parametrize("level,scale", [(0, 1), (1, 0), (2, 0)])
+def test_sa_call_in_two_halves_writes_the_same_bits(dev, seeded_sd, model, level, scale):
+    """include/caspr_hip.h: CASPR_SA_ONLY_MFMA + CASPR_SA_ONLY_F64 (ops.sa_mlp_max(part=...)) together write exactly what the plain call
+    writes, in either order; on the LDS kernel's shapes (level 2) the f64 half is a no-op and the MFMA half is the call."""
+    from caspr_amd import ops
+    sa = model.encoder.local_extract.set_abstractions[level]
+    n_in, C = [2048, 1024, 512][level], [6, 96, 128][level]
+    M = sa.num_points_out
+    c = clouds(2, n_in, seed=level + 30) * [1, 1.5, 2.0][level]
+    feat = rnd(level + 11, 2, n_in, C, scale=0.7)
+    idx = P.furthest_point_sampling(c, M)
+    ctr = torch.gather(c, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    g = sa.grouper_modules[scale]
+    bidx = P.ball_query(g.radius, g.num_samples, c, ctr)
+    ldf = (C + 3) // 4 * 4
+    fpad = torch.zeros(2, n_in, ldf)
+    fpad[:, :, :C] = feat
+    layers = sa.pointnet_modules[scale].kernel_layers()
+    cout = sa.pointnet_layer_dims_list[scale][-1]
+    a = (c.to(dev), ctr.to(dev), fpad.to(dev), bidx.to(dev), C, layers)
+    whole = torch.full((2, M, cout), float("nan"), device=dev)
+    ops.sa_mlp_max(*a, whole, 0)
+    for order in (("mfma", "f64"), ("f64", "mfma")):
+        out = torch.full((2, M, cout), float("nan"), device=dev)
+        for part in order:
+            ops.sa_mlp_max(*a, out, 0, part=part)
+        assert torch.isfinite(out).all()
+        assert torch.equal(out, whole), order
+
+
 # ---------------------------------------------------------------------------------------------
 # latent ODE and CNF
 # ---------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ for k, ev in ops.TIMERS.items():
     if p[0] != "k":
         continue
     ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    if p[1] == "sa_mlp_max":
+    if p[1].startswith("sa_mlp_max"):
         fl, peak = float(p[5]) * 1e6, 157.3
     elif p[1].startswith("conv1x1") or p[1].startswith("wgrad"):
         fl, peak = 2.0 * int(p[2]) * int(p[3]) * int(p[4]), (416.7 if p[1].endswith("bf16x6") else 157.3)
