@@ -952,6 +952,97 @@ extern "C" int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, 
     return gn_stats_impl(Y, ldy, B, P, C, G, gamma, beta, eps, scale, shift, pmax, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Feature propagation with its first conv on the COARSE level (round 5, second part; pointnet2.py:514-525).  The reference interpolates the
+// coarser level's features to the fine points, concatenates the skip features and applies conv -> GroupNorm -> ReLU; interpolation and a
+// pointwise conv commute -- W [sum_k w_k h_k ; s] + b = sum_k w_k (W_p h_k) + W_s s + b -- so the conv's large part runs over the m coarse
+// rows (caspr_conv1x1_*: u = W_p h, no bias) and this kernel produces the layer's raw output on the n fine rows: the three-neighbour
+// combination of u, plus the skip part on the vector pipe (C2 <= 8 channels: the finest level's 6 augmented coordinates), plus the bias,
+// with the GroupNorm statistics of the result in f64 per 64-row block (the layout gn_finalize_kernel reads).  At cfg-2's finest level:
+// a 544 -> 512 conv over 327,680 rows becomes a 512 -> 512 conv over 163,840.
+// ---------------------------------------------------------------------------------------------
+#define TIA_ROWS 64
+__global__ __launch_bounds__(256) void three_interp_add_gn_kernel(const float *__restrict__ u, int ldu, const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ weight, const float *__restrict__ skip, int lds,
+                                                                  int C2, const float *__restrict__ wsk, const float *__restrict__ bias, int m,
+                                                                  int n, int C, int G, float *__restrict__ y, int ldy, double *__restrict__ psum)
+{
+    __shared__ double s_sum[256], s_sq[256];
+    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    const int CQ = C >> 2, cpg = C / G, qpg = cpg >> 2;     // host: C % 4 == 0, cpg % 4 == 0, CQ <= 256
+    const int TP = 256 / CQ;
+    const int tq = threadIdx.x % CQ, tp = threadIdx.x / CQ;
+    const int pbeg = s * TIA_ROWS, pend = (pbeg + TIA_ROWS) < n ? (pbeg + TIA_ROWS) : n;
+    double sum = 0.0, sq = 0.0;
+    if (tp < TP) {
+        float wk[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) wk[q][c] = c < C2 ? wsk[(long)(4 * tq + q) * C2 + c] : 0.f;
+        const f32x4 b4 = bias ? ld4(bias + 4 * tq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float *ub = u + (long)b * m * ldu + 4 * tq;
+#pragma unroll 4
+        for (int p = pbeg + tp; p < pend; p += TP) {
+            const long row = (long)b * n + p;
+            const int i0 = idx[row * 3 + 0], i1 = idx[row * 3 + 1], i2 = idx[row * 3 + 2];
+            const float w0 = weight[row * 3 + 0], w1 = weight[row * 3 + 1], w2 = weight[row * 3 + 2];
+            const f32x4 a = ld4(ub + (long)i0 * ldu), bb = ld4(ub + (long)i1 * ldu), cc = ld4(ub + (long)i2 * ldu);
+            float sk[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sk[c] = c < C2 ? skip[row * lds + c] : 0.f;
+            f32x4 r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = b4[q];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) t = fmaf(wk[q][c], sk[c], t);
+                r[q] = fmaf(w2, cc[q], fmaf(w1, bb[q], w0 * a[q])) + t;
+                sum += (double)r[q];
+                sq += (double)r[q] * (double)r[q];
+            }
+            st4(y + row * ldy + 4 * tq, r);
+        }
+    }
+    s_sum[threadIdx.x] = sum;
+    s_sq[threadIdx.x] = sq;
+    __syncthreads();
+    if (threadIdx.x < G) {        // one thread per group: its quads x the TP row lanes, in index order (deterministic)
+        const int g = threadIdx.x;
+        double a0 = 0.0, a1 = 0.0;
+        for (int r = 0; r < TP; ++r)
+            for (int k = 0; k < qpg; ++k) {
+                a0 += s_sum[r * CQ + g * qpg + k];
+                a1 += s_sq[r * CQ + g * qpg + k];
+            }
+        double *o = psum + (((long)b * G + g) * S + s) * 2;
+        o[0] = a0;
+        o[1] = a1;
+    }
+}
+
+extern "C" long caspr_three_interp_add_gn_ws_bytes(int B, int n, int G) { return (long)B * G * ((n + TIA_ROWS - 1) / TIA_ROWS) * 2 * (long)sizeof(double); }
+
+extern "C" int caspr_three_interp_add_gn_f32(const float *u, int ldu, const int32_t *idx, const float *weight, const float *skip, int lds,
+                                             int C2, const float *wskip, const float *bias, int B, int m, int n, int C, float *y, int ldy,
+                                             int G, const float *gamma, const float *beta, float eps, float *scale, float *shift, void *ws,
+                                             long ws_bytes, void *stream)
+{
+    CASPR_REQUIRE(u && idx && weight && y && gamma && beta && scale && shift && ws && B > 0 && B <= 65535 && m > 0 && n > 0 && C > 0 && G > 0,
+                  "three_interp_add_gn: bad arguments");
+    CASPR_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "three_interp_add_gn: C=%d / G=%d: need C/G %% 4 == 0 and C/4 a divisor of 256", C, G);
+    CASPR_REQUIRE(ldu % 4 == 0 && ldu >= C && ldy % 4 == 0 && ldy >= C, "three_interp_add_gn: ldu=%d ldy=%d must be multiples of 4 and >= C", ldu, ldy);
+    CASPR_REQUIRE(C2 >= 0 && C2 <= 8 && (C2 == 0 || (skip && wskip && lds >= C2)), "three_interp_add_gn: C2=%d skip channels (0..8) need skip / wskip", C2);
+    const int S = ceil_div(n, TIA_ROWS);
+    CASPR_REQUIRE(ws_bytes >= caspr_three_interp_add_gn_ws_bytes(B, n, G), "three_interp_add_gn: workspace of %ld bytes is too small", ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    double *psum = reinterpret_cast<double *>(ws);
+    three_interp_add_gn_kernel<<<dim3(S, B), dim3(256), 0, st>>>(u, ldu, idx, weight, skip, lds, C2, wskip, bias, m, n, C, G, y, ldy, psum);
+    gn_finalize_kernel<<<dim3(ceil_div(B * C, 256)), dim3(256), 0, st>>>(psum, nullptr, B, n, C, G, S, gamma, beta, eps, scale, shift, nullptr, nullptr, nullptr);
+    CASPR_CHECK_LAUNCH("three_interp_add_gn");
+    return CASPR_OK;
+}
+
 // training tier: same statistics, and the per-(batch, group) mean / rstd the backward pass needs
 extern "C" int caspr_gn_stats_train_f32(const float *Y, int ldy, int B, int P, int C, int G, const float *gamma,
                                         const float *beta, float eps, float *scale, float *shift, float *pmax,

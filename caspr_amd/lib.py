@@ -38,6 +38,9 @@ SIGNATURES = {
                                         c_fp, c_int, c_int, c_ip, c_stream]),
     "caspr_three_nn_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_ip, c_fp, c_stream]),
     "caspr_three_interp_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
+    "caspr_three_interp_add_gn_ws_bytes": (c_long, [c_int, c_int, c_int]),
+    "caspr_three_interp_add_gn_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int,
+                                              c_int, c_fp, c_fp, c_float, c_fp, c_fp, ctypes.c_void_p, c_long, c_stream]),
     "caspr_packed_size": (c_long, [c_int, c_int]),
     "caspr_pack_weight_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_stream]),
     "caspr_conv1x1_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_stream]),

@@ -23,6 +23,7 @@ from .lazy import Lazy
 NUM_GROUPS = 16  # for group norm (pointnet2.py:12)
 LO_PARTS = _cfg.sa_lo_parts  # the first set-abstraction level hands its output to the second as an unevaluated sum hi + lo (PointNet2feat.run)
 SCALE_STREAMS = _cfg.sa_scale_streams  # the two scales of a set-abstraction level on two streams (PointNet2SetAbstraction.run)
+FP_COMMUTE = _cfg.fp_commute           # feature propagation's first conv on the coarse level where the skip part is tiny (PointNet2FeaturePropagator.run)
 F64_STREAMS = _cfg.sa_f64_streams      # ... and the f64 re-evaluation of each scale's small balls on a stream of its own, beside its MFMA kernel
 _SCALE_STREAM = {}
 
@@ -343,6 +344,29 @@ class PointNet2FeaturePropagator(nn.Module):
         """Point-major core.  feat (B,n,ldf) skip features with C valid channels (or None); prev = Lazy
         features of the coarser level; nn = precomputed ops.three_nn(xyz, xyz_prev, with_weights=True).  -> Lazy (B,n,Cout)."""
         _, idx, w = nn if nn is not None else ops.three_nn(xyz, xyz_prev, with_weights=True)    # pointnet2.py:514-518
+        n_layers = len(self.layer_dims)
+        conv0, gn0 = self.unit_pointnet[0], self.unit_pointnet[1]
+        # The first conv on the COARSE level (interpolation and a pointwise conv commute, csrc/gemm.hip: three_interp_add_gn_kernel):
+        # worth it where the fine level has at least twice the rows and the skip part is a handful of channels (the finest level's six
+        # augmented coordinates: a 544 -> 512 conv over 327,680 rows becomes a 512 -> 512 conv over 163,840 at cfg-2).  A rule on the
+        # level's shape only -- never on the number of frames -- so sharding stays bitwise invariant.
+        if (FP_COMMUTE and ops.CONV_BF16X6 and C <= 8 and 2 * prev.raw.shape[1] <= idx.shape[1] and prev.raw.shape[1] % 128 == 0
+                and prev.channels % 32 == 0 and prev.channels >= 192 and conv0.out_channels % 64 == 0 and 256 % (conv0.out_channels // 4) == 0):
+            Cp = prev.channels
+
+            def build():
+                W = conv0.weight.detach()[:, :, 0]
+                return ops.PackedWeight(W[:, :Cp].contiguous()), W[:, Cp:Cp + C].contiguous()
+            pw_p, w_s = self._cache.get(("commute", Cp, C), [conv0.weight], build)
+            u = ops.conv1x1(pw_p, None, prev.raw, in_scale=prev.scale, in_shift=prev.shift, in_relu=prev.relu)
+            y, s, t = ops.three_interp_add_gn(u, idx, w, feat, C, w_s if C else None, conv0.bias, gn0.weight, gn0.bias)
+            cur = Lazy(y, conv0.out_channels, s, t, True)
+            for l in range(1, n_layers):                                                        # :525
+                conv, gn = self.unit_pointnet[3 * l], self.unit_pointnet[3 * l + 1]
+                y, s, t = ops.conv1x1_gn(self._packed(3 * l), conv.bias, cur.raw, gn.weight, gn.bias, in_scale=cur.scale, in_shift=cur.shift,
+                                         in_relu=cur.relu)
+                cur = Lazy(y, conv.out_channels, s, t, True)
+            return cur
         # an input width the bf16x6 conv cannot take (518 at the finest level) is padded with zero columns to a multiple of 32
         cin = prev.channels + C
         pad = ops.CONV_BF16X6 and cin % 32 != 0 and cin >= 192 and idx.shape[1] % 128 == 0

@@ -204,6 +204,29 @@ def three_interpolate(feat, idx, weight, skip=None, skip_channels=None, in_scale
     return out
 
 
+def three_interp_add_gn(u, idx, weight, skip, skip_channels, wskip, bias, gamma, beta, groups=16, eps=1e-5):
+    """Feature propagation's first layer AFTER its conv ran on the coarse level (include/caspr_hip.h: caspr_three_interp_add_gn_f32):
+    u (B,m,>=C) = W_p h, idx / weight (B,n,3) from three_nn, skip (B,n,>=C2) | None, wskip (C,C2) -> (y (B,n,C) raw, scale (B,C), shift (B,C))."""
+    _chk_f32(u, weight, skip, wskip, bias, gamma, beta)
+    _chk_i32(idx)
+    ldu, lds = _chk_rows(u), _chk_rows(skip)
+    B, m, _ = u.shape
+    n = idx.shape[1]
+    C = gamma.numel()
+    C2 = 0 if skip is None else int(skip_channels)
+    y = torch.empty(B, n, C, device=u.device, dtype=torch.float32)
+    scale = torch.empty(B, C, device=u.device, dtype=torch.float32)
+    shift = torch.empty(B, C, device=u.device, dtype=torch.float32)
+    L = _lib.load()
+    nb = L.caspr_three_interp_add_gn_ws_bytes(B, n, groups)
+    ws = _workspace(nb, u.device)
+    with timed("k:three_interp_add_gn:%d:%d:%d" % (C2, C, B * n), 2):
+        _lib.check(L.caspr_three_interp_add_gn_f32(_p(u), ldu, _p(idx), _p(weight), _p(skip), lds, C2, _p(wskip), _p(bias), B, m, n, C, _p(y), C,
+                                                   groups, _p(gamma), _p(beta), float(eps), _p(scale), _p(shift), _p(ws), ws.numel(), _stream()),
+                   "caspr_three_interp_add_gn_f32")
+    return y, scale, shift
+
+
 # ---------------------------------------------------------------------------------------------
 # Matrix products.  Every contraction of this model is f32 arithmetic; there are two ways to run it on gfx950:
 #   "bf16x6" (default): each f32 operand is split EXACTLY into three bf16 numbers (x = x1 + x2 + x3) and a product is

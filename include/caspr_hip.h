@@ -125,6 +125,17 @@ int caspr_three_nn_f32(const float *unknown, const float *known, int B, int n, i
 int caspr_three_interp_f32(const float *feat, int ldf, const int32_t *idx, const float *weight,
                            const float *in_scale, const float *in_shift, int in_relu, const float *skip,
                            int lds, int B, int m, int n, int C, int C2, float *out, int ldo, void *stream);
+/* Feature propagation with its first conv on the COARSE level (pointnet2.py:514-525: three_interpolate -> concat skip -> conv -> GroupNorm;
+ * interpolation and a pointwise conv commute).  u (B,m,ldu) = W_p h over the coarse rows (caspr_conv1x1_*, no bias; W_p = the conv's first
+ * C_prev input columns); y[b,i,0:C] = sum_k weight[b,i,k] * u[b,idx[b,i,k],0:C] + wskip (C x C2, row-major: the conv's last C2 input columns)
+ * . skip[b,i,0:C2] + bias, C2 <= 8; scale / shift (B,C) = the GroupNorm(G) of y folded with gamma / beta, as caspr_conv1x1_gn_* return them.
+ * ws: caspr_three_interp_add_gn_ws_bytes(B, n, G) bytes of device scratch.                                                           */
+long caspr_three_interp_add_gn_ws_bytes(int B, int n, int G);
+int caspr_three_interp_add_gn_f32(const float *u, int ldu, const int32_t *idx, const float *weight, const float *skip, int lds,
+                                  int C2, const float *wskip, const float *bias, int B, int m, int n, int C, float *y, int ldy,
+                                  int G, const float *gamma, const float *beta, float eps, float *scale, float *shift, void *ws,
+                                  long ws_bytes, void *stream);
+
 
 /* ---------------- pointwise conv (nn.Conv1d k=1 / nn.Linear) on MFMA f32 --------------------------
  * Replaces the cuDNN/cuBLAS calls behind pointnet.py:37-41, pointnet2.py:525,247,

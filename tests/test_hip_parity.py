@@ -844,6 +844,37 @@ def test_encode_parity_cars(dev, seeded_sd, sd64, model):
     record_f64("enc_z0", gz0, z0, z64, 1e-5)    # FLAT since the f64 reference column (round 4): 4.1e-6 (round 3: 2.1e-5; f32 oracle 5.9e-4): the max over 20,480 pre-ReLU values
 
 
+def test_feature_propagation_conv_on_the_coarse_level(dev, seeded_sd, sd64, model):
+    """The finest feature-propagation level's first conv runs over the COARSE rows (interpolation and a pointwise conv commute:
+    models/pointnet2.py FP_COMMUTE, csrc/gemm.hip three_interp_add_gn_kernel) when the fine level has twice the points (N = 2048).
+    Against the reference's order (interpolate, concatenate, conv) on the same kernels, and both against the f64 oracle: flat 1e-5."""
+    from caspr_amd import ops
+    import caspr_amd.models.pointnet2 as P2
+    x, _ = car_sequences(1, 2, 2048, seed=5)
+    z64, t64 = O.encode(sd64, x.double())
+    res = {}
+    prev = P2.FP_COMMUTE
+    try:
+        for on in (True, False):
+            P2.FP_COMMUTE = on
+            ops.TIMERS.clear()
+            ops.TIMING = 2
+            z, tn = model.encode(x.to(dev))
+            torch.cuda.synchronize()
+            ops.TIMING = False
+            took = any(k.startswith("k:three_interp_add_gn") for k in ops.TIMERS)
+            assert took == on, "the coarse-level path %s" % ("was not taken" if on else "ran although switched off")
+            res[on] = (z.cpu(), tn.cpu())
+    finally:
+        P2.FP_COMMUTE = prev
+        ops.TIMING = False
+    record("fp_commute_tnocs_vs_f64", res[True][1], t64, 1e-5)
+    record("fp_commute_z0_vs_f64", res[True][0], z64, 1e-5)
+    record("fp_reference_order_tnocs_vs_f64", res[False][1], t64, 1e-5)
+    record("fp_commute_vs_reference_order_tnocs", res[True][1], res[False][1], 5e-6)
+    record("fp_commute_vs_reference_order_z0", res[True][0], res[False][0], 1e-5)
+
+
 @pytest.mark.parametrize("mode", ["bf16x6", "f32"])
 @pytest.mark.parametrize("B,T,N", [(2, 3, 1024), (1, 2, 1000)])
 def test_head_fold_matches_the_separate_last_layer(dev, seeded_sd, sd64, model, mode, B, T, N):
