@@ -958,10 +958,10 @@ extern "C" int caspr_gn_stats_f32(const float *Y, int ldy, int B, int P, int C, 
 // pointwise conv commute -- W [sum_k w_k h_k ; s] + b = sum_k w_k (W_p h_k) + W_s s + b -- so the conv's large part runs over the m coarse
 // rows (caspr_conv1x1_*: u = W_p h, no bias) and this kernel produces the layer's raw output on the n fine rows: the three-neighbour
 // combination of u, plus the skip part on the vector pipe (C2 <= 8 channels: the finest level's 6 augmented coordinates), plus the bias,
-// with the GroupNorm statistics of the result in f64 per 64-row block (the layout gn_finalize_kernel reads).  At cfg-2's finest level:
+// with the GroupNorm statistics of the result in f64 per 128-row block (measured 0.448 / 0.420 / 0.396 / 0.409 ms at 32 / 64 / 128 / 256 rows) (the layout gn_finalize_kernel reads).  At cfg-2's finest level:
 // a 544 -> 512 conv over 327,680 rows becomes a 512 -> 512 conv over 163,840.
 // ---------------------------------------------------------------------------------------------
-#define TIA_ROWS 64
+#define TIA_ROWS 128
 __global__ __launch_bounds__(256) void three_interp_add_gn_kernel(const float *__restrict__ u, int ldu, const int32_t *__restrict__ idx,
                                                                   const float *__restrict__ weight, const float *__restrict__ skip, int lds,
                                                                   int C2, const float *__restrict__ wsk, const float *__restrict__ bias, int m,
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void three_interp_add_gn_kernel(const float *_
             for (int c = 0; c < 8; ++c) wk[q][c] = c < C2 ? wsk[(long)(4 * tq + q) * C2 + c] : 0.f;
         const f32x4 b4 = bias ? ld4(bias + 4 * tq) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const float *ub = u + (long)b * m * ldu + 4 * tq;
-#pragma unroll 4
+#pragma unroll 8
         for (int p = pbeg + tp; p < pend; p += TP) {
             const long row = (long)b * n + p;
             const int i0 = idx[row * 3 + 0], i1 = idx[row * 3 + 1], i2 = idx[row * 3 + 2];
