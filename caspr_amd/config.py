@@ -21,6 +21,7 @@ class KernelConfig:
     early_latent_team: bool = True      # ... on the team kernel with 32 reserved compute units (False: single workgroup, one unit)
     sa_lo_parts: bool = True            # the first set-abstraction level hands hi + lo to the second (models/pointnet2.py)
     sa_scale_streams: bool = True       # the two scales of a set-abstraction level on two streams
+    sa_pre_aggregate: bool = True       # set abstraction, wide levels: the first layer's feature part once per source point, not per (centre, sample)
     fp_commute: bool = True             # feature propagation's first conv on the coarse level (finest level: interpolation and conv commute)
     sa_f64_streams: bool = False        # the f64 re-evaluation of a scale's small balls beside its MFMA kernel, on a stream of its own (measured: + 0.4 ms, off)
     train_cnf_out_node: bool = True     # training: the ODE function's output epilogue as one node (train/flow_grad.py)
@@ -41,6 +42,7 @@ _ENV = {
     "CASPR_SA_SCALE_STREAMS": ("sa_scale_streams", lambda v: v != "0"),
     "CASPR_SA_F64_STREAMS": ("sa_f64_streams", lambda v: v != "0"),
     "CASPR_FP_COMMUTE": ("fp_commute", lambda v: v != "0"),
+    "CASPR_SA_PRE_AGGREGATE": ("sa_pre_aggregate", lambda v: v != "0"),
     "CASPR_CNF_OUT_NODE": ("train_cnf_out_node", lambda v: v != "0"),
     "CASPR_CNF_NODE": ("train_cnf_hidden_node", lambda v: v != "0"),
     "CASPR_LATENT_NODE": ("train_latent_node", lambda v: v != "0"),
@@ -80,5 +82,5 @@ def active():
     d = asdict(config)
     d.update({"matmul": ops.matmul_mode(), "conv_x6w": ops.CONV_X6W, "x6w_min_cin": ops._X6W_MIN_CIN, "latent_team": ops.LATENT_TEAM,
               "early_latent": _c.EARLY_LATENT, "early_latent_team": _c.EARLY_LATENT_TEAM, "sa_lo_parts": _p.LO_PARTS,
-              "sa_scale_streams": _p.SCALE_STREAMS, "sa_f64_streams": _p.F64_STREAMS, "fp_commute": _p.FP_COMMUTE, "debug_env": os.environ.get("CASPR_DEBUG", "0") == "1"})
+              "sa_scale_streams": _p.SCALE_STREAMS, "sa_f64_streams": _p.F64_STREAMS, "fp_commute": _p.FP_COMMUTE, "sa_pre_aggregate": _p.PRE_AGGREGATE, "debug_env": os.environ.get("CASPR_DEBUG", "0") == "1"})
     return d

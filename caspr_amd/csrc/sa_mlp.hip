@@ -32,6 +32,9 @@ struct SaArgs {
     int ldo, out_off;
     int rowsA, rowsB;  // kq rows of the two ping-pong B-tiles
     int split_last;    // LDS kernel: the last layer in two halves of cout / 2 channels (8 GroupNorm groups each) through a half-size tile
+    const float *pre;  // LDS kernel, pre-aggregated first layer: pre[b, point, 0:C1] = W_f . feat of every SOURCE point (ldp floats per row) ...
+    int ldp;
+    const float *wx;   // ... and the layer's three coordinate columns, (C1, 3) row-major: y_1 = pre[sample] + wx . (p - centre) + bias
     unsigned long long *trace;   // debug stamps (NULL in production)
 };
 
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     float *s_rstd = reinterpret_cast<float *>(s_mean + NSTAT);              // [NSTAT]
     float *s_cen = s_rstd + NSTAT;              // [NCEN*4]
     int *s_idx = reinterpret_cast<int *>(s_cen + NCEN * 4);  // [NCOL]
+    float *s_d = reinterpret_cast<float *>(s_idx + NCOL);    // [NCOL*4]  p - centre of every column (pre-aggregated first layer)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
@@ -74,6 +78,47 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
     }
     __syncthreads();
 
+    if (a.pre) {
+        // ---- PRE-AGGREGATED FIRST LAYER.  Layer 1 is linear in front of its GroupNorm and its feature part does not depend on the centre:
+        // W [p - c ; f] = W_x (p - c) + W_f f, and W_f f is a property of the SOURCE point -- computed once per point by a plain conv over
+        // the level's n points (caspr_sa_mlp_max_pre_f32's `pre`) instead of once per (centre, sample) pair: 8-16 times fewer rows at the
+        // third level, 4-8 at the fourth, and the gather moves C1 floats per sample instead of C + 3.  The tile this pass fills IS layer 1's
+        // output (pre-GroupNorm), so the layer's MFMA phase is skipped.
+        if (tid < NCOL) {
+            const float *p = a.xyz + ((long)b * a.n + s_idx[tid]) * 3;
+            const float *c = s_cen + (tid / NS) * 4;
+            s_d[tid * 4 + 0] = p[0] - c[0];          // the grouper's f32 subtraction (pointnet2.py:391-398)
+            s_d[tid * 4 + 1] = p[1] - c[1];
+            s_d[tid * 4 + 2] = p[2] - c[2];
+        }
+        __syncthreads();
+        const int nq1 = a.L[0].cout >> 2;
+        constexpr int GU = 4;
+        const int nit = NCOL * nq1;
+        for (int base = tid; base < nit; base += 256 * GU) {
+            f32x4 v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int it = base + 256 * u < nit ? base + 256 * u : nit - 1;   // clamped: the store below is guarded
+                const int kq = it % nq1, col = it / nq1;
+                v[u] = ld4(a.pre + ((long)b * a.n + s_idx[col]) * a.ldp + kq * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int it = base + 256 * u;
+                if (it >= nit) continue;
+                const int kq = it % nq1, col = it / nq1;
+                const f32x4 w0 = ld4(a.wx + kq * 12), w1 = ld4(a.wx + kq * 12 + 4), w2 = ld4(a.wx + kq * 12 + 8);   // rows 4 kq .. 4 kq + 3 of (C1, 3)
+                const f32x4 bias4 = ld4(a.L[0].bias + kq * 4);
+                const float d0 = s_d[col * 4 + 0], d1 = s_d[col * 4 + 1], d2 = s_d[col * 4 + 2];
+                const float wr[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+                f32x4 r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = (fmaf(wr[3 * q + 2], d2, fmaf(wr[3 * q + 1], d1, wr[3 * q] * d0)) + v[u][q]) + bias4[q];
+                st4(bufB + btile_off(kq, col, NCOL), r);
+            }
+        }
+    } else
     // ---- gather: K order = [feat (C, padded to C4) | dx dy dz 0 | zeros ...]
     {
         const int C4 = (a.C + 3) & ~3;
@@ -132,7 +177,9 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SaArgs a)
         const int RT = halved ? RTall >> 1 : RTall;          // row tiles of this pass
         const int rt0 = halved ? half * RT : 0;              // ... starting at
         // ---- MFMA: work items (row tile, column group)
-        if (RT >= 4) {
+        if (pass == 0 && a.pre) {
+            // (the gather filled this pass's output tile)
+        } else if (RT >= 4) {
             for (int rtl = wave; rtl < RT; rtl += 4) {
                 const int rt = rt0 + rtl;
                 f32x4 acc[CT];
@@ -1088,10 +1135,12 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
                            const float *b1, const float *g1, const float *be1, int C1, const float *w2p,
                            const float *b2, const float *g2, const float *be2, int C2, const float *w3p,
                            const float *b3, const float *g3, const float *be3, int C3, float *out, int ldo,
-                           int out_off, int32_t *workspace, void *stream)
+                           int out_off, int32_t *workspace, void *stream, const float *pre = nullptr, int ldp = 0, const float *wx = nullptr)
 {
-    CASPR_REQUIRE(xyz && new_xyz && idx && out && w1p && w2p && w3p && b1 && b2 && b3 && g1 && g2 && g3 && be1 && be2 && be3,
+    CASPR_REQUIRE(xyz && new_xyz && idx && out && (w1p || pre) && w2p && w3p && b1 && b2 && b3 && g1 && g2 && g3 && be1 && be2 && be3,
                   "sa_mlp_max: null pointer");
+    CASPR_REQUIRE(!pre || (wx && C == 0 && !feat && feat_kind == 0 && C1 >= 64 && ldp % 4 == 0 && ldp >= C1 && ((uintptr_t)pre % 16) == 0 && ((uintptr_t)wx % 16) == 0),
+                  "sa_mlp_max_pre: needs wx, no feat / C / feat_kind, a first layer of >= 64 channels (the LDS kernel's shapes), pre rows of ldp %% 4 == 0 >= C1 floats");
     CASPR_REQUIRE(C == 0 || (feat && ldf % 4 == 0 && ldf >= ((C + 3) & ~3)), "sa_mlp_max: feat/ldf invalid (C=%d ldf=%d)", C, ldf);
     CASPR_REQUIRE(ns == 16 || ns == 32, "sa_mlp_max: ns=%d unsupported (16 or 32)", ns);
     CASPR_REQUIRE(C1 % 16 == 0 && C2 % 16 == 0 && C3 % 16 == 0 && C1 > 0 && C2 > 0 && C3 > 0,
@@ -1115,6 +1164,7 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
     a.L[1] = {w2p, b2, g2, be2, C2, 2 * ((C1 + 31) / 32), 2 * ((C1 + 31) / 32)};
     a.L[2] = {w3p, b3, g3, be3, C3, 2 * ((C2 + 31) / 32), 2 * ((C2 + 31) / 32)};
     a.out = out; a.ldo = ldo; a.out_off = out_off;
+    a.pre = pre; a.ldp = ldp; a.wx = wx;
     a.trace = nullptr;
     CASPR_IF_DEBUG(a.trace = g_sa_trace;)
     const int rA = a.L[0].kcr * 4 > a.L[2].kc * 4 ? a.L[0].kcr * 4 : a.L[2].kc * 4;
@@ -1192,9 +1242,9 @@ static int sa_mlp_max_impl(const float *xyz, const float *new_xyz, const float *
     if (only_f64) return CASPR_OK;        // the LDS kernel's shapes have no f64 half
     // 32 columns per workgroup from 128 input channels up (round 5, second part: the third level too -- 37 KB of LDS, four workgroups per
     // CU instead of two of 75 KB: 0.505 -> 0.474 and 1.219 -> 1.187 ms for its two scales, A/B in one box)
-    const int bigK = (K0 > 128) || (C3 > 128);
+    const int bigK = (K0 > 128) || (C3 > 128) || pre != nullptr;
     const int ncol = bigK ? 32 : 64;
-    const size_t shmem = (size_t)(a.rowsA + a.rowsB) * ncol * 16 + (3 * 64 + 16 + 64) * 4 + 64;
+    const size_t shmem = (size_t)(a.rowsA + a.rowsB) * ncol * 16 + (3 * 64 + 16 + 64) * 4 + 64 + 64 * 4 * 4;     // + s_d
     CASPR_REQUIRE(shmem <= 160 * 1024, "sa_mlp_max: needs %zu bytes of LDS (> 160 KiB)", shmem);
     int rc;
     if (ns == 16 && ncol == 64) rc = launch_sa<16, 64>(a, B, shmem, st);
@@ -1228,4 +1278,17 @@ extern "C" int caspr_sa_mlp_max_ws_f32(const float *xyz, const float *new_xyz, c
 {
     return sa_mlp_max_impl(xyz, new_xyz, feat, ldf, idx, B, n, M, C, ns, feat_kind, w1p, b1, g1, be1, C1, w2p, b2, g2, be2, C2, w3p, b3, g3,
                            be3, C3, out, ldo, out_off, workspace, stream);
+}
+
+// The LDS kernel's shapes with the first layer PRE-AGGREGATED (see sa_mlp_kernel): pre (B, n, ldp) = W_f . feat over the level's source points
+// (a plain conv, no bias: caspr_conv1x1_*), wx1 (C1, 3) row-major = the layer's coordinate columns, b1 / g1 / be1 its bias and GroupNorm.
+extern "C" int caspr_sa_mlp_max_pre_f32(const float *xyz, const float *new_xyz, const float *pre, int ldp, const int32_t *idx, int B, int n,
+                                        int M, int ns, const float *wx1, const float *b1, const float *g1, const float *be1, int C1,
+                                        const float *w2p, const float *b2, const float *g2, const float *be2, int C2, const float *w3p,
+                                        const float *b3, const float *g3, const float *be3, int C3, float *out, int ldo, int out_off,
+                                        void *stream)
+{
+    CASPR_REQUIRE(pre && wx1, "sa_mlp_max_pre: null pointer");
+    return sa_mlp_max_impl(xyz, new_xyz, nullptr, 0, idx, B, n, M, 0, ns, 0, nullptr, b1, g1, be1, C1, w2p, b2, g2, be2, C2, w3p, b3, g3, be3, C3,
+                           out, ldo, out_off, nullptr, stream, pre, ldp, wx1);
 }

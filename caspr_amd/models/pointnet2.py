@@ -23,6 +23,7 @@ from .lazy import Lazy
 NUM_GROUPS = 16  # for group norm (pointnet2.py:12)
 LO_PARTS = _cfg.sa_lo_parts  # the first set-abstraction level hands its output to the second as an unevaluated sum hi + lo (PointNet2feat.run)
 SCALE_STREAMS = _cfg.sa_scale_streams  # the two scales of a set-abstraction level on two streams (PointNet2SetAbstraction.run)
+PRE_AGGREGATE = _cfg.sa_pre_aggregate  # the wide set-abstraction levels' first layer once per source point (PointNet2SetAbstraction.run)
 FP_COMMUTE = _cfg.fp_commute           # feature propagation's first conv on the coarse level where the skip part is tiny (PointNet2FeaturePropagator.run)
 F64_STREAMS = _cfg.sa_f64_streams      # ... and the f64 re-evaluation of each scale's small balls on a stream of its own, beside its MFMA kernel
 _SCALE_STREAM = {}
@@ -112,6 +113,16 @@ class PointNetFeatureExtractor(nn.Module):
                 return ops.PackedWeight(w.contiguous())
             out.append((self._cache.get("l%d" % l, [conv.weight], build), conv.bias, gn.weight, gn.bias))
         return out
+
+    def pre_layers(self):
+        """The first layer split for pre-aggregation (csrc/sa_mlp.hip): (PackedWeight of its feature columns W[:, 3:], its coordinate
+        columns W[:, :3] as a (C1, 3) tensor)."""
+        conv = self.conv_layers[0]
+
+        def build():
+            w = conv.weight.detach()[:, :, 0]
+            return ops.PackedWeight(w[:, 3:].contiguous()), w[:, :3].contiguous()
+        return self._cache.get("pre", [conv.weight], build)
 
     def row_layers(self, cin_pad):
         """3 x (PackedWeight, bias, gamma, beta) for the row-materialised form (run_rows): reference channel order
@@ -257,6 +268,13 @@ class PointNet2SetAbstraction(nn.Module):
                     self._await(idx, i)
                 if ops.CONV_BF16X6 and C + 3 >= ROWS_MIN_CIN and (M * ns) % 128 == 0:
                     self._run_rows(xyz, new_xyz, feat, C, idx["ball_idx"][i], i, out, off)
+                elif PRE_AGGREGATE and self.pointnet_layer_dims_list[i][0] >= 64 and C >= 32 and feat_kind == 0 and xyz.shape[1] >= 128:
+                    # the first layer's feature part once per SOURCE point (a conv over this level's n points) instead of once per
+                    # (centre, sample) pair; the fused kernel starts from it (csrc/sa_mlp.hip: pre-aggregated first layer)
+                    pn = self.pointnet_modules[i]
+                    pw_f, wx = pn.pre_layers()
+                    pre = ops.conv1x1(pw_f, None, feat)
+                    ops.sa_mlp_max_pre(xyz, new_xyz, pre, idx["ball_idx"][i], wx, pn.kernel_layers(), out, off)
                 else:
                     ops.sa_mlp_max(xyz, new_xyz, feat, idx["ball_idx"][i], C, self.pointnet_modules[i].kernel_layers(), out, off,
                                    feat_kind=feat_kind, part="mfma" if halves else None)  # :391-409

@@ -595,6 +595,27 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0, pa
     return out
 
 
+def sa_mlp_max_pre(xyz, new_xyz, pre, idx, wx, layers, out, out_off):
+    """sa_mlp_max with the first layer pre-aggregated (include/caspr_hip.h: caspr_sa_mlp_max_pre_f32): pre (B,n,>=C1) = W_f . feat over the
+    level's source points, wx (C1,3) the layer's coordinate columns; layers = 3 x (PackedWeight | None, bias, gamma, beta) -- the first
+    entry's weight is not used."""
+    _chk_f32(xyz, new_xyz, pre, wx, out)
+    _chk_i32(idx)
+    B, n, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    ldp = _chk_rows(pre)
+    (_, b1, g1, be1), (pw2, b2, g2, be2), (pw3, b3, g3, be3) = layers
+    _chk_f32(b1, g1, be1, b2, g2, be2, b3, g3, be3)
+    C1 = g1.numel()
+    # FLOPs of the REFERENCE's formulation (every gathered sample through all three layers), so that the rate stays comparable
+    flop = 2.0 * B * M * ns * (C1 * pw2.cout + pw2.cout * pw3.cout)
+    with timed("k:sa_mlp_max_pre:%d:%d:%d:%d" % (C1, pw3.cout, B * M * ns, int(flop // 1000000)), 2):
+        _lib.check(_lib.load().caspr_sa_mlp_max_pre_f32(_p(xyz), _p(new_xyz), _p(pre), ldp, _p(idx), B, n, M, ns, _p(wx), _p(b1), _p(g1), _p(be1), C1,
+                                                        _p(pw2.data), _p(b2), _p(g2), _p(be2), pw2.cout, _p(pw3.data), _p(b3), _p(g3), _p(be3), pw3.cout,
+                                                        _p(out), out.shape[2], out_off, _stream()), "caspr_sa_mlp_max_pre_f32")
+    return out
+
+
 LATENT_TEAM = _cfg.latent_team   # multi-workgroup latent ODE kernel (False: single-workgroup kernel)
 _team_ws = {}
 

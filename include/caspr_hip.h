@@ -112,6 +112,17 @@ int caspr_sa_mlp_max_ws_f32(const float *xyz, const float *new_xyz, const float 
                             const float *w2p, const float *b2, const float *g2, const float *be2, int C2,
                             const float *w3p, const float *b3, const float *g3, const float *be3, int C3,
                             float *out, int ldo, int out_off, int32_t *workspace, void *stream);
+/* The same level with its first layer PRE-AGGREGATED (the LDS kernel's shapes: C1 >= 64).  Layer 1 is linear in front of its GroupNorm and
+ * its feature part does not depend on the centre -- W [p - c ; f] = W_x (p - c) + W_f f -- so W_f f is computed once per SOURCE point by a
+ * plain conv over the level's n points (pre (B, n, ldp), no bias) instead of once per (centre, sample) pair; the kernel gathers pre rows
+ * (C1 floats per sample instead of C + 3), adds wx1 (C1, 3) . (p - c) + b1 and continues with GroupNorm 1, layers 2 and 3 and the max.
+ * An exact reformulation of pointnet2.py:391-409,677-698 (the two parts of the dot product are rounded separately: ~1e-7).           */
+int caspr_sa_mlp_max_pre_f32(const float *xyz, const float *new_xyz, const float *pre, int ldp, const int32_t *idx, int B, int n,
+                             int M, int ns, const float *wx1, const float *b1, const float *g1, const float *be1, int C1,
+                             const float *w2p, const float *b2, const float *g2, const float *be2, int C2,
+                             const float *w3p, const float *b3, const float *g3, const float *be3, int C3,
+                             float *out, int ldo, int out_off, void *stream);
+
 
 /* ---------------- Kaolin three_nn + inverse-distance weights: models/pointnet2.py:514-518
  * unknown (B,n,3), known (B,m,3) -> dist (B,n,3) [sqrt], idx (B,n,3), weight (B,n,3) (may be NULL) */

@@ -617,6 +617,42 @@ def test_sa_mlp_max(dev, seeded_sd, model, level, scale):
     assert float(out[:, :, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("level,scale", [(2, 0), (2, 1), (3, 0), (3, 1)])
+def test_sa_mlp_max_pre_aggregated(dev, seeded_sd, model, level, scale):
+    """The wide levels with the first layer's feature part computed once per SOURCE point (ops.sa_mlp_max_pre, csrc/sa_mlp.hip): against
+    the f64 oracle of the reference's formulation at the flat 1e-5, and against the fused call's own result."""
+    from caspr_amd import ops
+    sa = model.encoder.local_extract.set_abstractions[level]
+    n_in = [2048, 1024, 512, 256, 64][level]
+    C = [6, 96, 128, 256, 512][level]
+    M = sa.num_points_out
+    c = clouds(2, n_in, seed=level) * [1, 1.5, 2.0, 3.0, 4.0][level]
+    feat = rnd(level + 7, 2, n_in, C, scale=0.7)
+    idx = P.furthest_point_sampling(c, M)
+    ctr = torch.gather(c, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    g = sa.grouper_modules[scale]
+    bidx = P.ball_query(g.radius, g.num_samples, c, ctr)
+    grouped = P.group(c, ctr, feat.transpose(1, 2).contiguous(), bidx)
+    pre_ = "encoder.local_extract.set_abstractions.%d.pointnet_modules.%d" % (level, scale)
+    want = O.feature_extractor(seeded_sd, pre_, grouped.view(-1, C + 3, g.num_samples)).view(2, M, -1)
+    sd64 = {k: v.double() for k, v in seeded_sd.items() if k.startswith(pre_)}
+    want64 = O.feature_extractor(sd64, pre_, grouped.view(-1, C + 3, g.num_samples).double()).view(2, M, -1)
+    pn = sa.pointnet_modules[scale]
+    pw_f, wx = pn.pre_layers()
+    fdev = feat.to(dev).contiguous()
+    pre = ops.conv1x1(pw_f, None, fdev)
+    out = torch.zeros(2, M, want.shape[2] + 8, device=dev)
+    ops.sa_mlp_max_pre(c.to(dev), ctr.to(dev), pre, bidx.to(dev), wx, pn.kernel_layers(), out, 8)
+    record_f64("sa_mlp_pre_l%d_s%d" % (level, scale), out[:, :, 8:], want, want64, 1e-5)
+    assert float(out[:, :, :8].abs().max()) == 0.0
+    fused = torch.zeros(2, M, want.shape[2], device=dev)
+    ldf = (C + 3) // 4 * 4
+    fpad = torch.zeros(2, n_in, ldf)
+    fpad[:, :, :C] = feat
+    ops.sa_mlp_max(c.to(dev), ctr.to(dev), fpad.to(dev), bidx.to(dev), C, pn.kernel_layers(), fused, 0)
+    record("sa_mlp_pre_vs_fused_l%d_s%d" % (level, scale), out[:, :, 8:], fused, 1e-5)
+
+
 @pytest.mark.parametrize("level,scale", [(0, 0), (0, 1), (1, 0)])
 def test_sa_small_balls_with_foreign_index_layouts(dev, seeded_sd, model, level, scale):
     """The f64 re-evaluation of small balls (sa_repair_f64_kernel) and the register kernel's early exit for waves made of such balls both
