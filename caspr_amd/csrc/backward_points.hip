@@ -119,6 +119,48 @@ extern "C" int caspr_group_rows_f32(const float *xyz, const float *new_xyz, cons
     return CASPR_OK;
 }
 
+// The first layer of a point MLP as rows when its feature part was PRE-AGGREGATED per source point (csrc/sa_mlp.hip: pre-aggregated first
+// layer; the row-materialised form of the coarsest level): Y1[(b*M+j)*ns+s, c] = pre[b, i, c] + wx[c] . (xyz[b,i] - new_xyz[b,j]) + bias[c].
+__global__ __launch_bounds__(256) void group_rows_pre_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                             const float *__restrict__ pre, int ldp, const int32_t *__restrict__ idx, int n,
+                                                             int M, int C1, int ns, const float *__restrict__ wx,
+                                                             const float *__restrict__ bias, float *__restrict__ Y, int ldy, long rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long bj = row / ns;
+    const long b = bj / M;
+    const int i = idx[row];
+    const float *px = xyz + (b * n + i) * 3, *pc = new_xyz + bj * 3;
+    const float d0 = px[0] - pc[0], d1 = px[1] - pc[1], d2 = px[2] - pc[2];      // the grouper's f32 subtraction (pointnet2.py:391-398)
+    const float *f = pre + (b * n + i) * ldp;
+    float *o = Y + row * ldy;
+    for (int c = lane * 4; c < C1; c += 256) {      // host: C1 % 4 == 0
+        const f32x4 v = ld4(f + c), b4 = ld4(bias + c);
+        const f32x4 w0 = ld4(wx + c * 3), w1 = ld4(wx + c * 3 + 4), w2 = ld4(wx + c * 3 + 8);   // rows c .. c + 3 of (C1, 3)
+        const float wr[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = (fmaf(wr[3 * q + 2], d2, fmaf(wr[3 * q + 1], d1, wr[3 * q] * d0)) + v[q]) + b4[q];
+        st4(o + c, r);
+    }
+}
+
+extern "C" int caspr_group_rows_pre_f32(const float *xyz, const float *new_xyz, const float *pre, int ldp, const int32_t *idx, int B, int n,
+                                        int M, int C1, int ns, const float *wx, const float *bias, float *Y, int ldy, void *stream)
+{
+    CASPR_REQUIRE(xyz && new_xyz && pre && idx && wx && bias && Y && B > 0 && n > 0 && M > 0 && ns > 0 && C1 > 0, "group_rows_pre: bad arguments");
+    CASPR_REQUIRE(C1 % 4 == 0 && ldp % 4 == 0 && ldp >= C1 && ldy % 4 == 0 && ldy >= C1 && ((uintptr_t)pre % 16) == 0 && ((uintptr_t)wx % 16) == 0 &&
+                  ((uintptr_t)bias % 16) == 0 && ((uintptr_t)Y % 16) == 0,
+                  "group_rows_pre: C1=%d ldp=%d ldy=%d must be multiples of 4 (16-byte rows)", C1, ldp, ldy);
+    const long rows = (long)B * M * ns;
+    group_rows_pre_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(xyz, new_xyz, pre, ldp, idx, n, M, C1, ns, wx,
+                                                                                                   bias, Y, ldy, rows);
+    CASPR_CHECK_LAUNCH("group_rows_pre");
+    return CASPR_OK;
+}
+
 extern "C" int caspr_group_rows_bwd_f32(const float *dG, int ldg, const int32_t *idx, int B, int n, int M, int C, int ns,
                                         float *dFeat, int ldf, void *stream)
 {

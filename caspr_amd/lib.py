@@ -41,6 +41,7 @@ SIGNATURES = {
                                          c_fp, c_fp, c_fp, c_fp, c_int,
                                          c_fp, c_fp, c_fp, c_fp, c_int,
                                          c_fp, c_int, c_int, c_stream]),
+    "caspr_group_rows_pre_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_stream]),
     "caspr_three_nn_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_ip, c_fp, c_stream]),
     "caspr_three_interp_f32": (c_int, [c_fp, c_int, c_ip, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_three_interp_add_gn_ws_bytes": (c_long, [c_int, c_int, c_int]),

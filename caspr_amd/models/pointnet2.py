@@ -309,9 +309,17 @@ class PointNet2SetAbstraction(nn.Module):
         pn = self.pointnet_modules[i]
         kin = (3 + C + 31) // 32 * 32
         layers = pn.row_layers(kin)
-        cur = T.group_rows(xyz, new_xyz, feat, C, ball_idx, align=32)
+        pre_agg = PRE_AGGREGATE and C % 4 == 0 and self.pointnet_layer_dims_list[i][0] % 4 == 0
+        if pre_agg:
+            # the first layer's feature part once per source point (64 rows per frame at the coarsest level instead of 256 / 512
+            # gathered ones), then its rows = pre[sample] + W_x (p - c) + b straight from the gather (csrc/backward_points.hip)
+            pw_f, wx = pn.pre_layers()
+            pre = ops.conv1x1(pw_f, None, feat)
+            cur = None
+        else:
+            cur = T.group_rows(xyz, new_xyz, feat, C, ball_idx, align=32)
         for l, (pw, bias, gamma, beta) in enumerate(layers):
-            y = ops.conv1x1(pw, bias, cur)
+            y = ops.group_rows_pre(xyz, new_xyz, pre, ball_idx, wx, bias) if (pre_agg and l == 0) else ops.conv1x1(pw, bias, cur)
             last = l == len(layers) - 1
             cur, _, _, _ = T.gn_rows(y, ns, pw.cout, gamma, beta, relu=not last, maxout=out[:, :, off:off + pw.cout] if last else None)
 

@@ -595,6 +595,19 @@ def sa_mlp_max(xyz, new_xyz, feat, idx, C, layers, out, out_off, feat_kind=0, pa
     return out
 
 
+def group_rows_pre(xyz, new_xyz, pre, idx, wx, bias):
+    """The pre-aggregated first layer as rows (include/caspr_hip.h: caspr_group_rows_pre_f32): -> Y (B, M*ns, C1) raw layer-1 output."""
+    _chk_f32(xyz, new_xyz, pre, wx, bias)
+    _chk_i32(idx)
+    B, n, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    C1 = bias.numel()
+    Y = torch.empty(B, M * ns, C1, device=xyz.device, dtype=torch.float32)
+    _lib.check(_lib.load().caspr_group_rows_pre_f32(_p(xyz), _p(new_xyz), _p(pre), _chk_rows(pre), _p(idx), B, n, M, C1, ns, _p(wx), _p(bias), _p(Y), C1,
+                                                    _stream()), "caspr_group_rows_pre_f32")
+    return Y
+
+
 def sa_mlp_max_pre(xyz, new_xyz, pre, idx, wx, layers, out, out_off):
     """sa_mlp_max with the first layer pre-aggregated (include/caspr_hip.h: caspr_sa_mlp_max_pre_f32): pre (B,n,>=C1) = W_f . feat over the
     level's source points, wx (C1,3) the layer's coordinate columns; layers = 3 x (PackedWeight | None, bias, gamma, beta) -- the first

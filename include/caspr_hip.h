@@ -122,6 +122,11 @@ int caspr_sa_mlp_max_pre_f32(const float *xyz, const float *new_xyz, const float
                              const float *w2p, const float *b2, const float *g2, const float *be2, int C2,
                              const float *w3p, const float *b3, const float *g3, const float *be3, int C3,
                              float *out, int ldo, int out_off, void *stream);
+/* The pre-aggregated first layer as ROWS (the row-materialised form of the coarsest level, models/pointnet2.py: _run_rows):
+ * Y[(b*M+j)*ns+s, 0:C1] = pre[b, idx[b,j,s], 0:C1] + wx (C1,3) . (xyz[b, idx[b,j,s]] - new_xyz[b,j]) + bias -- the raw output of layer 1. */
+int caspr_group_rows_pre_f32(const float *xyz, const float *new_xyz, const float *pre, int ldp, const int32_t *idx, int B, int n,
+                             int M, int C1, int ns, const float *wx, const float *bias, float *Y, int ldy, void *stream);
+
 
 
 /* ---------------- Kaolin three_nn + inverse-distance weights: models/pointnet2.py:514-518
