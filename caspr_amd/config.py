@@ -21,6 +21,7 @@ class KernelConfig:
     early_latent_team: bool = True      # ... on the team kernel with 32 reserved compute units (False: single workgroup, one unit)
     sa_lo_parts: bool = True            # the first set-abstraction level hands hi + lo to the second (models/pointnet2.py)
     sa_scale_streams: bool = True       # the two scales of a set-abstraction level on two streams
+    global_stream: bool = False         # the global PointNet on a stream of its own (models/tpointnet2.py); A/B pending
     sa_pre_aggregate: bool = True       # set abstraction, wide levels: the first layer's feature part once per source point, not per (centre, sample)
     fp_commute: bool = True             # feature propagation's first conv on the coarse level (finest level: interpolation and conv commute)
     sa_f64_streams: bool = False        # the f64 re-evaluation of a scale's small balls beside its MFMA kernel, on a stream of its own (measured: + 0.4 ms, off)
@@ -43,6 +44,7 @@ _ENV = {
     "CASPR_SA_F64_STREAMS": ("sa_f64_streams", lambda v: v != "0"),
     "CASPR_FP_COMMUTE": ("fp_commute", lambda v: v != "0"),
     "CASPR_SA_PRE_AGGREGATE": ("sa_pre_aggregate", lambda v: v != "0"),
+    "CASPR_GLOBAL_STREAM": ("global_stream", lambda v: v != "0"),
     "CASPR_CNF_OUT_NODE": ("train_cnf_out_node", lambda v: v != "0"),
     "CASPR_CNF_NODE": ("train_cnf_hidden_node", lambda v: v != "0"),
     "CASPR_LATENT_NODE": ("train_latent_node", lambda v: v != "0"),
@@ -78,9 +80,9 @@ config = load()
 def active():
     """The selection in force NOW (module state, which tests / tools / bench.py may have switched since import)."""
     from . import ops
-    from .models import caspr as _c, pointnet2 as _p
+    from .models import caspr as _c, pointnet2 as _p, tpointnet2 as _t
     d = asdict(config)
     d.update({"matmul": ops.matmul_mode(), "conv_x6w": ops.CONV_X6W, "x6w_min_cin": ops._X6W_MIN_CIN, "latent_team": ops.LATENT_TEAM,
               "early_latent": _c.EARLY_LATENT, "early_latent_team": _c.EARLY_LATENT_TEAM, "sa_lo_parts": _p.LO_PARTS,
-              "sa_scale_streams": _p.SCALE_STREAMS, "sa_f64_streams": _p.F64_STREAMS, "fp_commute": _p.FP_COMMUTE, "sa_pre_aggregate": _p.PRE_AGGREGATE, "debug_env": os.environ.get("CASPR_DEBUG", "0") == "1"})
+              "sa_scale_streams": _p.SCALE_STREAMS, "sa_f64_streams": _p.F64_STREAMS, "fp_commute": _p.FP_COMMUTE, "sa_pre_aggregate": _p.PRE_AGGREGATE, "global_stream": _t.GLOBAL_STREAM, "debug_env": os.environ.get("CASPR_DEBUG", "0") == "1"})
     return d

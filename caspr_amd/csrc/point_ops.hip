@@ -320,12 +320,70 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
     for (int s = cnt + lane; s < ns; s += 64) o[s] = first;  // first == 0 when there was no hit
 }
 
+// The same scan with the cloud in LDS (round 5, second part).  The kernel above reads the frame's 12 n bytes from L1 / L2 once per CENTRE:
+// 1024 centres x 24 KB x 160 frames = 3.9 GB per call at cfg-2's first level -- 12 TB/s of cache traffic in its 330 us, the bound.  Here a
+// workgroup copies the cloud into LDS once and its four waves walk BQ_CPW centres each against that copy: same comparisons in the same order
+// (bit-identical index rows by construction), the traffic on the LDS array.  For clouds that fit (n <= BQ_LDS_MAX_N) with enough centres
+// per frame to pay for the copy.
+#define BQ_CPW 16
+#define BQ_LDS_MAX_N 12288
+__global__ __launch_bounds__(256) void ball_query_lds_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int n, int M,
+                                                             float r2, int ns, int32_t *__restrict__ idx)
+{
+    extern __shared__ __attribute__((aligned(16))) float sp[];     // [n * 3]: stride-3 word reads across a wave are bank-conflict free
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const float *p = xyz + (long)b * n * 3;
+    for (int i = threadIdx.x; i < n * 3; i += 256) sp[i] = p[i];
+    __syncthreads();
+    const int m0 = (blockIdx.x * 4 + wave) * BQ_CPW;
+    for (int cc = 0; cc < BQ_CPW; ++cc) {
+        const int m = m0 + cc;
+        if (m >= M) break;                                         // wave-uniform
+        const long c = (long)b * M + m;
+        const float cx = new_xyz[c * 3 + 0], cy = new_xyz[c * 3 + 1], cz = new_xyz[c * 3 + 2];
+        int32_t *o = idx + c * ns;
+        int cnt = 0, first = 0;
+        for (int base = 0; base < n && cnt < ns; base += 64) {
+            const int k = base + lane;
+            bool hit = false;
+            if (k < n) {
+                const float d2 = sqdist3(cx, cy, cz, sp[k * 3 + 0], sp[k * 3 + 1], sp[k * 3 + 2]);
+                hit = d2 < r2;
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
+                const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                if (hit && slot < ns) o[slot] = k;
+                cnt += __popcll(mask);
+            }
+        }
+        cnt = cnt < ns ? cnt : ns;
+        for (int s = cnt + lane; s < ns; s += 64) o[s] = first;  // first == 0 when there was no hit
+    }
+}
+
 extern "C" int caspr_ball_query_f32(const float *xyz, const float *new_xyz, int B, int n, int M, float radius,
                                     int ns, int32_t *idx, void *stream)
 {
     CASPR_REQUIRE(xyz && new_xyz && idx && B > 0 && n > 0 && M > 0 && ns > 0, "ball_query: bad arguments");
     const long centres = (long)B * M;
     volatile float r2 = radius * radius;
+    if (n <= BQ_LDS_MAX_N && M >= 4 * BQ_CPW && n >= 256 && B <= 65535) {
+        // a rule on the frame's shape only (never on the number of frames); the two kernels write the same bits anyway
+        const size_t sh = (size_t)n * 3 * sizeof(float);
+        if (sh > 64 * 1024) {
+            static CasprLdsOptIn optin;
+            if (caspr_lds_opt_in(optin, (const void *)ball_query_lds_kernel, BQ_LDS_MAX_N * 3 * sizeof(float)) != hipSuccess) {
+                caspr_set_error("ball_query: hipFuncSetAttribute failed");
+                return CASPR_ELAUNCH;
+            }
+        }
+        ball_query_lds_kernel<<<dim3(ceil_div(M, 4 * BQ_CPW), B), dim3(256), sh, (hipStream_t)stream>>>(xyz, new_xyz, n, M, r2, ns, idx);
+        CASPR_CHECK_LAUNCH("ball_query");
+        return CASPR_OK;
+    }
     ball_query_kernel<<<dim3((unsigned)((centres + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
         xyz, new_xyz, n, M, r2, ns, idx, centres);
     CASPR_CHECK_LAUNCH("ball_query");

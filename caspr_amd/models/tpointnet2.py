@@ -8,10 +8,13 @@ Differences in *how* (not what) it computes, all documented in DESIGN.md:
   * GroupNorm+ReLU between the 1600-wide convs is folded into the next conv's operand load;
   * z0 = max over points of bn2(conv2(.)) comes out of the GroupNorm statistics pass.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
 from .. import ops
+from ..config import config as _cfg
 from ..utils.weight_cache import WeightCache
 from .pointnet import PointNetfeat
 from .pointnet2 import PointNet2feat as PointNet2
@@ -22,6 +25,7 @@ from .pointnet2 import PointNet2feat as PointNet2
 # early, this HBM-bound conv holds back the three small kernels the flow waits for (0.7 ms between the encoder's last statistics and the flow's
 # first workgroup) -- but queued late it runs entirely in front of the flow: 69.64 -> 69.97 ms.  Early it is.
 LATE_TNOCS_LAUNCH = False
+GLOBAL_STREAM = _cfg.global_stream   # the global PointNet on a stream of its own beside the index chain and the first set-abstraction kernels
 TAIL_BESIDE = True     # the last head layer's 64-channel remainder on the early solve's stream / compute units (ops.conv1x1_gn_early)
 
 
@@ -71,10 +75,10 @@ class TPointNet2(nn.Module):
         self._cache = WeightCache()
         self.record = None  # set to a list to capture FPS / ball-query indices (parity tests)
 
-    def _side_stream(self, device):
+    def _side_stream(self, device, which=0):
         # (a CU-masked side stream -- hipExtStreamCreateWithCUMask leaving one unit in eight to the latent team -- was tried in
         # round 3: the mask had no measurable effect on where kernels ran, and the step got 3 ms slower with the external stream)
-        key = (device.type, device.index)
+        key = (device.type, device.index, which)
         if not hasattr(self, "_streams"):
             self._streams = {}
         if key not in self._streams:
@@ -165,9 +169,19 @@ class TPointNet2(nn.Module):
             idx = self.local_extract.indices(xyz, events=True)
         if C == 0:
             feat = None
-        # global spatio-temporal feature (tpointnet2.py:75-76)
-        with ops.timed("enc_global_pointnet"):
-            pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
+        # global spatio-temporal feature (tpointnet2.py:75-76).  GLOBAL_STREAM: on a stream of its own, joined in front of the head -- the
+        # set abstraction then starts when the first level's indices are ready (0.9 ms with the LDS ball query) instead of behind these
+        # convs (1.2 ms), which run beside its latency-bound first kernels
+        gstream = None
+        if GLOBAL_STREAM and self.record is None and not torch.cuda.is_current_stream_capturing():
+            gstream = self._side_stream(x.device, 1)
+            gstream.wait_stream(main)
+        with (torch.cuda.stream(gstream) if gstream is not None else contextlib.nullcontext()):
+            with ops.timed("enc_global_pointnet"):
+                pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
+        if gstream is not None:
+            X1.record_stream(gstream)
+            x.record_stream(gstream)
         # no join here: local_extract.run waits for each level's indices where it uses them
         for t_ in _tensors(idx):
             t_.record_stream(main)
@@ -179,6 +193,11 @@ class TPointNet2(nn.Module):
             fold = self.record is None
             loc = self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record, idx=idx, feat_kind=kind,
                                          stop_before_last=fold)
+        if gstream is not None:
+            main.wait_stream(gstream)
+            for t_ in (pf.scale, pf.shift, gmax):
+                if t_ is not None:
+                    t_.record_stream(main)
         t_head = ops.timed("enc_head")
         t_head.__enter__()
 
