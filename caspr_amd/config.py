@@ -21,7 +21,7 @@ class KernelConfig:
     early_latent_team: bool = True      # ... on the team kernel with 32 reserved compute units (False: single workgroup, one unit)
     sa_lo_parts: bool = True            # the first set-abstraction level hands hi + lo to the second (models/pointnet2.py)
     sa_scale_streams: bool = True       # the two scales of a set-abstraction level on two streams
-    global_stream: bool = False         # the global PointNet on a stream of its own (models/tpointnet2.py); A/B pending
+    global_stream: bool = True          # the global PointNet on a stream of its own (models/tpointnet2.py): -0.05 .. -0.17 ms, bit-identical
     sa_pre_aggregate: bool = True       # set abstraction, wide levels: the first layer's feature part once per source point, not per (centre, sample)
     fp_commute: bool = True             # feature propagation's first conv on the coarse level (finest level: interpolation and conv commute)
     sa_f64_streams: bool = False        # the f64 re-evaluation of a scale's small balls beside its MFMA kernel, on a stream of its own (measured: + 0.4 ms, off)
