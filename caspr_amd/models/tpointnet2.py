@@ -26,6 +26,7 @@ from .pointnet2 import PointNet2feat as PointNet2
 # first workgroup) -- but queued late it runs entirely in front of the flow: 69.64 -> 69.97 ms.  Early it is.
 LATE_TNOCS_LAUNCH = False
 GLOBAL_STREAM = _cfg.global_stream   # the global PointNet on a stream of its own beside the index chain and the first set-abstraction kernels
+HEAD1_TAIL_BESIDE = True   # the head's first layer: its 64-channel remainder beside the main tiles too (no reserved units: it shares them)
 TAIL_BESIDE = True     # the last head layer's 64-channel remainder on the early solve's stream / compute units (ops.conv1x1_gn_early)
 
 
@@ -212,8 +213,10 @@ class TPointNet2(nn.Module):
             in_scale = torch.cat([s_f, rep(pf.scale)], dim=1).contiguous()
             in_shift = torch.cat([t_f, rep(pf.shift)], dim=1).contiguous()
             bb = rep(bbias.view(B, -1)[:, :self.conv1.out_channels] + b_fold).contiguous()
-            y1, s1, t1 = ops.conv1x1_gn(w_fold, None, X1.view(B * T, N, L + S), self.bn1.weight, self.bn1.bias, bbias=bb, in_scale=in_scale,
-                                        in_shift=in_shift, in_relu=True, in_relu_from=0, pool=T)
+            # (its 64-channel remainder beside the main tiles, as the next layer's: ops.conv1x1_gn_tail_beside)
+            y1, s1, t1 = ops.conv1x1_gn_tail_beside(w_fold, None, X1.view(B * T, N, L + S), self.bn1.weight, self.bn1.bias,
+                                                    self._side_stream(x.device, 2) if HEAD1_TAIL_BESIDE else None, bbias=bb, in_scale=in_scale,
+                                                    in_shift=in_shift, in_relu=True, in_relu_from=0, pool=T)
             y1 = y1.view(B, P, y1.shape[2])
         else:
             ones = torch.ones(B, L, device=x.device, dtype=torch.float32)

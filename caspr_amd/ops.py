@@ -557,6 +557,54 @@ def conv1x1_gn_early(pw, bias, x, gamma, beta, on_early, groups=16, eps=1e-5, in
     return y, scale, shift, pmax
 
 
+def conv1x1_gn_tail_beside(pw, bias, x, gamma, beta, tail_stream, groups=16, eps=1e-5, bbias=None, in_scale=None, in_shift=None, in_relu=False,
+                           in_relu_from=0, pool=1):
+    """conv1x1_gn(...) of a layer that runs on the persistent 512-channel kernel with a < 512-channel remainder (1600 = 3 x 512 + 64), the
+    remainder's pass -- bound by reading the input once -- queued on `tail_stream` BESIDE the main tiles instead of behind them (its
+    workgroups need 4 KB of LDS and 116 registers: they share the compute units with the persistent kernel's one wave per SIMD).  Same
+    pieces (caspr_conv1x1_x6w_part_f32 / caspr_conv_gn_finalize_f32), same bits as conv1x1_gn; falls back to it when the layer does not
+    take that kernel.  -> (y, scale, shift)."""
+    B, P, _ = x.shape
+    C = pw.cout
+    ok = (tail_stream is not None and CONV_BF16X6 and CONV_X6W and pw.x6w_ok and pw.x6_gn_ok and P % 128 == 0 and C % groups == 0 and in_relu_from % 8 == 0
+          and C % 512 != 0 and C > 512 and B % pool == 0 and _x6w_fills(pw, B, P) and not torch.cuda.is_current_stream_capturing())
+    if not ok:
+        return conv1x1_gn(pw, bias, x, gamma, beta, groups, eps, bbias=bbias, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu,
+                          in_relu_from=in_relu_from, pool=pool)
+    _chk_f32(bias, bbias, in_scale, in_shift, gamma, beta)
+    ldx = _chk_rows(x)
+    dev = x.device
+    y = torch.empty(B, P, (C + 3) // 4 * 4, device=dev, dtype=torch.float32)
+    ldy = _chk_rows(y)
+    Bs = B // pool
+    scale = torch.empty(Bs, C, device=dev, dtype=torch.float32)
+    shift = torch.empty(Bs, C, device=dev, dtype=torch.float32)
+    L = _lib.load()
+    ws = _workspace(L.caspr_conv_gn_ws_bytes(B, P, C), dev)
+    main, tail = pw.xw()
+    mt_all = C // 512
+
+    def part(mt0, mt1, with_tail):
+        _lib.check(L.caspr_conv1x1_x6w_part_f32(_p(main), _p(tail), _p(bias), _p(bbias), _p(x), ldx, _p(in_scale), _p(in_shift), int(in_relu), int(in_relu_from),
+                                                _p(y), ldy, B, P, pw.cin, C, mt0, mt1, int(with_tail), 0, _p(ws), ws.numel(), _stream()),
+                   "caspr_conv1x1_x6w_part_f32")
+    with timed("k:conv1x1_bf16x6:%d:%d:%d" % (pw.cin, C, B * P), 2):
+        main_stream = torch.cuda.current_stream()
+        tail_stream.wait_stream(main_stream)
+        with torch.cuda.stream(tail_stream):
+            part(mt_all, mt_all, True)               # the remainder only: its own columns of y and of the partials
+            tail_done = torch.cuda.Event()
+            tail_done.record(tail_stream)
+        part(0, mt_all, False)
+        main_stream.wait_event(tail_done)
+        for t_ in (x, y, ws, in_scale, in_shift, bbias, bias):
+            if t_ is not None:
+                t_.record_stream(tail_stream)
+        _lib.check(L.caspr_conv_gn_finalize_f32(_p(ws), ws.numel(), B, P, C, groups, 0, groups, int(pool), _p(gamma), _p(beta), float(eps), _p(scale), _p(shift),
+                                                None, None, None, _stream()), "caspr_conv_gn_finalize_f32")
+    return y, scale, shift
+
+
 FEAT_QUAD, FEAT_PAIRS, FEAT_LO_IN, FEAT_LO_OUT = 1, 2, 4, 8     # include/caspr_hip.h
 SA_ONLY_MFMA, SA_ONLY_F64 = 16, 32                              # the call in two halves (two streams): the MFMA kernel / the f64 re-evaluation
 
