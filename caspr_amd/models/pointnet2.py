@@ -214,6 +214,7 @@ class PointNet2SetAbstraction(nn.Module):
         if events:
             d["scale_ready"] = ready
             d["last_scale"] = order[-1]
+            d["first_scale"] = order[0]
         return d
 
     @staticmethod
@@ -512,6 +513,11 @@ class PointNet2feat(nn.Module):
         lo_from = [l + 1 < len(sas) and sas[l].narrow() and sas[l + 1].narrow() and LO_PARTS and l == 0 for l in range(len(sas))]
         for l, sa in enumerate(sas):                                                            # pointnet2.py:232
             lo_in = l > 0 and lo_from[l - 1]
+            if "scale_ready" in idx["sa"][l]:
+                # (the stage clock below starts when the level's FIRST index rows exist -- what the level's first kernel waits for anyway --
+                # not when the host reaches this line: with the global PointNet on its own stream the main stream arrives here a
+                # millisecond before the first level's ball query is done, and that wait belongs to the index chain)
+                sa._await(idx["sa"][l], idx["sa"][l].get("first_scale"))
             with ops.timed("enc_set_abstraction"):       # wall time of the level on the main stream (its scales overlap on two streams)
                 xyz, feat = sa.run(xyz, feat, C, record, idx["sa"][l], feat_kind=feat_kind if l == 0 else 0, lo_in=lo_in, lo_out=lo_from[l])
             C = sa.get_num_features_out()

@@ -26,7 +26,10 @@ from .pointnet2 import PointNet2feat as PointNet2
 # first workgroup) -- but queued late it runs entirely in front of the flow: 69.64 -> 69.97 ms.  Early it is.
 LATE_TNOCS_LAUNCH = False
 GLOBAL_STREAM = _cfg.global_stream   # the global PointNet on a stream of its own beside the index chain and the first set-abstraction kernels
-HEAD1_TAIL_BESIDE = True   # the head's first layer: its 64-channel remainder beside the main tiles too (no reserved units: it shares them)
+# the head's FIRST layer (576 -> 1600) with its 64-channel remainder beside the main tiles too (ops.conv1x1_gn_tail_beside; no reserved units here:
+# the remainder shares them with the persistent kernel).  Measured and NOT adopted (tools/head1_tail_ab.py, outputs identical): 67.30 / 66.82 / 66.41 ms
+# with it against 66.71 / 66.60 / 66.39 without -- the remainder's 755 MB of reads slow the tiles down by what it saves behind them.
+HEAD1_TAIL_BESIDE = False
 TAIL_BESIDE = True     # the last head layer's 64-channel remainder on the early solve's stream / compute units (ops.conv1x1_gn_early)
 
 
