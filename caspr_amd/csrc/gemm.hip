@@ -719,7 +719,13 @@ extern "C" int caspr_conv1x1_f32(const float *wp, const float *bias, const float
     }
     if (force == 7 || (force == 0 && P >= 128 && Cin >= 32 * ST_DB && !(act & CASPR_CONV_ROW_INVARIANT))) {
         dim3 grid(ceil_div(Cout, GEMM_MT), ceil_div(P, 128), B);
-#define ST_LAUNCH(F, N) conv1x1_stream_kernel<F, N><<<grid, dim3(256), 0, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, \
+        // The narrow variant (<= 16 outputs: the T-NOCS regression, a pure stream over 2.1 GB) is launched POLITE: 16 KB of unused dynamic LDS on
+        // top of its 16 KB, so that at most five of its workgroups share a compute unit (it needs ~8 MB in flight to saturate HBM and has
+        // 37 MB with three) instead of ten that fill every wave slot -- the small kernels of another stream (the flow's context cat and
+        // hyper-network conv, which the flow waits for) then find slots at once instead of queueing behind 2,560 workgroups -- and exactly one
+        // still fits beside a workgroup of the flow (127 KB).
+        const size_t st_pad = Cout <= 16 ? 16 * 1024 : 0;
+#define ST_LAUNCH(F, N) conv1x1_stream_kernel<F, N><<<grid, dim3(256), st_pad, (hipStream_t)stream>>>(wp, bias, bbias, X, ldx, in_scale, in_shift, in_relu, \
                                                                                     in_relu_from, Y, ldy, P, Cin, Cout, act)
         if (Cout <= 16) {
             if (in_scale) ST_LAUNCH(true, 1);
