@@ -157,7 +157,10 @@ def test_fps_tie_order_tree_reduction(ops, dev, golden):
 
 
 @pytest.mark.parametrize("n,M,r,ns", [(2048, 1024, 0.02, 16), (2048, 1024, 0.05, 32), (1024, 512, 0.1, 32), (256, 64, 0.4, 32),
-                                     (64, 16, 0.8, 32), (64, 16, 0.4, 16), (300, 50, 0.2, 16)])
+                                     (64, 16, 0.8, 32), (64, 16, 0.4, 16), (300, 50, 0.2, 16),
+                                     # the LDS kernel's edges (csrc/point_ops.hip: ball_query_lds_kernel): a ragged last workgroup / wave, a
+                                     # cloud above 64 KB (LDS opt-in), the largest cloud it takes, and the first one it leaves to the plain kernel
+                                     (2048, 100, 0.05, 32), (8192, 1024, 0.03, 32), (12288, 128, 0.02, 16), (12289, 128, 0.02, 16)])
 def test_ball_query_bit_exact(ops, dev, n, M, r, ns):
     c = clouds(2, n, seed=n, dup=(n == 300))
     ctr = torch.gather(c, 1, P.furthest_point_sampling(c, M).long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
