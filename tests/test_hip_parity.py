@@ -883,6 +883,37 @@ def test_encode_parity_cars(dev, seeded_sd, sd64, model):
     record_f64("enc_z0", gz0, z0, z64, 1e-5)    # FLAT since the f64 reference column (round 4): 4.1e-6 (round 3: 2.1e-5; f32 oracle 5.9e-4): the max over 20,480 pre-ReLU values
 
 
+@pytest.mark.parametrize("B,m,n,C,C2", [(3, 128, 1000, 512, 6), (2, 64, 256, 128, 0), (1, 256, 512, 64, 8)])
+def test_three_interp_add_gn_op(ops, dev, B, m, n, C, C2):
+    """caspr_three_interp_add_gn_f32 alone: the three-neighbour combination of u + skip part + bias against f64 torch, and the GroupNorm
+    scale / shift it returns against the statistics of its own output in f64 (ragged row blocks, no skip, the maximal skip width)."""
+    u = rnd(1, B, m, C)
+    unk, known = clouds(B, n, seed=5), clouds(B, m, seed=6)
+    _, idx, w = ops.three_nn(unk.to(dev), known.to(dev), with_weights=True)
+    skip = rnd(2, B, n, 8) if C2 else None
+    wsk = rnd(3, C, C2, scale=0.3) if C2 else None
+    bias, gamma, beta = rnd(4, C, scale=0.2), rnd(5, C, scale=0.5) + 1.0, rnd(6, C, scale=0.1)
+    y, s, t_ = ops.three_interp_add_gn(u.to(dev), idx, w, None if skip is None else skip.to(dev), C2, None if wsk is None else wsk.to(dev), bias.to(dev),
+                                       gamma.to(dev), beta.to(dev))
+    i64, w64 = idx.cpu().long(), w.cpu().double()
+    ref = torch.zeros(B, n, C, dtype=torch.float64)
+    for k in range(3):
+        ref += w64[:, :, k:k + 1] * torch.gather(u.double(), 1, i64[:, :, k:k + 1].expand(-1, -1, C))
+    if C2:
+        ref += skip[:, :, :C2].double() @ wsk.double().t()
+    ref += bias.double()
+    record("three_interp_add_gn_y_%d_%d" % (n, C), y, ref, 2e-6 * float(ref.abs().max()))
+    G = 16
+    yg = y.cpu().double().view(B, n, G, C // G)
+    mean = yg.mean(dim=(1, 3), keepdim=True)
+    var = ((yg - mean) ** 2).mean(dim=(1, 3), keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    sc = (gamma.double().view(1, 1, G, C // G) * rstd).reshape(B, C)
+    sh = (beta.double().view(1, 1, G, C // G) - mean * gamma.double().view(1, 1, G, C // G) * rstd).reshape(B, C)
+    record("three_interp_add_gn_scale_%d_%d" % (n, C), s, sc, 1e-5 * float(sc.abs().max()))
+    record("three_interp_add_gn_shift_%d_%d" % (n, C), t_, sh, 1e-5 * max(1.0, float(sh.abs().max())))
+
+
 def test_feature_propagation_conv_on_the_coarse_level(dev, seeded_sd, sd64, model):
     """The finest feature-propagation level's first conv runs over the COARSE rows (interpolation and a pointwise conv commute:
     models/pointnet2.py FP_COMMUTE, csrc/gemm.hip three_interp_add_gn_kernel) when the fine level has twice the points (N = 2048).
