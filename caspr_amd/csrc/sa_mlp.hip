@@ -423,6 +423,16 @@ __device__ __forceinline__ void sa_window_sync()
 }
 
 // mcen[cen]: the neighbourhood (centre index) of this wave's centre slot cen, -1 for an empty slot (wave-uniform): see sa_small_entry
+// SA_F32REF = 1 (round 5, second part): the reference column mu = W a_0 is read from the MFMA's own column 0 (f32, row_newbcast:0) again, and
+// the f64 side computation described above (per-lane f64 products between the MFMAs, permlane row sums, the wave's LDS window, a_0 handed on in
+// f64) is compiled out.  It was introduced in round 4 for neighbourhoods that are all copies of one point or nearly so -- since round 5 exactly
+// those (1 .. 8 / 1 .. 4 distinct samples) are re-evaluated entirely in f64 by sa_repair_f64_kernel, and with the per-cloud list this kernel does
+// not even compute them.  On the balls it still computes the two forms agree to the last digits of every check (tests/test_hip_parity.py, all flat
+// at 1e-5: isolated scales 1.6e-6 / 2.8e-6 / 4.4e-6 either way, z0 on sparse cars 4.5e-6 vs 4.4e-6, cfg-5 T-NOCS 7.6e-7 vs 6.4e-7), the kernels
+// need 117-143 registers instead of 134-220 and no LDS: first level's 32-sample scale 1.11 -> 0.97 ms.  SA_F32REF = 0 restores the f64 column.
+#ifndef SA_F32REF
+#define SA_F32REF 1
+#endif
 template <int NS, int C1, int C2, int C3>
 __device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)[64 / NS])
 {
@@ -548,19 +558,23 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)
         // the reference quads of this lane's k (exact f32 inputs) ride in column 0 of each neighbourhood's first tile: row broadcast; the
         // f64 products sit BETWEEN the MFMAs of the chunk (behind them, fenced, the widest variant lost a quarter: 0.44 -> 0.55 ms)
         double rq[NCEN][4];
+        if (!SA_F32REF) {
 #pragma unroll
-        for (int cen = 0; cen < NCEN; ++cen)
+            for (int cen = 0; cen < NCEN; ++cen)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rq[cen][q] = (double)dpp_mov<0x150>(bf[cen * TPC][q]);      // row_newbcast:0
+                for (int q = 0; q < 4; ++q) rq[cen][q] = (double)dpp_mov<0x150>(bf[cen * TPC][q]);      // row_newbcast:0
+        }
 #pragma unroll
         for (int rt = 0; rt < C1 / 16; ++rt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) h1[rt][ct] = mfma16(af[rt][q], bf[ct][q], h1[rt][ct]);
-                const double wq = (double)af[rt][q];
+                if (!SA_F32REF) {
+                    const double wq = (double)af[rt][q];
 #pragma unroll
-                for (int cen = 0; cen < NCEN; ++cen) P1[rt][cen] = __builtin_fma(wq, rq[cen][q], P1[rt][cen]);
+                    for (int cen = 0; cen < NCEN; ++cen) P1[rt][cen] = __builtin_fma(wq, rq[cen][q], P1[rt][cen]);
+                }
             }
     };
     auto load_a1 = [&](f32x4(&af)[C1 / 16], int kc) {
@@ -601,8 +615,10 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)
 #pragma unroll
             for (int cen = 0; cen < NCEN; ++cen) mus[rt][cen][ar] = sa_rows_allreduce(P[rt][cen]);
     };
-    publish_mu(P1, std::integral_constant<int, C1 / 16>{});
-    sa_window_sync();
+    if (!SA_F32REF) {
+        publish_mu(P1, std::integral_constant<int, C1 / 16>{});
+        sa_window_sync();
+    }
 
     // bias + GroupNorm(16) per neighbourhood on a register-resident layer output in the centred form: on entry column 0 of the
     // neighbourhood's first tile holds W a_0 (lane j = 0), every other column W d_s.  FINAL = false: ReLU, and the output is written back
@@ -624,7 +640,8 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)
                 double mu[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    mu[e] = mus[rt][cen][4 * g + e] + (double)bias4[e];
+                    if (SA_F32REF) mu[e] = (double)dpp_mov<0x150>(h[rt][cen * TPC][e]) + (double)bias4[e];      // column 0 of the MFMA: W a_0 in f32
+                    else mu[e] = mus[rt][cen][4 * g + e] + (double)bias4[e];
                     if (refl) h[rt][cen * TPC][e] = 0.f;
                 }
                 f32x4 mx = (f32x4){0.f, 0.f, 0.f, 0.f}, mlo = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -668,7 +685,7 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)
                         } else {
                             const double a64 = n64 > 0.0 ? n64 : 0.0;
                             const float a0 = (float)a64;
-                            a0s[cen][16 * rt + 4 * g + e] = a64;          // the next layer's reference input, in f64 (every lane of the row
+                            if (!SA_F32REF) a0s[cen][16 * rt + 4 * g + e] = a64;          // the next layer's reference input, in f64 (every lane of the row
                                                                           // writes the same value: no branch for hipcc to sink 32 doubles into)
 #pragma unroll
                             for (int t = 0; t < TPC; ++t) {
@@ -710,6 +727,7 @@ __device__ __forceinline__ void sa_small_body(const SaArgs &a, const int (&mcen)
         }
         // mu = W a_0 of the reference column in f64: this lane's weight row ar against the a_0 of its k quads (the window), the four
         // k-rows summed, row ar published for norm()
+        if (SA_F32REF) return;
 #pragma unroll
         for (int cen = 0; cen < NCEN; ++cen) {          // one centre at a time: RO doubles live, not RO x NCEN
             double P[RO];
