@@ -30,7 +30,8 @@ GLOBAL_STREAM = _cfg.global_stream   # the global PointNet on a stream of its ow
 # the remainder shares them with the persistent kernel).  Measured and NOT adopted (tools/head1_tail_ab.py, outputs identical): 67.30 / 66.82 / 66.41 ms
 # with it against 66.71 / 66.60 / 66.39 without -- the remainder's 755 MB of reads slow the tiles down by what it saves behind them.
 HEAD1_TAIL_BESIDE = False
-TAIL_OWN_STREAM = False  # experiment: that remainder on a stream of its own from the start of the main tiles (not behind the latent solve)
+# (that remainder on a stream of its OWN from the start of the main tiles, instead of behind the latent solve, was measured too: 71.34 / 71.46 / 71.37 ms
+# against 71.51 / 71.44 / 71.52 -- within the noise; not kept)
 TAIL_BESIDE = True     # the last head layer's 64-channel remainder on the early solve's stream / compute units (ops.conv1x1_gn_early)
 
 
@@ -231,7 +232,7 @@ class TPointNet2(nn.Module):
         if early is not None and self.record is None and ops.conv1x1_gn_early_ok(p2, B, P, 16, early.channels):
             y2, s2, t2, z0 = ops.conv1x1_gn_early(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, early, in_scale=s1, in_shift=t1,
                                                   in_relu=True, reserve_cus=early.reserve_cus(B),
-                                                  tail_stream=(self._side_stream(x.device, 3) if TAIL_OWN_STREAM else early.stream) if TAIL_BESIDE else None)   # :99-100, 111
+                                                  tail_stream=early.stream if TAIL_BESIDE else None)   # :99-100, 111
         else:
             y2, s2, t2, z0 = ops.conv1x1_gn(p2, self.conv2.bias, y1, self.bn2.weight, self.bn2.bias, want_max=True,
                                             in_scale=s1, in_shift=t1, in_relu=True)               # :99-100, 111
