@@ -22,11 +22,19 @@ for lvl in range(5):
         for sc in range(2):
             out = torch.empty(cur_xyz.shape[0], sa[lvl].num_points_out, sa[lvl].get_num_features_out(), device=dev)
             buf = torch.zeros(16, dtype=torch.int64, device=dev)
-            layers = sa[lvl].pointnet_modules[sc].kernel_layers()
-            ops.sa_mlp_max(cur_xyz, idx["new_xyz"], cur_feat, idx["ball_idx"][sc], C, layers, out, 0); torch.cuda.synchronize()
+            pn = sa[lvl].pointnet_modules[sc]
+            layers = pn.kernel_layers()
+            pre_mode = "--pre" in sys.argv and lvl < 4        # the production path of levels 3-4: first layer pre-aggregated (stamps 1-2: the gather fills layer 1's tile)
+            if pre_mode:
+                pw_f, wx = pn.pre_layers()
+                pre = ops.conv1x1(pw_f, None, cur_feat)
+                call = lambda: ops.sa_mlp_max_pre(cur_xyz, idx["new_xyz"], pre, idx["ball_idx"][sc], wx, layers, out, 0)
+            else:
+                call = lambda: ops.sa_mlp_max(cur_xyz, idx["new_xyz"], cur_feat, idx["ball_idx"][sc], C, layers, out, 0)
+            call(); torch.cuda.synchronize()
             so.caspr_debug_set_sa_trace(ctypes.c_void_p(buf.data_ptr()))
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t0.record()
-            ops.sa_mlp_max(cur_xyz, idx["new_xyz"], cur_feat, idx["ball_idx"][sc], C, layers, out, 0)
+            call()
             t1.record(); torch.cuda.synchronize()
             so.caspr_debug_set_sa_trace(ctypes.c_void_p(0))
             t = buf.cpu()
