@@ -60,8 +60,10 @@ def measure(args, dev, rank=0, world=1):
     losses = []
     for _ in range(args.warmup):
         train_step(model, opt, x, sp, bucket=bucket, e=e)
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+        bucket.timers = []             # the duration of every step's ONE collective (HIP events on the launch stream under RCCL)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -69,7 +71,17 @@ def measure(args, dev, rank=0, world=1):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    torch.cuda.synchronize()
     el_local = time.perf_counter() - t0
+    allreduce_ms, bucket_bytes = None, None
+    if world > 1:
+        from caspr_amd.train.loop import collective_ms
+        ms_ = collective_ms(bucket.timers)
+        bucket.timers = None
+        # per rank: the mean over the steps (a rank that arrives early waits inside the collective for the slowest one: its figure holds
+        # that wait; the MINIMUM over ranks is the closest to the transport's own time)
+        allreduce_ms = [round(v, 3) for v in per_rank_values(sum(ms_) / max(len(ms_), 1), dev)]
+        bucket_bytes = int(bucket.flat.numel() * 4)
     per_rank_ms = [round(1e3 * v / args.steps, 3) for v in per_rank_values(el_local, dev)]
     elapsed = max_over_ranks(el_local, dev)
     # ---- detail pass (not part of the timing above): one HIP-event pair per launch of every matrix kernel, by pipe
@@ -90,7 +102,7 @@ def measure(args, dev, rank=0, world=1):
         acc = pipes["bf16x6" if p[1].endswith("bf16x6") else "f32_mfma"]
         acc[0] += fl; acc[1] += ms_k; acc[2] += len(ev)
 
-    return {"elapsed": elapsed, "per_rank_ms": per_rank_ms, "losses": losses, "pipes": pipes, "sd": sd, "x_all": x_all, "sp_all": sp_all, "e": e,
+    return {"elapsed": elapsed, "per_rank_ms": per_rank_ms, "losses": losses, "pipes": pipes, "allreduce_ms": allreduce_ms, "bucket_bytes": bucket_bytes, "sd": sd, "x_all": x_all, "sp_all": sp_all, "e": e,
             "full": full, "collective_library": collective_library() if world > 1 else None}
 
 
@@ -199,6 +211,7 @@ def main():
                        "global_batch": world * B, "seq_len": T, "num_pts": N, "cnf_rk4_steps": args.cnf_steps,
                        "latent_rk4_steps": args.latent_steps, "parallelism": "seq-shard x%d + 1 gradient all-reduce" % world,
                        "ranks": {"ms_per_step": per_rank_ms, "collectives": "1 all-reduce of the flat gradient bucket per step (in place: .grad tensors are views of it)",
+                                 "allreduce_ms": m["allreduce_ms"], "bucket_bytes": m["bucket_bytes"],
                                  "library": collective_library() if world > 1 else None}},
             "roofline": roofline, "cpu_baseline": cpu, "loss_first": losses[0], "loss_last": losses[-1],
             "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),

@@ -86,20 +86,62 @@ def _guard_stream(device):
 
 def _other_steps(S):
     """The step count a guarded solve is compared with, and the factor that turns max |x_S - x_other| into the error estimate of the
-    S-step result (RK4, global error ~ C h^4): half the steps when S is even -- x_S/2 - x_S = 15 e_S, estimate = diff / 15 -- else
-    twice -- x_S - x_2S = (15 / 16) e_S, estimate = diff * 16 / 15."""
-    return (S // 2, 1.0 / 15.0) if (S % 2 == 0 and S >= 2) else (2 * S, 16.0 / 15.0)
+    S-step result (RK4, global error ~ C h^4): S' = S // 2 steps when S >= 2 -- x_S' - x_S = ((S / S')^4 - 1) e_S, so estimate =
+    diff / ((S / S')^4 - 1): 1 / 15 for an even S, and the same cheap half-cost check for an odd one (S = 11 -> S' = 5, 1 / 22.4) --
+    else twice the steps: x_1 - x_2 = (15 / 16) e_1, estimate = diff * 16 / 15."""
+    if S >= 2:
+        S2 = S // 2
+        return S2, 1.0 / ((float(S) / S2) ** 4 - 1.0)
+    return 2 * S, 16.0 / 15.0
+
+
+def _first_passing(diff_of, candidates, tol, refine=True, max_tries=3):
+    """Step-count search of calibrate_rk4_steps.  diff_of(S) = max |x_S - x_2S| (15/16 of the S-step error of a 4th-order method).
+    Walk `candidates` in ascending order to the first count that passes (diff <= tol); then, with `refine`, look BETWEEN the last
+    failing candidate and it: predict the smallest passing count from the two measured differences (observed order p = log2 of their
+    ratio per doubling, clipped to [2, 4]; diff(S) ~ diff(fail) (fail / S)^p), and VERIFY the prediction by an actual S-vs-2S solve,
+    moving up one count at a time (at most `max_tries` solves) -- a trained flow that fails at 8 and passes at 16 usually passes at
+    11 or 12, which is a quarter fewer function evaluations than 16.  -> (chosen, {S: diff} of every count tried)."""
+    import math
+    diffs, chosen, fail = {}, None, None
+    for S in sorted(candidates):
+        diffs[S] = diff_of(S)
+        if diffs[S] <= tol:
+            chosen = S
+            break
+        fail = S
+    if chosen is None:
+        return max(candidates), diffs
+    if refine and fail is not None and chosen - fail > 1:
+        d_fail, d_pass = diffs[fail], diffs[chosen]
+        order = 4.0
+        if math.isfinite(d_fail) and d_pass > 0 and d_fail > d_pass:
+            order = min(4.0, max(2.0, math.log(d_fail / d_pass) / math.log(float(chosen) / fail)))
+        guess = chosen
+        if math.isfinite(d_fail) and d_fail > 0:
+            guess = max(fail + 1, int(math.ceil(fail * (d_fail / tol) ** (1.0 / order) - 1e-9)))
+        S, tries = guess, 0
+        while S < chosen and tries < max_tries:
+            diffs[S] = diff_of(S)
+            tries += 1
+            if diffs[S] <= tol:
+                chosen = S
+                break
+            S += 1
+    return chosen, diffs
 
 
 class CaSPR(nn.Module):
     def __init__(self, radii_list=[0.02, 0.05, 0.1, 0.2, 0.4, 0.8], local_feat_size=512, latent_feat_size=1600,
                  ode_hidden_size=512, motion_feat_size=64, pretrain_tnocs=False, augment_quad=True, augment_pairs=True,
-                 cnf_blocks=1, regress_tnocs=True, *, cnf_rk4_steps=8, latent_rk4_steps=2, check_tol=None, latent_check_tol=None,
-                 check_action="raise", check_points=64):
+                 cnf_blocks=1, regress_tnocs=True, *, cnf_rk4_steps=8, latent_rk4_steps=2, check_tol=1e-5, latent_check_tol=None,
+                 check_action="warn", check_points=64):
         super(CaSPR, self).__init__()
-        # Run-time accuracy guard of the fixed-step integrators (off by default).  The reference's dopri5 controls its error at every
-        # call (CNF atol = rtol = 1e-5, flow.py:96-99; latent ODE 1e-3, latent_ode_model.py:38,83); a fixed step count does not.  With
-        # check_tol set, every inference solve (reconstruct / decode / forward / aggregate_and_solve_latent under no_grad) is repeated at half
+        # Run-time accuracy guard of the fixed-step integrators: ON by default at the reference's own tolerances, reporting as a
+        # RuntimeWarning (check_action="raise": CasprAccuracyError; check_tol=None: off).  The reference's dopri5 controls its error at every
+        # call (CNF atol = rtol = 1e-5, flow.py:96-99; latent ODE 1e-3, latent_ode_model.py:38,83); a fixed step count does not -- a trained
+        # checkpoint loaded at the default 8 / 2 steps must not be silently under-resolved (calibrate_rk4_steps installs counts that pass).
+        # With check_tol set, every inference solve (reconstruct / decode / forward / aggregate_and_solve_latent under no_grad) is repeated at half
         # the step count on `check_points` samples per frame (the latent solve: all of it, on one compute unit) on a side stream, the
         # results are compared on the device, and the Richardson estimate of the delivered solution's error is examined through
         # ops.check_deferred_errors() / at the next guarded call: CasprAccuracyError (check_action "raise") or a RuntimeWarning
@@ -250,7 +292,9 @@ class CaSPR(nn.Module):
             diff = (sample_feats - zc).abs().amax()
             ops.guard_track(diff, sample_feats.abs().amax(), {"name": "latent", "tol": float(tol), "factor": factor, "steps": L, "other_steps": L2, "action": self.check_action,
                                    "what": "latent ODE (latent_ode_model.py:45-70; reference: dopri5 at rtol = atol = 1e-3)"})
-        for t_ in (z_init, sample_feats, time_tensor):
+        # everything the guard stream reads was allocated on another stream (the plan: on the plan / copy stream): keep it alive until
+        # the check has run, also when reconstruct() drops the plan right after this call
+        for t_ in (z_init, sample_feats, time_tensor) + tuple(v for v in plan.values() if torch.is_tensor(v)):
             t_.record_stream(gs)
 
     def _guard_cnf_begin(self, y, z, logpx=None, e=None):
@@ -451,19 +495,23 @@ class CaSPR(nn.Module):
                     y, logp_y, x = self.decode(z, num_points, constant_in_time, truncate_std, sample_contours, y=y, _early=early)
             finally:
                 ops.BEFORE_CNF_LAUNCH = None
-            if defer and JOIN_TNOCS_LATE:
-                # the T-NOCS regression (a 0.5 ms HBM-bound conv on the side stream) is joined BEHIND the flow's launch, not in front of
-                # it: nothing of the flow reads it, and its workgroups drain while the flow's first ones start
-                self.encoder.join()
+                if defer and JOIN_TNOCS_LATE:
+                    # the T-NOCS regression (a 0.5 ms HBM-bound conv on the side stream) is joined BEHIND the flow's launch, not in front of
+                    # it: nothing of the flow reads it, and its workgroups drain while the flow's first ones start.  In the `finally`: a
+                    # CasprAccuracyError of an EARLIER call surfacing inside decode() must not leave the side stream unjoined
+                    self.encoder.join()
             return y, logp_y, x, tnocs_pred
 
     def calibrate_rk4_steps(self, x, tol=1e-6, candidates=(1, 2, 4, 8, 16, 32, 64, 128), num_points=512, timestamps=None, max_timestamp=5.0,
-                            latent_tol=None, latent_candidates=(1, 2, 4, 8, 16, 32)):
+                            latent_tol=None, latent_candidates=(1, 2, 4, 8, 16, 32), refine=True, rtol=0.0):
         """Pick the CNF's fixed RK4 step count the way an adaptive solver picks its step: by an error estimate on the
         actual weights and input.  Decodes every sequence of `x` with S and 2S steps (same base samples) for each
-        candidate S in ascending order and keeps the first S whose step-doubling difference max|x_S - x_2S| (= 15/16 of the
-        S-step error for a 4th-order method) is <= tol.  Sets `rk4_steps` on every CNF block; returns (S, {S: difference}) with the
-        differences of the candidates that were tried.  With `latent_tol` the latent ODE's steps per interval are chosen FIRST, the
+        candidate S in ascending order and keeps the first S whose error estimate (16/15) max|x_S - x_2S| (Richardson: the
+        step-doubling difference is 15/16 of the S-step error of a 4th-order method) is <= tol; with `refine` (default) the counts BETWEEN the last failing candidate and
+        that one are then tried where the S^-4 law predicts they pass (_first_passing: prediction verified by an actual S-vs-2S
+        solve), so the result need not be a power of two.  Sets `rk4_steps` on every CNF block; returns (S, {S: difference}) with the
+        differences of the counts that were tried.  `rtol` > 0 relaxes the bound to tol + rtol max|x| (torchdiffeq's atol + rtol |x|,
+        the form the run-time guard uses with atol = rtol = check_tol); the default is the absolute bound.  With `latent_tol` the latent ODE's steps per interval are chosen FIRST, the
         same way (max|z_L - z_2L| <= latent_tol over the requested stamps), and installed on `latent_ode.rk4_steps`; the return
         value then is (S, diffs, L, latent_diffs).
         The reference's dopri5 runs at atol = rtol = 1e-5 (flow.py:96-99; 1e-3 for the latent ODE, latent_ode_model.py:38,83);
@@ -472,34 +520,30 @@ class CaSPR(nn.Module):
         blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
         guard, self.check_tol = self.check_tol, None          # the candidates below are MEANT to be under-resolved: no guard while choosing
         try:
-            return self._calibrate(blocks, x, tol, candidates, num_points, timestamps, max_timestamp, latent_tol, latent_candidates)
+            return self._calibrate(blocks, x, tol, candidates, num_points, timestamps, max_timestamp, latent_tol, latent_candidates, refine, rtol)
         finally:
             self.check_tol = guard
 
-    def _calibrate(self, blocks, x, tol, candidates, num_points, timestamps, max_timestamp, latent_tol, latent_candidates):
+    def _calibrate(self, blocks, x, tol, candidates, num_points, timestamps, max_timestamp, latent_tol, latent_candidates, refine=True, rtol=0.0):
         with torch.no_grad():
             xs = x                   # every sequence of x (round 4 looked at the first only: the worst one decides)
             z0, _ = self.encode(xs)
             times = xs[:, :, 0, 3] / max_timestamp if timestamps is None else timestamps.view(1, -1).repeat(xs.shape[0], 1).to(xs)
             lat = None
             if latent_tol is not None:
-                zs, ldiffs, lchosen = {}, {}, max(latent_candidates)
+                zs = {}
 
                 def zsol(L):
                     if L not in zs:
                         self.latent_ode.rk4_steps = L
                         zs[L] = self.aggregate_and_solve_latent(z0, times)
                     return zs[L]
-                for L in sorted(latent_candidates):
-                    ldiffs[L] = float((zsol(L) - zsol(2 * L)).abs().max())
-                    if ldiffs[L] <= latent_tol:
-                        lchosen = L
-                        break
+                lchosen, ldiffs = _first_passing(lambda L: float((zsol(L) - zsol(2 * L)).abs().max()), latent_candidates, latent_tol * 15.0 / 16.0, refine)
                 self.latent_ode.rk4_steps = lchosen
                 lat = (lchosen, ldiffs)
             z = self.aggregate_and_solve_latent(z0, times)
             y = torch.randn(z.shape[0], z.shape[1], num_points, self.cnf_args.input_dim, device=x.device)
-            sols, diffs, chosen = {}, {}, max(candidates)
+            sols = {}
 
             def sol(S):
                 if S not in sols:
@@ -507,11 +551,9 @@ class CaSPR(nn.Module):
                         b.rk4_steps = S
                     sols[S] = self.decode(z, num_points, y=y)[2]
                 return sols[S]
-            for S in sorted(candidates):
-                diffs[S] = float((sol(S) - sol(2 * S)).abs().max())
-                if diffs[S] <= tol:
-                    chosen = S
-                    break
+            bound = tol + rtol * float(sol(max(candidates)).abs().max()) if rtol > 0 else tol
+            bound *= 15.0 / 16.0       # the criterion is on the ERROR of the S-step solution, (16 / 15) max |x_S - x_2S|, not on the difference
+            chosen, diffs = _first_passing(lambda S: float((sol(S) - sol(2 * S)).abs().max()), candidates, bound, refine)
         for b in blocks:
             b.rk4_steps = chosen
         self.cnf_args.rk4_steps = chosen

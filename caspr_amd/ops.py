@@ -236,8 +236,8 @@ def three_interp_add_gn(u, idx, weight, skip, skip_channels, wskip, bias, gamma,
 #       per-instruction FLOP rate, i.e. a 2.67x higher ceiling (2500 / 6 = 416.7 f32-equivalent TFLOP/s vs 157.3);
 #   "f32": v_mfma_f32_16x16x4_f32 only (csrc/gemm.hip, csrc/ode.hip), bit-for-bit an ordered fmaf chain.
 # Shapes the bf16x6 kernels do not cover (Cin < 192 or not a multiple of 32, fewer than 128 rows per batch entry, the
-# set-abstraction MLPs, the latent ODE) run on the f32 MFMA kernels in either mode.  CASPR_MATMUL=f32 selects the f32
-# kernels at import; set_matmul_mode() switches at run time (bench.py times both in one process).
+# set-abstraction MLPs, the latent ODE) run on the f32 MFMA kernels in either mode.  config.matmul = "f32" (or, under
+# CASPR_DEBUG=1 only, CASPR_MATMUL=f32) selects the f32 kernels at import; set_matmul_mode() switches at run time (bench.py times both in one process).
 _mode = _cfg.matmul            # caspr_amd/config.py (the environment only under CASPR_DEBUG=1)
 CONV_BF16X6 = _mode == "bf16x6"      # pointwise convs (conv1x1) on the bf16x6 kernel where the shape allows
 CONV_X6W = _cfg.conv_x6w             # ... and the layers with >= 512 output channels on the 512-channel kernel

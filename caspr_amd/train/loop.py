@@ -62,6 +62,8 @@ class GradBucket:
         # the decision is collective by construction -- every rank enters the same ONE collective every step, whatever its local
         # marks are (a rank without data, a loss-weight schedule that switches a term on later, layers unfrozen mid-run) -- and it
         # is taken per step, like the reference's zero_grad(): a parameter touched once is NOT kept alive afterwards.
+        self.timers = None         # a list: all_reduce_mean appends the duration of its collective (HIP event pairs on the current stream under
+                                   # RCCL -- read with collective_ms(); seconds of wall clock under gloo, whose copy is on the host)
         self._touched = set()
         self._mask = None          # the reduced flags of the last all_reduce_mean (None: no collective ran -> the local marks decide)
         self._hooks = [p.register_post_accumulate_grad_hook(lambda t, i=i: self._touched.add(i)) for i, p in enumerate(self.params)]
@@ -134,9 +136,37 @@ class GradBucket:
                 flags[sorted(self._touched)] = 1.0
             flat[ng:ng + npar].copy_(flags, non_blocking=True)
             flat[-1] = float(weight)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if self.timers is None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        elif dist.get_backend() == "gloo":
+            import time
+            torch.cuda.synchronize(flat.device) if flat.is_cuda else None
+            t0 = time.perf_counter()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(flat.device) if flat.is_cuda else None
+            self.timers.append(time.perf_counter() - t0)
+        else:
+            # RCCL: the collective runs on the library's own stream, which waits for the current stream at entry and which the current stream
+            # waits for at exit (async_op=False) -- an event pair on the current stream brackets exactly the collective
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            b.record()
+            self.timers.append((a, b))
         flat[:ng].div_(flat[-1].clamp_min(1e-30))
         self._mask = (flat[ng:ng + npar] > 0).cpu().tolist()
+
+
+def collective_ms(timers):
+    """Milliseconds of each record of GradBucket.timers (synchronises: call after the timed region)."""
+    out = []
+    for t in timers or []:
+        if isinstance(t, tuple):
+            t[1].synchronize()
+            out.append(t[0].elapsed_time(t[1]))
+        else:
+            out.append(1e3 * t)
+    return out
 
 
 def broadcast_model(model, src=0):

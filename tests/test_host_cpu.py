@@ -658,3 +658,42 @@ def test_bench_box_calibration_is_optional_and_parses_the_micro_benchmark(tmp_pa
     assert box["bare_mfma_bf16_tflops"] == {"zeros": 2428.2, "random_sign_exponent_mantissa": 1772.4, "bf16x6_operand_planes": 1827.3}
     monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(OSError("no such binary")))
     assert bench.box_calibration() is None
+
+
+def test_step_count_search_refines_between_powers_of_two():
+    """CaSPR.calibrate_rk4_steps' search (models/caspr.py:_first_passing) on a synthetic 4th-order error law: the first passing power of
+    two is found, then the counts between the last failing one and it are tried where the law predicts they pass -- and every accepted
+    count was VERIFIED by an evaluation (nothing is accepted on the prediction alone)."""
+    from caspr_amd.models.caspr import _first_passing, _other_steps
+    calls = []
+
+    def law(C, p=4.0):
+        def diff_of(S):
+            calls.append(S)
+            return C / float(S) ** p
+        return diff_of
+    # the round-5 trained checkpoint: diff(8) = 3.17e-5, diff(16) = 1.79e-6 -> 11 (3.17e-5 (8/11)^4 = 8.9e-6)
+    S, diffs = _first_passing(law(3.17e-5 * 8 ** 4), (1, 2, 4, 8, 16, 32), 1e-5)
+    assert S == 11 and diffs[11] <= 1e-5 < diffs[8] and 16 in diffs and S in calls
+    # a flow that passes at the first candidate, or at adjacent candidates: nothing to refine
+    assert _first_passing(law(1e-9), (1, 2, 4), 1e-5)[0] == 1
+    assert _first_passing(law(1.5e-5), (1, 2, 4), 1e-5)[0] == 2
+    # none passes: the largest candidate, as before
+    assert _first_passing(law(1.0), (1, 2, 4), 1e-5)[0] == 4
+    # not yet in the asymptotic regime (observed order 2 between the bracketing candidates): the guess follows the OBSERVED order, and a
+    # failed guess moves up one count at a time, at most three solves, else the power of two stands
+    S2, d2 = _first_passing(law(1e-5 * 12 ** 2 * 0.999, p=2.0), (8, 16), 1e-5)
+    assert S2 == 12 and all(d2[k] > 1e-5 for k in d2 if k < 12)
+    stubborn = lambda S: 1e-4 if S < 16 else 1e-6          # a cliff: no count below 16 passes
+    S3, d3 = _first_passing(stubborn, (8, 16), 1e-5)
+    assert S3 == 16 and len([k for k in d3 if 8 < k < 16]) <= 3
+    assert _first_passing(law(3.17e-5 * 8 ** 4), (8, 16), 1e-5, refine=False)[0] == 16
+    # the guard's comparison partner: half the steps (floor) with the Richardson factor of THAT ratio; S = 1 doubles
+    assert _other_steps(8) == (4, 1.0 / 15.0) and _other_steps(1) == (2, 16.0 / 15.0)
+    s2, f = _other_steps(11)
+    assert s2 == 5 and abs(f - 1.0 / ((11 / 5) ** 4 - 1.0)) < 1e-15
+    # the factor recovers e_S exactly under the S^-4 law: e_S' - e_S = diff
+    for S_ in (2, 3, 11, 12, 17):
+        o, fac = _other_steps(S_)
+        e = lambda n: 7.0 / n ** 4
+        assert abs(fac * (e(o) - e(S_)) - e(S_)) < 1e-12 * e(S_) + 1e-18

@@ -73,7 +73,7 @@ def _bench_two_ranks(extra):
     import json
     _free_parent_cache()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-sub-blocks",
-                          "--no-cpu-baseline", "--no-f32-subblock"] + extra, capture_output=True, text=True, timeout=900, env=_clean_env(), cwd=ROOT)
+                          "--no-cpu-baseline", "--no-f32-subblock", "--train-shape", "1,2,1024"] + extra, capture_output=True, text=True, timeout=900, env=_clean_env(), cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -85,6 +85,16 @@ def _bench_two_ranks(extra):
     return r, ranks
 
 
+def _check_sharded_train_leg(r, library):
+    """N > 1 (round 6): the line's `train_cfg3` is the SHARDED training step -- the one place the path has a collective (train.py:131-132's
+    replacement: one flat gradient all-reduce per step) -- with the collective timed per rank; here at a shrunken per-rank shape."""
+    t = r["train_cfg3"]
+    assert t is not None and "sharded" in t["workload"] and t["ms_per_step"] > 0 and library in t["ranks"]["library"].lower(), t
+    assert len(t["allreduce_ms"]) == 2 and all(v > 0 for v in t["allreduce_ms"]) and t["allreduce_ms_min_over_ranks"] == min(t["allreduce_ms"])
+    assert t["bucket_bytes"] >= 4 * 16262189 and len(t["ranks"]["ms_per_step"]) == 2
+    assert t["loss_first"] == t["loss_first"] and abs(t["loss_first"]) < 1e6          # finite
+
+
 def test_bench_two_gpus_is_a_tested_path():
     """`python bench.py --gpus 2` as the driver's scaling run starts it (round-4 review: the first 8-GPU run must not be the first
     execution of this path): one JSON line, n_gpus = 2, the collective library named, one per-rank time per rank, and the whole-job
@@ -92,6 +102,7 @@ def test_bench_two_gpus_is_a_tested_path():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs (RCCL); test_bench_two_ranks_sharing_one_gpu runs the same rank logic on this box over gloo")
     r, ranks = _bench_two_ranks([])
+    _check_sharded_train_leg(r, "ccl")
     assert ranks["library"] and ("nccl" in ranks["library"].lower() or "rccl" in ranks["library"].lower()), ranks
     assert abs(r["value"] - 32 / (r["ms_per_step"] * 1e-3)) <= 0.02 * r["value"]
     per_rank = sum(16 / (ms * 1e-3) for ms in ranks["ms_per_step"])
@@ -106,6 +117,7 @@ def test_bench_two_ranks_sharing_one_gpu():
     GPU suite actually runs on."""
     r, ranks = _bench_two_ranks(["--share-gpu"])
     assert r["value"] is None and "NOT a measurement" in r["test_mode"] and "gloo" in ranks["library"]
+    _check_sharded_train_leg(r, "gloo")
 
 
 MODEL_WORKER = r'''

@@ -1,7 +1,7 @@
 # HBM-side traffic of the 1600 -> 1600 head layer alone on the persistent 512-channel kernel: with the default dispatch the kernel also
 # runs other layers and the head layer in two pieces, which the per-kernel PMC summary cannot tell apart -> this pass restricts the
 # kernel to that layer (CASPR_X6W_MIN_CIN=1024) in one piece (CASPR_EARLY_LATENT=0)
-export TMPDIR=/tmp CASPR_X6W_MIN_CIN=1024 CASPR_EARLY_LATENT=0
+export TMPDIR=/tmp CASPR_DEBUG=1 CASPR_X6W_MIN_CIN=1024 CASPR_EARLY_LATENT=0
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT
 : > $OUT/r04_run3_conv_traffic_pmc.txt
 cd /tmp
