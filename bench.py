@@ -593,17 +593,28 @@ def kernel_rooflines(cnf, detail, traffic_table, shape, sa_wall_ms=None):
         ms_all = sum(sum(ms) for ms in convs.values())
         (ci, co, rows), ms = max(convs.items(), key=lambda kv: kv[0][0] * kv[0][1] * kv[0][2])
         a_big = 2.0 * ci * co * rows / (sum(ms) / len(ms) * 1e-3) / 1e12
-        tj = traffic_table.get("conv_largest:%dx%d:%s" % (ci, co, wl))
+        # per LAYER (round 6): the sum over the launches of one conv -> GroupNorm call of that shape, run on its own between marker launches
+        # (tools/conv_layers_pmc.py; rounds 3-5 averaged every launch of the persistent kernel, which hid the pieces that re-read their input)
+        def layer_traffic(ci_, co_, rows_):
+            t_ = traffic_table.get("conv_layer:%d:%d:%d:%s" % (ci_, co_, rows_, wl))
+            return None if not t_ else {"bytes": int(1024 * (t_["fetch_size_kb"] * t_["fetch_correction"] + t_["write_size_kb"])),
+                                        "over_algorithmic": round((t_["fetch_size_kb"] * t_["fetch_correction"] + t_["write_size_kb"]) / t_["algorithmic_kb"], 3)}
+        big_t = layer_traffic(ci, co, rows)
+        tj = None if big_t else traffic_table.get("conv_largest:%dx%d:%s" % (ci, co, wl))
         out.append({"kernel": "pointwise convs on the bf16x6 kernels (csrc/gemm_bf16x6w.hip for >= 1024 input and >= 512 output channels, csrc/gemm_bf16x6.hip "
                               "otherwise); largest layer %d -> %d over %d rows" % (ci, co, rows), "bound": "mfma",
                     "achieved": round(a_big, 3), "peak": round(PEAK_MFMA_BF16_TFLOPS / 6.0, 1), "unit": "TFLOP/s", "frac": round(a_big / (PEAK_MFMA_BF16_TFLOPS / 6.0), 4),
-                    "traffic": int(1024 * (tj["fetch_size_kb_per_launch"] * tj["fetch_correction"] + tj["write_size_kb_per_launch"])) if tj else None,
+                    "traffic": big_t["bytes"] if big_t else (int(1024 * (tj["fetch_size_kb_per_launch"] * tj["fetch_correction"] + tj["write_size_kb_per_launch"])) if tj else None),
+                    "traffic_over_algorithmic": big_t["over_algorithmic"] if big_t else None,
+                    "traffic_unit": "bytes per conv -> GroupNorm call of the largest layer, all of its launches (main tiles + channel remainder + finalize)",
                     "launch_ms": round(sum(ms) / len(ms), 3),
                     "all_layers": {"launches_per_step": sum(len(m) for m in convs.values()) // 2, "ms_per_step": round(ms_all / 2, 3),
                                    "achieved": round(flop_all / (ms_all * 1e-3) / 1e12, 3), "frac": round(flop_all / (ms_all * 1e-3) / 1e12 / (PEAK_MFMA_BF16_TFLOPS / 6.0), 4)},
                     # per layer shape (Cin -> Cout over rows): launches per step, ms per launch, fraction of the bf16x6 ceiling
                     "layers": [{"cin": ci_, "cout": co_, "rows": rows_, "launches_per_step": len(m_) // 2, "ms": round(sum(m_) / len(m_), 4),
-                                "frac": round(2.0 * ci_ * co_ * rows_ / (sum(m_) / len(m_) * 1e-3) / 1e12 / (PEAK_MFMA_BF16_TFLOPS / 6.0), 4)}
+                                "frac": round(2.0 * ci_ * co_ * rows_ / (sum(m_) / len(m_) * 1e-3) / 1e12 / (PEAK_MFMA_BF16_TFLOPS / 6.0), 4),
+                                "traffic": (layer_traffic(ci_, co_, rows_) or {}).get("bytes"),
+                                "traffic_over_algorithmic": (layer_traffic(ci_, co_, rows_) or {}).get("over_algorithmic")}
                                for (ci_, co_, rows_), m_ in sorted(convs.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2])]})
     sa = [(float(k.split(":")[5]) * 1e6, ms) for k, ms in detail.items() if k.split(":")[1].startswith("sa_mlp_max")]     # (+ "_mfma" / "_f64": a scale's two halves on two streams)
     if sa:

@@ -24,6 +24,15 @@ python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pm -name "*results.db" | h
 grep -E "counter|cnf_rk4|conv1x1_bf16x6|conv1x1_x6w" /tmp/pmc_sq.txt > $OUT/${TAG}_sq_pmc.txt
 # the traffic table bench.py reads (profiles/kernel_traffic.json): cfg-2
 python $REPO/tools/make_traffic_table.py $OUT/${TAG}_traffic_pmc.txt 16x10x2048 8 ${TAG}_traffic_pmc.txt
+# per-LAYER traffic of the pointwise convs (each layer of cfg-2 on its own between marker launches: tools/conv_layers_pmc.py)
+: > $OUT/${TAG}_conv_layers_pmc.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pc && rocprofv3 --kernel-trace --pmc $C -d /tmp/pc -o r -- python $REPO/tools/conv_layers_pmc.py run > /dev/null 2> /tmp/pc.err
+  rm -f /tmp/conv_$C.txt
+  python $REPO/tools/rocprof_pmc_summary.py $(find /tmp/pc -name "*results.db" | head -1) /tmp/conv_$C.txt --dispatches "conv1x1|chamfer_kernel|conv_gn"
+  grep -E "^D |counter" /tmp/conv_$C.txt >> $OUT/${TAG}_conv_layers_pmc.txt
+done
+python $REPO/tools/conv_layers_pmc.py join /tmp/conv_FETCH_SIZE.txt /tmp/conv_WRITE_SIZE.txt ${TAG}_conv_layers_pmc.txt > $OUT/${TAG}_conv_layers_traffic.txt 2>&1
 # cfg-5 shape (BASELINE.json configs[4], one GPU's share): 64 sequences x 20 x 4096, random clouds
 python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 3 --warmup 1 --no-f32-subblock > $OUT/${TAG}_cfg5_bench.json 2> $OUT/${TAG}_cfg5_bench.err; echo "cfg5 rc=$?" >> $OUT/${TAG}_cfg5_bench.err
 rm -rf /tmp/p5 && rocprofv3 --kernel-trace --stats -d /tmp/p5 -o r -- python $REPO/bench.py --clouds random --batch 64 --seq-len 20 --num-pts 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-f32-subblock --no-guard-subblock > /dev/null 2> /tmp/p5.err
