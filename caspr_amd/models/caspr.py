@@ -298,28 +298,36 @@ class CaSPR(nn.Module):
             t_.record_stream(gs)
 
     def _guard_cnf_begin(self, y, z, logpx=None, e=None):
-        """Queue the point CNF once more on the first `check_points` samples of every frame at half (or twice) the step count on the
-        guard stream, BEHIND AN EVENT RECORDED BEFORE THE MAIN SOLVE IS LAUNCHED: the check needs y and z only, so its 160 small
-        workgroups run beside the main launch instead of after it.  -> what _guard_cnf_end needs.
+        """What the check of this solve needs, captured BEFORE the main launch (the weight packs / end time are built on first use: on the
+        MAIN stream, before the guard stream reads them).  -> what _guard_cnf_end needs.
         logpx / e given: the density direction of forward() (cnf.py:70-128 with the Hutchinson divergence, same noise on the same
         samples); otherwise the sampling direction of decode()."""
         from .cnf import CNF
         blocks = [l for l in self.point_cnf.chain if isinstance(l, CNF)]
-        for b in blocks:               # weight packs / end time are built on first use: on the MAIN stream, before the guard stream reads them
+        for b in blocks:
             b._weights()
             if ops.CNF_BF16X6:
                 b._weights_x6()
             b.end_time()
         S = blocks[0].rk4_steps
         S2, factor = _other_steps(S)
-        g = min(int(self.check_points), y.shape[1])
-        main = torch.cuda.current_stream()
-        gs = _guard_stream(y.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
+        return {"y": y, "z": z, "logpx": logpx, "e": e, "blocks": blocks, "g": min(int(self.check_points), y.shape[1]), "S": S, "S2": S2, "factor": factor,
+                "stream": _guard_stream(y.device)}
+
+    def _guard_cnf_end(self, ctx, x):
+        """The point CNF once more on the first `check_points` samples of every frame at half (S = 1: twice) the step count on the guard
+        stream, queued BEHIND the main launch (round 6; rounds 5 queued it beside the launch, where each of its 160 workgroups held up one
+        of the 256 compute units' ten main workgroups: +3 % of a step): the check then runs under whatever the caller does next -- in a loop
+        over batches the first, latency-bound milliseconds of the next call's encoder (farthest-point sampling on 160 of 256 units) -- and
+        its verdict, which travels through the deferred channel anyway (ops.guard_track), arrives a millisecond later.
+        max |x_S - x_S'| on the checked samples -> the deferred channel; nothing on the current stream waits."""
+        gs, g, blocks = ctx["stream"], ctx["g"], ctx["blocks"]
+        y, z, logpx, e = ctx["y"], ctx["z"], ctx["logpx"], ctx["e"]
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
         saved = [(b, b.rk4_steps) for b in blocks]
         with torch.cuda.stream(gs), ops.untimed():
-            gs.wait_event(ready)
+            gs.wait_event(done)
             try:
                 for b in blocks:
                     b.rk4_steps, b._count_evals, b.odefunc._count_evals, b._narrow = _other_steps(b.rk4_steps)[0], False, False, g <= 64
@@ -330,28 +338,17 @@ class CaSPR(nn.Module):
             finally:
                 for b, st in saved:
                     b.rk4_steps, b._count_evals, b.odefunc._count_evals, b._narrow = st, True, True, False
-        for t_ in (y, z, logpx, e):
-            if t_ is not None:
-                t_.record_stream(gs)
-        return {"xh": xh, "g": g, "S": S, "S2": S2, "factor": factor, "stream": gs}
-
-    def _guard_cnf_end(self, ctx, x):
-        """max |x_S - x_S'| on the checked samples -> the deferred channel (ops.guard_track); nothing on the current stream waits."""
-        gs, g = ctx["stream"], ctx["g"]
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream())
-        with torch.cuda.stream(gs), ops.untimed():
-            gs.wait_event(done)
             meta = {"tol": float(self.check_tol), "factor": ctx["factor"], "steps": ctx["S"], "other_steps": ctx["S2"], "action": self.check_action}
             if torch.is_tensor(x):
-                diff = (x[:, :g] - ctx["xh"]).abs().amax()
+                diff = (x[:, :g] - xh).abs().amax()
                 ops.guard_track(diff, x[:, :g].abs().amax(), dict(meta, name="cnf", what="point CNF (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"))
             else:               # density direction: the state is (y, logp), both integrated (cnf.py:112-126)
                 for i, (nm, what) in enumerate((("cnf_fwd_y", "point CNF, density direction, y"), ("cnf_fwd_logp", "point CNF, density direction, log-density"))):
-                    diff = (x[i][:, :g] - ctx["xh"][i]).abs().amax()
+                    diff = (x[i][:, :g] - xh[i]).abs().amax()
                     ops.guard_track(diff, x[i][:, :g].abs().amax(), dict(meta, name=nm, what=what + " (cnf.py:70-128; reference: dopri5 at atol = rtol = 1e-5)"))
-        for t_ in ((x,) if torch.is_tensor(x) else x):
-            t_.record_stream(gs)
+        for t_ in (y, z, logpx, e) + ((x,) if torch.is_tensor(x) else tuple(x)):
+            if t_ is not None:
+                t_.record_stream(gs)
 
     def gen_latent(self, z0, timestamps):
         """caspr.py:185-196."""
