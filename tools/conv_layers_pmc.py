@@ -58,8 +58,8 @@ def parse(path, counter):
         m = re.match(r"^D (\d+) (\S+) ([0-9.e+-]+) (\d+) (.*)$", ln.rstrip("\n"))
         if not m or m.group(2) != counter:
             continue
-        if "chamfer_kernel" in m.group(5):
-            if cur is not None:
+        if "chamfer_kernel" in m.group(5):          # (a marker is two launches: both directions of the distance)
+            if cur:
                 groups.append(cur)
             cur = []
         elif cur is not None:
