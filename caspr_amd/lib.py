@@ -24,6 +24,7 @@ SIGNATURES = {
     "caspr_fps_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_ip, c_fp, c_stream]),
     "caspr_gather_points_f32": (c_int, [c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_fp, c_int, c_stream]),
     "caspr_ball_query_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_float, c_int, c_ip, c_stream]),
+    "caspr_ball_query2_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_float, c_int, c_ip, c_float, c_int, c_ip, c_stream]),
     "caspr_group_points_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_fp, c_stream]),
     "caspr_sa_mlp_max_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_ip, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_fp, c_fp, c_fp, c_fp, c_int,

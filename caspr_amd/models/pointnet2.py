@@ -22,6 +22,8 @@ from .lazy import Lazy
 
 NUM_GROUPS = 16  # for group norm (pointnet2.py:12)
 LO_PARTS = _cfg.sa_lo_parts  # the first set-abstraction level hands its output to the second as an unevaluated sum hi + lo (PointNet2feat.run)
+LONG_SCALE_ON_MAIN = True              # of a level's two scales the one with MORE samples on the caller's stream, the other on the side stream (False: rounds 5's order)
+BALL_QUERY_PAIR = True                 # the two ball queries of a level as one launch (ops.ball_query_pair)
 SCALE_STREAMS = _cfg.sa_scale_streams  # the two scales of a set-abstraction level on two streams (PointNet2SetAbstraction.run)
 PRE_AGGREGATE = _cfg.sa_pre_aggregate  # the wide set-abstraction levels' first layer once per source point (PointNet2SetAbstraction.run)
 FP_COMMUTE = _cfg.fp_commute           # feature propagation's first conv on the coarse level where the skip part is tiny (PointNet2FeaturePropagator.run)
@@ -205,11 +207,20 @@ class PointNet2SetAbstraction(nn.Module):
         # the scales on two streams (run()) the level ends when that one does -- it should not wait behind the other scale's query
         ball, ready = [None] * len(self.layers), [None] * len(self.layers)
         order = sorted(range(len(self.layers)), key=lambda i_: -self.layers[i_])
-        for i in order:
-            ball[i] = ops.ball_query(self.grouper_modules[i].radius, self.layers[i], xyz, new_xyz)  # :391
+        if BALL_QUERY_PAIR and len(self.layers) == 2:
+            # both scales' queries in one pass over the cloud (round 6: at the first level they were 0.50 + 0.38 ms in front of the first
+            # set-abstraction kernel; one distance per (centre, point) serves both radii) -- the same rows, bit for bit
+            g0, g1 = self.grouper_modules
+            ball[0], ball[1] = ops.ball_query_pair(g0.radius, self.layers[0], g1.radius, self.layers[1], xyz, new_xyz)      # :391
             if events:
-                ready[i] = torch.cuda.Event()
-                ready[i].record()
+                ready[0] = ready[1] = torch.cuda.Event()
+                ready[0].record()
+        else:
+            for i in order:
+                ball[i] = ops.ball_query(self.grouper_modules[i].radius, self.layers[i], xyz, new_xyz)  # :391
+                if events:
+                    ready[i] = torch.cuda.Event()
+                    ready[i].record()
         d = {"fps_idx": fps_idx, "new_xyz": new_xyz, "ball_idx": ball}
         if events:
             d["scale_ready"] = ready
@@ -262,8 +273,13 @@ class PointNet2SetAbstraction(nn.Module):
         # scales already fill, and every extra stream costs its joins.
         halves = side is not None and self.narrow() and F64_STREAMS
         off, extra = 0, []
+        # which scale goes to the side stream: the one with FEWER samples (round 6).  The side stream shares a hardware queue with other side
+        # streams of the step (HIP multiplexes a process's streams onto four queues; more queues measured slower: profiles/r06_hwq_ab.txt) --
+        # at the first level with the global PointNet's convs, behind which a kernel queued there waits (profiles/r06c_step_timeline.txt:
+        # the 32-sample scale started 1.3 ms after its indices were ready) -- so the LONG kernel of the level runs on the caller's stream
+        side_scale = (min(range(len(self.layers)), key=lambda i_: (self.layers[i_], -i_)) if LONG_SCALE_ON_MAIN else len(self.layers) - 1) if side is not None else None
         for i, ns in enumerate(self.layers):
-            on_side = side is not None and i == len(self.layers) - 1
+            on_side = side is not None and i == side_scale
             with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
                 if "scale_ready" in idx:
                     self._await(idx, i)

@@ -132,6 +132,19 @@ def furthest_point_sampling(xyz, M, guard=True, return_xyz=False):
     return (idx, new_xyz) if return_xyz else idx
 
 
+def ball_query_pair(radius_a, ns_a, radius_b, ns_b, xyz, new_xyz):
+    """The two ball queries of a set-abstraction level (one grouper per radius over the same xyz / new_xyz, pointnet2.py:338-342,391) in ONE
+    pass over the cloud -> (idx_a (B,M,ns_a), idx_b (B,M,ns_b)), each what ball_query returns for its radius, bit for bit."""
+    _chk_f32(xyz, new_xyz)
+    B, n, _ = xyz.shape
+    M = new_xyz.shape[1]
+    ia = torch.empty(B, M, ns_a, device=xyz.device, dtype=torch.int32)
+    ib = torch.empty(B, M, ns_b, device=xyz.device, dtype=torch.int32)
+    _lib.check(_lib.load().caspr_ball_query2_f32(_p(xyz), _p(new_xyz), B, n, M, float(radius_a), ns_a, _p(ia), float(radius_b), ns_b, _p(ib), _stream()),
+               "caspr_ball_query2_f32")
+    return ia, ib
+
+
 def gather_points(feat, idx):
     """Point-major `fps_gather_by_index`: feat (B,n,C), idx (B,M) -> (B,M,C)  (pointnet2.py:385)."""
     _chk_f32(feat)

@@ -60,6 +60,11 @@ int caspr_gather_points_f32(const float *feat, int ldf, const int32_t *idx, int 
  * xyz (B,n,3), new_xyz (B,M,3) -> idx (B,M,ns) int32.  Contract = oracle_ball_query.              */
 int caspr_ball_query_f32(const float *xyz, const float *new_xyz, int B, int n, int M, float radius,
                          int ns, int32_t *idx, void *stream);
+/* The two queries of a set-abstraction level (PointNet2SetAbstraction builds one grouper per radius over the same xyz / new_xyz:
+ * models/pointnet2.py:338-342, both called at :391) in one pass over the cloud: idx_a (B,M,ns_a), idx_b (B,M,ns_b), each row what
+ * caspr_ball_query_f32 writes for its radius, bit for bit.                                                                      */
+int caspr_ball_query2_f32(const float *xyz, const float *new_xyz, int B, int n, int M, float radius_a, int ns_a, int32_t *idx_a,
+                          float radius_b, int ns_b, int32_t *idx_b, void *stream);
 
 /* Kaolin group_gather_by_index + centre subtraction + xyz||feat concat (pointnet2.py:391-398):
  * out (B,M,3+C,ns) exactly as the reference's grouper returns it.  feat point-major (B,n,C), may be NULL. */

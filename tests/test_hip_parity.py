@@ -167,6 +167,22 @@ def test_ball_query_bit_exact(ops, dev, n, M, r, ns):
     exact("ball_n%d_r%g_ns%d" % (n, r, ns), ops.ball_query(r, ns, c.to(dev), ctr.to(dev)), P.ball_query(r, ns, c, ctr))
 
 
+@pytest.mark.parametrize("n,M,ra,nsa,rb,nsb", [(2048, 1024, 0.02, 16, 0.05, 32), (1024, 512, 0.05, 16, 0.1, 32), (512, 256, 0.2, 32, 0.1, 16), (256, 64, 0.2, 16, 0.4, 32),
+                                               (64, 16, 0.4, 16, 0.8, 32),          # below the LDS kernel's shapes: two plain launches behind the same entry
+                                               (2048, 100, 0.05, 32, 0.05, 32), (8192, 1024, 0.01, 16, 0.03, 32), (300, 64, 0.1, 16, 0.2, 16)])
+def test_ball_query_pair_is_the_two_queries(ops, dev, n, M, ra, nsa, rb, nsb):
+    """caspr_ball_query2_f32 (round 6: both scales of a set-abstraction level in one pass over the cloud, pointnet2.py:338-342,391): each
+    scale's rows bit-identical to its own caspr_ball_query_f32 call AND to the oracle -- car clouds, duplicate padding (exact ties, full
+    balls: a scale that has its ns hits stops recording while the other goes on), radii in either order, equal radii, a ragged last wave."""
+    c = clouds(2, n, seed=n + 1, dup=(n == 300))
+    ctr = torch.gather(c, 1, P.furthest_point_sampling(c, M).long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    ga, gb = ops.ball_query_pair(ra, nsa, rb, nsb, c.to(dev), ctr.to(dev))
+    exact("ball_pair_a_n%d_r%g_ns%d" % (n, ra, nsa), ga, ops.ball_query(ra, nsa, c.to(dev), ctr.to(dev)))
+    exact("ball_pair_b_n%d_r%g_ns%d" % (n, rb, nsb), gb, ops.ball_query(rb, nsb, c.to(dev), ctr.to(dev)))
+    exact("ball_pair_a_oracle_n%d" % n, ga, P.ball_query(ra, nsa, c, ctr))
+    exact("ball_pair_b_oracle_n%d" % n, gb, P.ball_query(rb, nsb, c, ctr))
+
+
 def test_ball_query_empty_ball(ops, dev):
     c = clouds(1, 128)
     ctr = torch.tensor([[[10.0, 10.0, 10.0], [c[0, 5, 0], c[0, 5, 1], c[0, 5, 2]]]])

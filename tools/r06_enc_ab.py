@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""A/B of round 6's encoder-side scheduling changes on the headline call (B=16, T=10, N=2048, guard on = the default), alternating in one
+process: the two ball queries of a level as one launch (pointnet2.BALL_QUERY_PAIR), the long scale of a level on the caller's stream
+(pointnet2.LONG_SCALE_ON_MAIN)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from caspr_amd.models import CaSPR
+from caspr_amd.models import pointnet2 as P2
+from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences
+dev = torch.device("cuda:0")
+m = CaSPR()
+m.load_state_dict(seeded_state_dict(m.state_dict(), 0))
+m = m.to(dev).eval()
+x, sp = car_sequences(16, 10, 2048, seed=1234)
+x, ts = x.to(dev), sp[0, :, 0, 3].to(dev)
+def run(k):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(k): out = m.reconstruct(x, num_points=2048, timestamps=ts)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / k * 1e3, out
+ref = None
+for guard in (1e-5, None):
+    m.check_tol = guard
+    for rep in range(3):
+        for pair, long_main in ((False, False), (True, False), (False, True), (True, True)):
+            P2.BALL_QUERY_PAIR, P2.LONG_SCALE_ON_MAIN = pair, long_main
+            run(2)
+            ms, out = run(10)
+            print("guard %-5s rep %d  ball_query_pair %-5s long_scale_on_main %-5s : %.3f ms/step" % (guard, rep, pair, long_main, ms), flush=True)
+P2.BALL_QUERY_PAIR, P2.LONG_SCALE_ON_MAIN = True, True
+# same outputs whatever the schedule (same base samples)
+torch.manual_seed(0); y = torch.randn(16, 10, 2048, 3, device=dev)
+outs = []
+for pair, long_main in ((False, False), (True, True)):
+    P2.BALL_QUERY_PAIR, P2.LONG_SCALE_ON_MAIN = pair, long_main
+    with torch.no_grad():
+        o = m.reconstruct(x, num_points=2048, timestamps=ts, y=y)
+    torch.cuda.synchronize()
+    outs.append(o)
+print("outputs identical across schedules:", bool(torch.equal(outs[0][2], outs[1][2])) and bool(torch.equal(outs[0][3], outs[1][3])))
