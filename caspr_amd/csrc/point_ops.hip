@@ -89,55 +89,12 @@ extern "C" int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int
 // Wave reduction by DPP row steps + v_readlane (wave_max_u64), 4 wave results through a double-buffered LDS slot:
 // one barrier per round.
 // ---------------------------------------------------------------------------------------------
-// Round 6: the per-round instruction stream (the rounds are a dependent chain: 1,023 of them per frame at the first level, ~1,900
-// cycles each in round 5) was halved without touching a single rounding:
-//  * the distances of a thread's points in PAIRS on the packed f32 pipe (v_pk_add / v_pk_mul / v_pk_fma_f32: the same IEEE operations
-//    in the same order as sqdist3 -- dy * dy first, then fma(dx, dx, .), then fma(dz, dz, .) -- two points per instruction);
-//  * the per-thread arg-max on 32-bit operands: the thread's points are HELD IN PRIORITY ORDER of the tie key (smaller
-//    (bitrev(k mod bs), k) first: for bs = 512 the points with even i before the odd ones, ascending otherwise), so a strict
-//    `d > best` in that order keeps exactly the point the 64-bit key comparison kept -- compare + two selects per point instead of
-//    a 64-bit key build, a 64-bit compare and two selects; points outside the cloud / under the origin guard carry a running minimum of
-//    -1, which never wins (the identity);
-//  * the wave arg-max as two 32-bit DPP reductions (max distance, then max tie key among the lanes that hold it) instead of one 64-bit
-//    one; the four wave results still meet as 64-bit keys in the double-buffered LDS slot, one barrier per round.
-typedef float fps_f32x2 __attribute__((ext_vector_type(2)));
-typedef int fps_i32x2 __attribute__((ext_vector_type(2)));
-
-// max over the wave of a signed 32-bit value / an unsigned one: four DPP row steps with the operation on the DPP operand itself, the four
-// row results through v_readlane.  (Distances travel as their BIT PATTERNS: a non-negative float orders like its pattern read as a
-// signed integer, and the "never a candidate" value -1.0f, 0xBF800000, is below all of them -- integer min / max have no NaN
-// canonicalisation step in front of them, v_min_f32 / v_max_f32 under IEEE mode do.)
-__device__ __forceinline__ int fps_wave_max_i32(int x)
-{
-    int o;
-    o = dpp_mov_i32<0xB1>(x);  x = o > x ? o : x;
-    o = dpp_mov_i32<0x4E>(x);  x = o > x ? o : x;
-    o = dpp_mov_i32<0x141>(x); x = o > x ? o : x;
-    o = dpp_mov_i32<0x140>(x); x = o > x ? o : x;
-    int best = __builtin_amdgcn_readlane(x, 0);
-#pragma unroll
-    for (int row = 1; row < 4; ++row) {
-        const int r = __builtin_amdgcn_readlane(x, row * 16);
-        best = r > best ? r : best;
-    }
-    return best;
-}
-__device__ __forceinline__ unsigned fps_wave_max_u32(unsigned x)
-{
-    unsigned o;
-    o = (unsigned)dpp_mov_i32<0xB1>((int)x);  x = o > x ? o : x;
-    o = (unsigned)dpp_mov_i32<0x4E>((int)x);  x = o > x ? o : x;
-    o = (unsigned)dpp_mov_i32<0x141>((int)x); x = o > x ? o : x;
-    o = (unsigned)dpp_mov_i32<0x140>((int)x); x = o > x ? o : x;
-    unsigned best = (unsigned)__builtin_amdgcn_readlane((int)x, 0);
-#pragma unroll
-    for (int row = 1; row < 4; ++row) {
-        const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)x, row * 16);
-        best = r > best ? r : best;
-    }
-    return best;
-}
-
+// (Round 6 tried a leaner round -- packed f32 distances, a 32-bit selection in tie-key priority order, two 32-bit wave reductions: 810 -> 660 us
+// at the first level, every selection bit-exact on an idle chip -- and REVERTED it: beside the global PointNet's stats-only conv
+// (conv1x1_bf16x6_kernel<true, true> with no output: 128 -> 1024) on another stream its selections at the later levels (n <= 1024) went
+// wrong in a few frames from some round on, run to run differently, while this kernel next to the same partner never does
+// (tools/r06_fps_beside_conv.py, profiles/r06_fps_beside_conv.txt).  Neither the in-place DPP operands nor the packed arithmetic were the
+// cause (variants without them fail the same way); the root cause was not found in the time available, so the proven kernel stays.)
 template <int PPT>
 __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz, int n, int M, int bs_bits,
                                                   int guard, int32_t *__restrict__ idx,
@@ -151,29 +108,22 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
     for (int i = tid; i < n * 3; i += 256) sx[i] = p[i];
     __syncthreads();
 
-    constexpr int NP = (PPT + 1) / 2;          // pairs of points
-    fps_f32x2 px[NP], py[NP], pz[NP];
-    int tmp[2 * NP];                           // running minimum distance, as its bit pattern
-    unsigned kkey[2 * NP];
+    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    bool ok[PPT];
+    unsigned kkey[PPT];
 #pragma unroll
-    for (int s = 0; s < 2 * NP; ++s) {
-        // slot s holds the thread's point of priority s: its tie key (bitrev(k mod bs) << 16 | k, smaller wins) ascends with s.  k = tid + 256 i;
-        // for bs = 512 the bit reversal turns bit 8 of k mod 512 -- the parity of i -- into the lowest bit of the reversed field, below the
-        // bits tid fixes: even i first, then odd i, ascending inside each; for bs <= 256 the reversed part is the same for all i: ascending i.
-        int i = s;
-        if (PPT >= 2 && bs_bits == 9) i = (s < PPT / 2) ? 2 * s : 2 * (s - PPT / 2) + 1;
+    for (int i = 0; i < PPT; ++i) {
         const int k = tid + 256 * i;
-        const bool in = s < PPT && k < n;
-        const float x_ = in ? sx[k * 3 + 0] : 0.f, y_ = in ? sx[k * 3 + 1] : 0.f, z_ = in ? sx[k * 3 + 2] : 0.f;
-        px[s >> 1][s & 1] = x_;
-        py[s >> 1][s & 1] = y_;
-        pz[s >> 1][s & 1] = z_;
-        const float mag = sqsum3(x_, y_, z_);
-        const bool ok = in && !(guard && mag <= 1e-3f);
-        tmp[s] = __builtin_bit_cast(int, ok ? 1e10f : -1.0f);      // -1: never a candidate (every real distance is >= +0: min(d, -1) stays -1)
+        const bool in = k < n;
+        px[i] = in ? sx[k * 3 + 0] : 0.f;
+        py[i] = in ? sx[k * 3 + 1] : 0.f;
+        pz[i] = in ? sx[k * 3 + 2] : 0.f;
+        tmp[i] = 1e10f;
+        const float mag = sqsum3(px[i], py[i], pz[i]);
+        ok[i] = in && !(guard && mag <= 1e-3f);
         // bit reversal of (k mod bs) over bs_bits bits (bs_bits = 0: a one-thread block, no tie key)
         const unsigned rev = bs_bits ? (__brev((unsigned)k) >> (32 - bs_bits)) : 0u;
-        kkey[s] = ~((rev << 16) | (unsigned)k);
+        kkey[i] = ~((rev << 16) | (unsigned)k);
     }
     int32_t *out = idx + (long)b * M;
     float *oxyz = new_xyz ? new_xyz + (long)b * M * 3 : nullptr;
@@ -183,35 +133,23 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
         if (oxyz) { oxyz[0] = sx[0]; oxyz[1] = sx[1]; oxyz[2] = sx[2]; }
     }
     const int lane = tid & 63, wave = tid >> 6;
-    const int never = __builtin_bit_cast(int, -1.0f);
     for (int j = 1; j < M; ++j) {
         const float x1 = sx[old * 3 + 0], y1 = sx[old * 3 + 1], z1 = sx[old * 3 + 2];
-        const fps_f32x2 xx = {x1, x1}, yy = {y1, y1}, zz = {z1, z1};
-        int bd = never;
+        unsigned long long best = 0ull;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            // sqdist3 on two points at once: (py - y1)^2 rounded, then fma((px - x1), (px - x1), .), then fma((pz - z1), (pz - z1), .)
-            const fps_f32x2 dx = px[q] - xx, dy = py[q] - yy, dz = pz[q] - zz;
-            const fps_f32x2 yy2 = dy * dy;
-            const fps_f32x2 t1 = __builtin_elementwise_fma(dx, dx, yy2);
-            const fps_f32x2 d = __builtin_elementwise_fma(dz, dz, t1);
-            const fps_i32x2 dbits = __builtin_bit_cast(fps_i32x2, d);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int di = dbits[h], t = tmp[2 * q + h];
-                const int d2 = di < t ? di : t;               // = (d < tmp ? d : tmp) on the patterns: d >= +0, tmp >= +0 or -1.0f
-                tmp[2 * q + h] = d2;
-                bd = d2 > bd ? d2 : bd;
+        for (int i = 0; i < PPT; ++i) {
+            if (ok[i]) {
+                const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
+                const float d2 = d < tmp[i] ? d : tmp[i];
+                tmp[i] = d2;
+                const unsigned long long key =
+                    ((unsigned long long)(__float_as_uint(d2) + 1u) << 32) | (unsigned long long)kkey[i];
+                best = key > best ? key : best;
             }
         }
-        const int wm = fps_wave_max_i32(bd);
-        // the tie key of this thread's candidate: its FIRST slot (best tie key) that holds the wave's maximum, 0 if none does
-        unsigned bk = 0u;
-#pragma unroll
-        for (int s = 2 * NP - 1; s >= 0; --s) bk = tmp[s] == wm ? kkey[s] : bk;
-        const unsigned wk = fps_wave_max_u32(bk);
+        best = wave_max_u64(best);
         unsigned long long *s = slot + (j & 1) * 4;
-        if (lane == 0) s[wave] = wm == never ? 0ull : (((unsigned long long)((unsigned)wm + 1u) << 32) | (unsigned long long)wk);
+        if (lane == 0) s[wave] = best;
         __syncthreads();
         unsigned long long m = s[0];
         m = s[1] > m ? s[1] : m;
