@@ -89,12 +89,59 @@ extern "C" int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int
 // Wave reduction by DPP row steps + v_readlane (wave_max_u64), 4 wave results through a double-buffered LDS slot:
 // one barrier per round.
 // ---------------------------------------------------------------------------------------------
-// (Round 6 tried a leaner round -- packed f32 distances, a 32-bit selection in tie-key priority order, two 32-bit wave reductions: 810 -> 660 us
-// at the first level, every selection bit-exact on an idle chip -- and REVERTED it: beside the global PointNet's stats-only conv
-// (conv1x1_bf16x6_kernel<true, true> with no output: 128 -> 1024) on another stream its selections at the later levels (n <= 1024) went
-// wrong in a few frames from some round on, run to run differently, while this kernel next to the same partner never does
-// (tools/r06_fps_beside_conv.py, profiles/r06_fps_beside_conv.txt).  Neither the in-place DPP operands nor the packed arithmetic were the
-// cause (variants without them fail the same way); the root cause was not found in the time available, so the proven kernel stays.)
+// Round 6: the per-round instruction stream (the rounds are a dependent chain: 1,023 of them per frame at the first level, ~1,900 cycles each in
+// round 5) was cut without touching a single rounding: 810 -> 575 us at the first level, 470 -> 230 us at the second.
+//  * the per-thread arg-max on 32-bit operands: the thread's points are HELD IN PRIORITY ORDER of the tie key (smaller (bitrev(k mod bs), k) first:
+//    for bs = 512 the points with even i before the odd ones, ascending otherwise); distances travel as their bit patterns (a non-negative float
+//    orders like its pattern read as a signed integer; points outside the cloud / under the origin guard carry -1.0f, below every distance, the
+//    identity): v_min_i32 / v_max3_i32 per point instead of a 64-bit key build, a 64-bit compare and two selects;
+//  * the wave arg-max as two 32-bit DPP reductions (max distance, then max tie key among the lanes that hold it -- each lane's candidate is its FIRST
+//    slot equal to the wave's maximum) instead of one 64-bit one; the four wave results still meet as 64-bit keys in the double-buffered LDS slot,
+//    one barrier per round.
+// NO PACKED f32 ARITHMETIC.  The first form of this kernel computed two distances per v_pk_add / v_pk_mul / v_pk_fma_f32 -- bit-exact on an idle chip,
+// and WRONG beside the global PointNet's conv on another stream: in a few frames, from some round on, a different centre.  tools/micro/pk_check.hip
+// reduced it to this: a packed-f32 operation that consumes a register an LDS read has just returned (here: the selected point's y, behind
+// s_waitcnt lgkmcnt) now and then sees the register's OLD content in one 16-lane pass when a kernel with VGPR-accumulator MFMAs (conv1x1_bf16x6_kernel)
+// shares the compute unit; the same arithmetic in scalar form on the same registers, and the packed form repeated an instruction later, are right
+// (profiles/r06_pk_check.txt: the failing subtraction used y_ref = 0).  The whole library is therefore compiled WITHOUT packed-f32 instructions
+// (csrc/build.py: -target-feature -packed-fp32-ops; csrc/audit.py refuses an object that holds one): the compiler had put 9,000 of them into the
+// product kernels on its own (SLP vectorisation), and taking them out cost nothing (the headline step: 69.0 -> 68.85 ms).
+
+// max over the wave of a signed 32-bit value / an unsigned one: four DPP row steps with the operation on the DPP operand itself, the four
+// row results through v_readlane.  (Distances travel as their BIT PATTERNS: a non-negative float orders like its pattern read as a
+// signed integer, and the "never a candidate" value -1.0f, 0xBF800000, is below all of them -- integer min / max have no NaN
+// canonicalisation step in front of them, v_min_f32 / v_max_f32 under IEEE mode do.)
+__device__ __forceinline__ int fps_wave_max_i32(int x)
+{
+    int o;
+    o = dpp_mov_i32<0xB1>(x);  x = o > x ? o : x;
+    o = dpp_mov_i32<0x4E>(x);  x = o > x ? o : x;
+    o = dpp_mov_i32<0x141>(x); x = o > x ? o : x;
+    o = dpp_mov_i32<0x140>(x); x = o > x ? o : x;
+    int best = __builtin_amdgcn_readlane(x, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        const int r = __builtin_amdgcn_readlane(x, row * 16);
+        best = r > best ? r : best;
+    }
+    return best;
+}
+__device__ __forceinline__ unsigned fps_wave_max_u32(unsigned x)
+{
+    unsigned o;
+    o = (unsigned)dpp_mov_i32<0xB1>((int)x);  x = o > x ? o : x;
+    o = (unsigned)dpp_mov_i32<0x4E>((int)x);  x = o > x ? o : x;
+    o = (unsigned)dpp_mov_i32<0x141>((int)x); x = o > x ? o : x;
+    o = (unsigned)dpp_mov_i32<0x140>((int)x); x = o > x ? o : x;
+    unsigned best = (unsigned)__builtin_amdgcn_readlane((int)x, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)x, row * 16);
+        best = r > best ? r : best;
+    }
+    return best;
+}
+
 template <int PPT>
 __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz, int n, int M, int bs_bits,
                                                   int guard, int32_t *__restrict__ idx,
@@ -108,22 +155,29 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
     for (int i = tid; i < n * 3; i += 256) sx[i] = p[i];
     __syncthreads();
 
-    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
-    bool ok[PPT];
-    unsigned kkey[PPT];
+    constexpr int NP = (PPT + 1) / 2;          // slots come in pairs (PPT = 1: the second one never holds a point)
+    float px[2 * NP], py[2 * NP], pz[2 * NP];
+    int tmp[2 * NP];                           // running minimum distance, as its bit pattern
+    unsigned kkey[2 * NP];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
+    for (int s = 0; s < 2 * NP; ++s) {
+        // slot s holds the thread's point of priority s: its tie key (bitrev(k mod bs) << 16 | k, smaller wins) ascends with s.  k = tid + 256 i;
+        // for bs = 512 the bit reversal turns bit 8 of k mod 512 -- the parity of i -- into the lowest bit of the reversed field, below the
+        // bits tid fixes: even i first, then odd i, ascending inside each; for bs <= 256 the reversed part is the same for all i: ascending i.
+        int i = s;
+        if (PPT >= 2 && bs_bits == 9) i = (s < PPT / 2) ? 2 * s : 2 * (s - PPT / 2) + 1;
         const int k = tid + 256 * i;
-        const bool in = k < n;
-        px[i] = in ? sx[k * 3 + 0] : 0.f;
-        py[i] = in ? sx[k * 3 + 1] : 0.f;
-        pz[i] = in ? sx[k * 3 + 2] : 0.f;
-        tmp[i] = 1e10f;
-        const float mag = sqsum3(px[i], py[i], pz[i]);
-        ok[i] = in && !(guard && mag <= 1e-3f);
+        const bool in = s < PPT && k < n;
+        const float x_ = in ? sx[k * 3 + 0] : 0.f, y_ = in ? sx[k * 3 + 1] : 0.f, z_ = in ? sx[k * 3 + 2] : 0.f;
+        px[s] = x_;
+        py[s] = y_;
+        pz[s] = z_;
+        const float mag = sqsum3(x_, y_, z_);
+        const bool ok = in && !(guard && mag <= 1e-3f);
+        tmp[s] = __builtin_bit_cast(int, ok ? 1e10f : -1.0f);      // -1: never a candidate (every real distance is >= +0: min(d, -1) stays -1)
         // bit reversal of (k mod bs) over bs_bits bits (bs_bits = 0: a one-thread block, no tie key)
         const unsigned rev = bs_bits ? (__brev((unsigned)k) >> (32 - bs_bits)) : 0u;
-        kkey[i] = ~((rev << 16) | (unsigned)k);
+        kkey[s] = ~((rev << 16) | (unsigned)k);
     }
     int32_t *out = idx + (long)b * M;
     float *oxyz = new_xyz ? new_xyz + (long)b * M * 3 : nullptr;
@@ -133,23 +187,26 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
         if (oxyz) { oxyz[0] = sx[0]; oxyz[1] = sx[1]; oxyz[2] = sx[2]; }
     }
     const int lane = tid & 63, wave = tid >> 6;
+    const int never = __builtin_bit_cast(int, -1.0f);
     for (int j = 1; j < M; ++j) {
         const float x1 = sx[old * 3 + 0], y1 = sx[old * 3 + 1], z1 = sx[old * 3 + 2];
-        unsigned long long best = 0ull;
+        int bd = never;
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            if (ok[i]) {
-                const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
-                const float d2 = d < tmp[i] ? d : tmp[i];
-                tmp[i] = d2;
-                const unsigned long long key =
-                    ((unsigned long long)(__float_as_uint(d2) + 1u) << 32) | (unsigned long long)kkey[i];
-                best = key > best ? key : best;
-            }
+        for (int s_ = 0; s_ < 2 * NP; ++s_) {
+            const float d = sqdist3(px[s_], py[s_], pz[s_], x1, y1, z1);
+            const int di = __builtin_bit_cast(int, d), t = tmp[s_];
+            const int d2 = di < t ? di : t;               // = (d < tmp ? d : tmp) on the patterns: d >= +0, tmp >= +0 or -1.0f
+            tmp[s_] = d2;
+            bd = d2 > bd ? d2 : bd;
         }
-        best = wave_max_u64(best);
+        const int wm = fps_wave_max_i32(bd);
+        // the tie key of this thread's candidate: its FIRST slot (best tie key) that holds the wave's maximum, 0 if none does
+        unsigned bk = 0u;
+#pragma unroll
+        for (int s = 2 * NP - 1; s >= 0; --s) bk = tmp[s] == wm ? kkey[s] : bk;
+        const unsigned wk = fps_wave_max_u32(bk);
         unsigned long long *s = slot + (j & 1) * 4;
-        if (lane == 0) s[wave] = best;
+        if (lane == 0) s[wave] = wm == never ? 0ull : (((unsigned long long)((unsigned)wm + 1u) << 32) | (unsigned long long)wk);
         __syncthreads();
         unsigned long long m = s[0];
         m = s[1] > m ? s[1] : m;

@@ -580,6 +580,26 @@ def test_conv_x6w_kernel_keeps_its_accumulator_file_to_itself():
     assert len(r) >= 4 and all(k["mfma"] == 384 for k in r), r
 
 
+def test_library_holds_no_packed_f32_instructions(tmp_path):
+    """Round 6: the product objects are compiled without v_pk_add / v_pk_mul / v_pk_fma_f32 (csrc/build.py: NO_PACKED_F32; why: audit.audit_no_packed_f32
+    and the header of fps_kernel in csrc/point_ops.hip).  Every in-tree object passes the check build() runs before linking, and the check has teeth: the
+    index kernels' source compiled WITHOUT the switch -- the compiler's own SLP vectorisation puts packed instructions into it -- is refused."""
+    from caspr_amd.csrc import audit, build as B
+    if not audit.tools_present():
+        pytest.skip("needs the ROCm LLVM tools")
+    objs = {s_: os.path.join(ROOT, "caspr_amd", "csrc", s_.replace(".hip", ".o")) for s_ in B.SOURCES}
+    if not all(os.path.exists(o) for o in objs.values()):
+        pytest.skip("needs the in-tree objects (python -c 'import __graft_entry__ as g; g.build()')")
+    assert audit.audit_no_packed_f32(objs) == {s_: 0 for s_ in B.SOURCES}
+    src = os.path.join(ROOT, "caspr_amd", "csrc", "point_ops.hip")
+    obj = str(tmp_path / "packed.o")
+    flags = [f for f in B.FLAGS if f not in B.NO_PACKED_F32] + B.EXTRA["point_ops.hip"]
+    r = subprocess.run([B.HIPCC] + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    with pytest.raises(audit.AuditError, match="packed-f32"):
+        audit.audit_no_packed_f32({"point_ops.hip": obj})
+
+
 def test_build_refuses_a_code_object_whose_accumulator_file_the_compiler_touched(tmp_path):
     """The build-time gate: the same kernel compiled WITHOUT -amdgpu-mfma-vgpr-form (hipcc then parks layer 2's accumulators on top of
     the hand-managed ones) must be rejected by audit_objects -- i.e. build() would not link it."""
