@@ -198,9 +198,14 @@ def main():
     torch.cuda.synchronize()
     ops.TIMERS.clear()
     ops.TIMING = 2
+    # (per-kernel durations are measured WITHOUT the accuracy guard's check solve: queued behind a step's flow it runs under the next step's first
+    # millisecond, beside the global PointNet's convs, whose event pairs would otherwise time the contention instead of the kernel -- the 128 -> 1024
+    # layer read 2.2 ms instead of 1.0; the headline above and its own cnf_rk4 launch times are measured with the guard on)
+    guard_tol, model.check_tol = model.check_tol, None
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    model.check_tol = guard_tol
     ops.TIMING = False
     detail = {k: [a.elapsed_time(b_) for a, b_ in v] for k, v in ops.TIMERS.items() if k.startswith("k:")}
     stage_timers = {k: list(v) for k, v in ops.TIMERS.items() if not k.startswith("k:")}      # the stage clocks of the two detail steps
