@@ -562,8 +562,9 @@ def sub_blocks(args, dev, ops, timed_steps, x_headline, ts_headline):
         import contextlib
         import io
         with contextlib.redirect_stdout(io.StringIO()):
-            rep = tae.main(["--steps", str(args.trained_steps), "--eval-seqs", "2", "--ckpt", os.path.join(td, "time_model_0.pth"), "--no-dopri5"],
-                           timed_steps=timed_steps)
+            probe_at = ",".join(str(v) for v in (1200, 1600) if v < args.trained_steps)
+            rep = tae.main(["--steps", str(args.trained_steps), "--eval-seqs", "2", "--ckpt", os.path.join(td, "time_model_0.pth"), "--no-dopri5",
+                            "--probe-at", probe_at], timed_steps=timed_steps)
     curve = rep["train"]["curve"]
     head = rep["headline_on_trained_weights"]
     cal = dict(head["at_calibrated_steps"])
@@ -583,7 +584,11 @@ def sub_blocks(args, dev, ops, timed_steps, x_headline, ts_headline):
         "calibration_tol_1e-5": rep["calibration_tol_1e-5"], "guard_at_8_and_2_steps": rep["guard_at_8_and_2_steps"],
         "parity_hip_vs_f64_oracle": rep["parity_trained_weights"]["hip_vs_f64_oracle_same_rk4_map"],
         "at_default_steps": {k: head[k] for k in ("cnf_rk4_steps", "latent_rk4_steps", "steps", "ms_per_step", "sequences_per_sec", "guard")},
-        "at_calibrated_steps": cal}
+        "at_calibrated_steps": cal,
+        # the SAME training run calibrated on the way (the run is not disturbed: counts and generator states restored): the flow gets harder to
+        # integrate as it trains, and not smoothly -- the calibrated count, and with it the throughput at 1e-5, is a property of the checkpoint
+        "along_training": rep["along_training"] + [{"train_steps": args.trained_steps, "cnf_rk4_steps": cal["cnf_rk4_steps"], "latent_rk4_steps": cal["latent_rk4_steps"],
+                                                    "ms_per_step": cal["ms_per_step"], "sequences_per_sec": cal["sequences_per_sec"]}]}
     torch.cuda.empty_cache()
     return out
 

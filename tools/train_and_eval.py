@@ -42,6 +42,8 @@ def main(argv=None, timed_steps=None):
     ap.add_argument("--no-oracle", action="store_true", help="skip the CPU f64 oracle legs (parity, dopri5)")
     ap.add_argument("--no-dopri5", action="store_true", help="skip the oracle's dopri5 leg only")
     ap.add_argument("--no-headline", action="store_true", help="skip timing the headline call on the trained weights")
+    ap.add_argument("--probe-at", default="", metavar="N1,N2", help="training steps at which the model is calibrated (tol 1e-5) and the headline call timed at the "
+                    "calibrated counts, WITHOUT disturbing the run (step counts and both generators' states restored): how the flow's stiffness grows with training")
     args = ap.parse_args(argv)
 
     from caspr_amd import ops
@@ -80,7 +82,49 @@ def main(argv=None, timed_steps=None):
     curve = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    probes = sorted(int(v) for v in args.probe_at.split(",") if v.strip())
+    along = []
+    xb_p = None
+
+    def probe(at):
+        """Calibrate the CURRENT weights and time the headline call at the calibrated counts; the training run continues as if this had not happened."""
+        nonlocal xb_p
+        from caspr_amd.models.cnf import CNF as _CNF
+        cpu_rng, gpu_rng = torch.get_rng_state(), torch.cuda.get_rng_state(dev)
+        blocks = [b_ for b_ in model.point_cnf.chain if isinstance(b_, _CNF)]
+        keep = ([b_.rk4_steps for b_ in blocks], model.cnf_args.rk4_steps, model.latent_ode.rk4_steps, model.training)
+        model.eval()
+        try:
+            with torch.no_grad():
+                S_, d_, L_, ld_ = model.calibrate_rk4_steps(xe.to(dev), tol=1e-5, num_points=512, timestamps=spe[0, :, 0, 3].to(dev), latent_tol=1e-5)
+                if xb_p is None:
+                    xb_, spb_ = car_sequences(16, 10, 2048, seed=1234)
+                    xb_p = (xb_.to(dev), spb_[0, :, 0, 3].to(dev))
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    model.reconstruct(xb_p[0], num_points=2048, timestamps=xb_p[1])
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(4):
+                        model.reconstruct(xb_p[0], num_points=2048, timestamps=xb_p[1])
+                    torch.cuda.synchronize()
+                    ms_ = (time.perf_counter() - t1) / 4 * 1e3
+                    ops.check_deferred_errors()
+            along.append({"train_steps": at, "cnf_rk4_steps": S_, "latent_rk4_steps": L_, "cnf_step_doubling_diffs": {str(k): v for k, v in d_.items()},
+                          "ms_per_step": round(ms_, 3), "sequences_per_sec": round(16e3 / ms_, 2)})
+        finally:
+            for b_, st_ in zip(blocks, keep[0]):
+                b_.rk4_steps = st_
+            model.cnf_args.rk4_steps, model.latent_ode.rk4_steps = keep[1], keep[2]
+            model.train(keep[3])
+            torch.set_rng_state(cpu_rng)
+            torch.cuda.set_rng_state(gpu_rng, dev)
+            ops.reset_guard()
+
     for step in range(args.steps):
+        if step in probes:
+            probe(step)
         x, sp = car_sequences(args.batch, args.seq_len, args.num_pts, seed=100000 + step * args.batch)
         loss, cnf_l, tnocs_l = train_step(model, opt, x.to(dev), sp.to(dev))
         if step % 10 == 0 or step == args.steps - 1:
@@ -90,6 +134,7 @@ def main(argv=None, timed_steps=None):
     rep["train"]["wall_s"] = round(time.perf_counter() - t0, 2)
     rep["train"]["curve"] = curve
     rep["train"]["finite"] = all(c["loss"] == c["loss"] and abs(c["loss"]) < 1e30 for c in curve)
+    rep["along_training"] = along
     ops.check_deferred_errors()
 
     # ---- checkpoint in the reference's format, loaded back as test.py / bench.py --weights load one
