@@ -201,14 +201,26 @@ def main():
     # (per-kernel durations are measured WITHOUT the accuracy guard's check solve: queued behind a step's flow it runs under the next step's first
     # millisecond, beside the global PointNet's convs, whose event pairs would otherwise time the contention instead of the kernel -- the 128 -> 1024
     # layer read 2.2 ms instead of 1.0; the headline above and its own cnf_rk4 launch times are measured with the guard on)
+    # ... and with the global PointNet on the caller's stream: on its own stream (the default schedule) its convs run beside the first
+    # set-abstraction kernels since round 6 (the index chain in front of those got 0.5 ms shorter), and an event pair around a launch then times the
+    # contention: 1.7 ms for the 128 -> 1024 layer against 1.0 ms beside the latency-bound index kernels alone.  The kernel table is about kernels;
+    # the STAGE clocks below come from a second pass on the default schedule with the guard on, as the headline ran.
+    import caspr_amd.models.tpointnet2 as _tp
     guard_tol, model.check_tol = model.check_tol, None
+    gstream_on, _tp.GLOBAL_STREAM = _tp.GLOBAL_STREAM, False
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    model.check_tol = guard_tol
+    model.check_tol, _tp.GLOBAL_STREAM = guard_tol, gstream_on
     ops.TIMING = False
     detail = {k: [a.elapsed_time(b_) for a, b_ in v] for k, v in ops.TIMERS.items() if k.startswith("k:")}
-    stage_timers = {k: list(v) for k, v in ops.TIMERS.items() if not k.startswith("k:")}      # the stage clocks of the two detail steps
+    ops.TIMERS.clear()
+    ops.TIMING, ops.TIMING_ONLY = 1, None
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ops.TIMING = False
+    stage_timers = {k: list(v) for k, v in ops.TIMERS.items() if not k.startswith("k:")}      # the stage clocks of two steps on the headline's own schedule
 
     # ---- the same step on the pure f32-MFMA kernels (sub-block; every rank takes part so the barriers pair up)
     f32_block = None
