@@ -24,8 +24,8 @@ DEBUG = DEBUG or bool(XW_EXP)
 OUT = os.path.join(HERE, ("libcaspr_hip_debug_xw%s.so" % XW_EXP) if XW_EXP else ("libcaspr_hip_debug.so" if DEBUG else "libcaspr_hip.so"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # NO PACKED f32 VALU INSTRUCTIONS in this library (round 6): v_pk_add / v_pk_mul / v_pk_fma_f32 that consume a register an LDS read has just returned
-# were seen to use the register's OLD content in one 16-lane pass when a kernel with VGPR-accumulator MFMAs shares the compute unit (tools/micro/
-# pk_check.hip, profiles/r06_pk_check.txt: farthest-point sampling chose wrong centres beside the encoder's conv).  The compiler had placed ~9,000 of them
+# were seen to use the register's OLD content in one 16-lane pass when another kernel that also executes packed-f32 instructions shares the compute
+# unit (tools/micro/pk_check.hip, profiles/r06_pk_check.txt: farthest-point sampling chose wrong centres beside the encoder's conv; it takes two).  The compiler had placed ~9,000 of them
 # in these kernels on its own (SLP vectorisation, float2 / float4 arithmetic); without them the headline step is as fast (69.0 -> 68.85 ms).  The feature
 # switch is a device feature: the host pass of hipcc prints a "not a recognized feature" note for it, filtered below; audit.py checks the objects.
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]

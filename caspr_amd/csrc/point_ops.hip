@@ -101,9 +101,10 @@ extern "C" int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int
 // NO PACKED f32 ARITHMETIC.  The first form of this kernel computed two distances per v_pk_add / v_pk_mul / v_pk_fma_f32 -- bit-exact on an idle chip,
 // and WRONG beside the global PointNet's conv on another stream: in a few frames, from some round on, a different centre.  tools/micro/pk_check.hip
 // reduced it to this: a packed-f32 operation that consumes a register an LDS read has just returned (here: the selected point's y, behind
-// s_waitcnt lgkmcnt) now and then sees the register's OLD content in one 16-lane pass when a kernel with VGPR-accumulator MFMAs (conv1x1_bf16x6_kernel)
-// shares the compute unit; the same arithmetic in scalar form on the same registers, and the packed form repeated an instruction later, are right
-// (profiles/r06_pk_check.txt: the failing subtraction used y_ref = 0).  The whole library is therefore compiled WITHOUT packed-f32 instructions
+// s_waitcnt lgkmcnt) now and then sees the register's OLD content in one 16-lane pass when ANOTHER kernel that executes packed-f32 instructions
+// (conv1x1_bf16x6_kernel as it was compiled then) shares the compute unit; the same arithmetic in scalar form on the same registers, and the packed
+// form repeated an instruction later, are right (profiles/r06_pk_check.txt: the failing subtraction used y_ref = 0; beside the same conv compiled
+// WITHOUT packed instructions the test kernel is clean: it takes two).  The whole library is therefore compiled WITHOUT packed-f32 instructions
 // (csrc/build.py: -target-feature -packed-fp32-ops; csrc/audit.py refuses an object that holds one): the compiler had put 9,000 of them into the
 // product kernels on its own (SLP vectorisation), and taking them out cost nothing (the headline step: 69.0 -> 68.85 ms).
 

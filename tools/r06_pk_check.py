@@ -18,6 +18,25 @@ LAY = {"conv128_1024 stats only": (mk(16, 20480, 128, 1024), False), "conv128_10
        "conv1600_1600": (mk(16, 20480, 1600, 1600), True)}
 side = torch.cuda.Stream()
 seen_detail = []
+if "--f64" in sys.argv:
+    # the same question for f64 VALU arithmetic on a register pair ds_read_b64 has just returned (tools/micro/f64_check.hip): first evaluation vs a second
+    # one a few instructions later
+    F = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libf64_check.so"))
+    F.f64_check.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for which in ["alone"] + list(LAY):
+        res = []
+        for r in range(6):
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                assert F.f64_check(pts.data_ptr(), 160, 512, 4000, bad.data_ptr(), side.cuda_stream) == 0
+            if which != "alone":
+                Ld, wr = LAY[which]
+                keep = ops.conv1x1_gn(Ld["pw"], Ld["bias"], Ld["x"], Ld["g"], Ld["be"], in_scale=Ld["sc"], in_shift=Ld["sh"], in_relu=True, want_max=True, write=wr)
+            torch.cuda.synchronize()
+            res.append(int(bad))
+        print("f64 arithmetic behind ds_read_b64, first vs repeated evaluation, %-28s: disagreements per run %s" % (which, res), flush=True)
+    sys.exit(0)
 for which in ["alone"] + list(LAY):
     res = []
     for r in range(6):
