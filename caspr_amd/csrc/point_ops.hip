@@ -79,6 +79,47 @@ extern "C" int caspr_prep_input_f32(const float *x, int BT, int N, int quad, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Copy of a frame's cloud (count floats) into LDS by NT threads.  The plain loop `for (i = tid; i < count; i += NT) dst[i] = src[i]` compiles to one
+// 4-byte load per thread and trip with s_waitcnt vmcnt(0) behind it: 24-48 dependent global round trips in front of every index kernel (a fifth of the
+// thread-per-centre ball query's time).  Here: 16-byte loads, four in flight per thread, when the frame is 16-byte aligned (n % 4 == 0 for every cloud of
+// the model); scalar loads, eight in flight, otherwise.  Same bytes in the same places.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void stage_cloud(float *__restrict__ dst, const float *__restrict__ src, int count, int tid)
+{
+    if ((count & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15ull) == 0ull) {
+        const int n4 = count >> 2;
+        for (int i = tid; i < n4; i += 4 * NT) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = i + u * NT;
+                v[u] = j < n4 ? ld4(src + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = i + u * NT;
+                if (j < n4) st4(dst + 4 * j, v[u]);
+            }
+        }
+    } else {
+        for (int i = tid; i < count; i += 8 * NT) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = i + u * NT;
+                v[u] = j < count ? src[j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = i + u * NT;
+                if (j < count) dst[j] = v[u];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // farthest point sampling (pointnet2.py:384).  One 256-thread workgroup per cloud; the cloud and
 // the running min-distance live in registers (PPT points per thread, point k = tid + 256*i), a
 // copy of xyz in LDS serves the "last selected point" broadcast.  Arg-max key = 64-bit
@@ -153,7 +194,7 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
     unsigned long long *slot = reinterpret_cast<unsigned long long *>(smem + ((n * 3 + 3) & ~3));  // [2][4]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *p = xyz + (long)b * n * 3;
-    for (int i = tid; i < n * 3; i += 256) sx[i] = p[i];
+    stage_cloud<256>(sx, p, n * 3, tid);
     __syncthreads();
 
     constexpr int NP = (PPT + 1) / 2;          // slots come in pairs (PPT = 1: the second one never holds a point)
@@ -398,7 +439,7 @@ __global__ __launch_bounds__(256) void ball_query_lds_kernel(const float *__rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const float *p = xyz + (long)b * n * 3;
-    for (int i = threadIdx.x; i < n * 3; i += 256) sp[i] = p[i];
+    stage_cloud<256>(sp, p, n * 3, threadIdx.x);
     __syncthreads();
     const int m0 = (blockIdx.x * 4 + wave) * BQ_CPW;
     for (int cc = 0; cc < BQ_CPW; ++cc) {
@@ -443,7 +484,7 @@ __global__ __launch_bounds__(256) void ball_query2_lds_kernel(const float *__res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const float *p = xyz + (long)b * n * 3;
-    for (int i = threadIdx.x; i < n * 3; i += 256) sp[i] = p[i];
+    stage_cloud<256>(sp, p, n * 3, threadIdx.x);
     __syncthreads();
     const int m0 = (blockIdx.x * 4 + wave) * BQ_CPW;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -484,6 +525,10 @@ __global__ __launch_bounds__(256) void ball_query2_lds_kernel(const float *__res
     }
 }
 
+// (Round 6 also built a ONE-CENTRE-PER-LANE form -- the wave walks the cloud point by point through LDS broadcast reads, every lane appends hits to rows
+// of its own, no ballots: ~17 instructions per 64 (centre, point) pairs against ~40 here -- bit-identical rows, and SLOWER: 393 us for the first level's
+// pair of queries against 322 us for the kernel above, 260 / 291 against 164 / 193 us for single queries, 0.1-0.2 ms on the whole step
+// (gpurun r06aj).  The instruction count is not what bounds this kernel; the form was dropped.  What DID help every index kernel is stage_cloud.)
 extern "C" int caspr_ball_query2_f32(const float *xyz, const float *new_xyz, int B, int n, int M, float radius_a, int ns_a, int32_t *idx_a,
                                      float radius_b, int ns_b, int32_t *idx_b, void *stream)
 {
@@ -577,7 +622,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__
     extern __shared__ __attribute__((aligned(16))) float sk[];
     const int b = blockIdx.y;
     const float *kp = known + (long)b * m * 3;
-    for (int i = threadIdx.x; i < m * 3; i += 256) sk[i] = kp[i];
+    stage_cloud<256>(sk, kp, m * 3, threadIdx.x);
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
