@@ -30,23 +30,18 @@ class PointNetfeat(nn.Module):
         conv = getattr(self, name)
         return self._cache.get(name, [conv.weight], lambda: ops.PackedWeight(conv.weight.detach()[:, :, 0].contiguous()))
 
-    def features(self, x_pm, y1_out=None, defer_last=False):
+    def features(self, x_pm, y1_out=None):
         """x_pm (B,P,4) point-major.  Returns (pointfeat Lazy (B,P,64) = relu(bn1(conv1)), gmax (B,1024)).
-        y1_out: optional (B,P,64) column slice to hold conv1's raw output.
-        defer_last: return (pointfeat, finish) instead, finish() -> gmax running the last layer (conv3 -> bn3 -> max) when the caller calls it -- on
-        whatever stream is current then (the same launches either way: same bits)."""
+        y1_out: optional (B,P,64) column slice to hold conv1's raw output."""
         c1, c2, c3 = self.conv1, self.conv2, self.conv3
         y1 = ops.conv1x1(self._packed("conv1"), c1.bias, x_pm, out=y1_out)                     # pointnet.py:37
         s1, t1 = ops.gn_stats(y1, c1.out_channels, self.bn1.weight, self.bn1.bias)
         y2, s2, t2 = ops.conv1x1_gn(self._packed("conv2"), c2.bias, y1, self.bn2.weight, self.bn2.bias,
                                     in_scale=s1, in_shift=t1, in_relu=True)                     # :39, statistics in the conv's epilogue
-
-        def finish():
-            # conv3 -> bn3 -> max over points (:40-42): only the pooled maximum is used, so the 1024-channel output is not stored
-            return ops.conv1x1_gn(self._packed("conv3"), c3.bias, y2, self.bn3.weight, self.bn3.bias, want_max=True, write=False,
-                                  in_scale=s2, in_shift=t2, in_relu=True)[3]
-        pf = Lazy(y1, c1.out_channels, s1, t1, True)
-        return (pf, finish) if defer_last else (pf, finish())
+        # conv3 -> bn3 -> max over points (:40-42): only the pooled maximum is used, so the 1024-channel output is not stored
+        _, _, _, gmax = ops.conv1x1_gn(self._packed("conv3"), c3.bias, y2, self.bn3.weight, self.bn3.bias, want_max=True, write=False,
+                                       in_scale=s2, in_shift=t2, in_relu=True)
+        return Lazy(y1, c1.out_channels, s1, t1, True), gmax
 
     def forward(self, x):
         """Reference signature: x (B,input_dim,P) channels-first -> (B, out_size + 64, P)."""

@@ -513,7 +513,7 @@ class PointNet2feat(nn.Module):
             out["nn_ready"].record()
         return out
 
-    def run(self, xyz, feat, C, out=None, record=None, idx=None, feat_kind=0, stop_before_last=False, after_level=None):
+    def run(self, xyz, feat, C, out=None, record=None, idx=None, feat_kind=0, stop_before_last=False):
         """Point-major core: xyz (B,n,3), feat (B,n,ldf) with C valid channels.  -> (B,n,num_classes)
         written into `out` (may be a column slice of a wider buffer) if given.  `idx` = precomputed self.indices(xyz);
         feat_kind: what the input features of the FIRST level are (ops.FEAT_QUAD | ops.FEAT_PAIRS), see ops.sa_mlp_max.
@@ -540,8 +540,6 @@ class PointNet2feat(nn.Module):
             xyz_list.append(xyz)
             feat_list.append(feat[:, :, :C] if lo_from[l] else feat)                           # consumers other than the next level: hi only
             ch_list.append(C)
-            if after_level is not None and l in after_level:
-                after_level[l]()            # (a caller's hook behind level l's launches: TPointNet2 queues the global branch's last conv there)
         prev = Lazy(feat_list[-1], ch_list[-1])
         target = -2
         if idx.get("nn_ready") is not None:

@@ -25,7 +25,6 @@ from .pointnet2 import PointNet2feat as PointNet2
 # early, this HBM-bound conv holds back the three small kernels the flow waits for (0.7 ms between the encoder's last statistics and the flow's
 # first workgroup) -- but queued late it runs entirely in front of the flow: 69.64 -> 69.97 ms.  Early it is.
 LATE_TNOCS_LAUNCH = False
-GLOBAL_LAST_LATE = True              # ... and its last layer behind the fourth set-abstraction level (TPointNet2.forward)
 GLOBAL_STREAM = _cfg.global_stream   # the global PointNet on a stream of its own beside the index chain and the first set-abstraction kernels
 # the head's FIRST layer (576 -> 1600) with its 64-channel remainder beside the main tiles too (ops.conv1x1_gn_tail_beside; no reserved units here:
 # the remainder shares them with the persistent kernel).  Measured and NOT adopted (tools/head1_tail_ab.py, outputs identical): 67.30 / 66.82 / 66.41 ms
@@ -183,26 +182,12 @@ class TPointNet2(nn.Module):
         if GLOBAL_STREAM and self.record is None and not torch.cuda.is_current_stream_capturing():
             gstream = self._side_stream(x.device, 1)
             gstream.wait_stream(main)
-        # GLOBAL_LAST_LATE (round 6): the branch's last layer (128 -> 1024 + max: 1.0 ms of bf16 MFMAs, two thirds of the branch) is queued on that stream
-        # behind the FOURTH set-abstraction level instead of at the start: the index chain in front of the first level is 0.9 ms now (1.7 in round 5),
-        # so the whole branch no longer fits beside it and its tail ran INTO the first levels' kernels (and the accuracy guard's check of the previous
-        # call); the coarsest level and the first feature-propagation layers that follow level four are small launches that leave most of the chip idle
-        late = None
         with (torch.cuda.stream(gstream) if gstream is not None else contextlib.nullcontext()):
             with ops.timed("enc_global_pointnet"):
-                if gstream is not None and GLOBAL_LAST_LATE:
-                    pf, late = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:], defer_last=True)
-                else:
-                    pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
+                pf, gmax = self.global_extract.features(x.view(B, P, 4), y1_out=X1[:, :, L:])
         if gstream is not None:
             X1.record_stream(gstream)
             x.record_stream(gstream)
-        gm = {}
-
-        def last_layer():
-            gstream.wait_stream(torch.cuda.current_stream())        # behind what the caller's stream holds now: the fourth level
-            with torch.cuda.stream(gstream):
-                gm["gmax"] = late()
         # no join here: local_extract.run waits for each level's indices where it uses them
         for t_ in _tensors(idx):
             t_.record_stream(main)
@@ -213,11 +198,7 @@ class TPointNet2(nn.Module):
             # that layer's operand -- the raw output of final_layers[0] with its per-FRAME GroupNorm + ReLU still to be applied
             fold = self.record is None
             loc = self.local_extract.run(xyz, feat, C, out=X1.view(B * T, N, L + S)[:, :, :L], record=self.record, idx=idx, feat_kind=kind,
-                                         stop_before_last=fold, after_level={3: last_layer} if late is not None else None)
-        if late is not None:
-            if "gmax" not in gm:          # (fewer than four levels: nothing called the hook)
-                last_layer()
-            gmax = gm["gmax"]
+                                         stop_before_last=fold)
         if gstream is not None:
             main.wait_stream(gstream)
             for t_ in (pf.scale, pf.shift, gmax):

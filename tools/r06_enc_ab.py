@@ -6,7 +6,7 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from caspr_amd.models import CaSPR
-from caspr_amd.models import pointnet2 as P2, tpointnet2 as TP
+from caspr_amd.models import pointnet2 as P2
 from caspr_amd.utils.synthetic import seeded_state_dict, car_sequences
 dev = torch.device("cuda:0")
 m = CaSPR()
@@ -20,18 +20,21 @@ def run(k):
         for _ in range(k): out = m.reconstruct(x, num_points=2048, timestamps=ts)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / k * 1e3, out
+ref = None
 for guard in (1e-5, None):
     m.check_tol = guard
     for rep in range(3):
-        for late in (False, True):
-            TP.GLOBAL_LAST_LATE = late
+        for pair, long_main in ((False, False), (True, False), (False, True), (True, True)):
+            P2.BALL_QUERY_PAIR, P2.LONG_SCALE_ON_MAIN = pair, long_main
             run(2)
             ms, out = run(10)
-            print("guard %-5s rep %d  global branch's last conv behind level four: %-5s : %.3f ms/step" % (guard, rep, late, ms), flush=True)
+            print("guard %-5s rep %d  ball_query_pair %-5s long_scale_on_main %-5s : %.3f ms/step" % (guard, rep, pair, long_main, ms), flush=True)
+P2.BALL_QUERY_PAIR, P2.LONG_SCALE_ON_MAIN = True, True
+# same outputs whatever the schedule (same base samples)
 torch.manual_seed(0); y = torch.randn(16, 10, 2048, 3, device=dev)
 outs = []
-for late in (False, True):
-    TP.GLOBAL_LAST_LATE = late
+for pair, long_main in ((False, False), (True, True)):
+    P2.BALL_QUERY_PAIR, P2.LONG_SCALE_ON_MAIN = pair, long_main
     with torch.no_grad():
         o = m.reconstruct(x, num_points=2048, timestamps=ts, y=y)
     torch.cuda.synchronize()
